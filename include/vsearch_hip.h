@@ -1,0 +1,179 @@
+/*
+ * vsearch_hip.h -- C ABI of libvsearch_hip.so: the MI355X (gfx950) implementation of vsearch's
+ * vocabulary-space retrieval hot path.
+ *
+ * The reference (jzhoubu/vsearch @ 2024-12-18) is pure Python and has no FFI layer; the boundary it
+ * offers is its Python API (src/ir/retriever/index.py, retriever.py, src/ir/utils/sparse.py,
+ * src/ir/encoder/vdr.py).  This header is the boundary *below* that API: each entry point names the
+ * reference call site (file:line under the reference root) whose arithmetic it replaces.  The
+ * Python facade in vsearch_amd/ir/ (same class / method names as src/ir) binds these symbols
+ * through ctypes; INTEGRATION.md shows the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - Plain C: pointers + explicit sizes, no C++ or torch types.  Returns 0 (VS_OK) or a negative
+ *     VS_E* code; vs_last_error() gives the thread-local message.
+ *   - Data pointers may be host or device (HIP) pointers; the library detects which
+ *     (hipPointerGetAttributes).  Device pointers must belong to the index's device.
+ *   - `stream` is a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream).  NULL = the
+ *     device's null stream; the call then returns after the work has completed.  With a non-NULL
+ *     stream the call is asynchronous when every in/out pointer is a device pointer.
+ *   - One search at a time per vs_index handle (the handle owns scratch memory).
+ *   - Top-k order is canonical: score descending, then id ascending (torch.topk leaves ties
+ *     unspecified, index.py:92).  fp32 accumulation order differs from MKL/cuSPARSE: scores agree to
+ *     ~1e-6 relative; on binary index x dyadic query weights they are bit-exact.
+ */
+#ifndef VSEARCH_HIP_H
+#define VSEARCH_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VS_API __attribute__((visibility("default")))
+
+/* error codes */
+#define VS_OK            0
+#define VS_EINVAL       -1   /* bad argument (Python facade: ValueError / TypeError)                   */
+#define VS_ERANGE       -2   /* k > number of rows: torch.topk's RuntimeError (index.py:92)           */
+#define VS_ENOMEM       -3   /* host or device allocation failed                                      */
+#define VS_EHIP         -4   /* HIP runtime error (message has the hipError string)                   */
+#define VS_EUNSUPPORTED -5   /* e.g. n_cols > 65535                                                   */
+#define VS_ENODEVICE    -6   /* no usable gfx950 device: the product path never falls back to the CPU */
+
+/* element types */
+#define VS_F32   0
+#define VS_F16   1
+#define VS_I32   2
+#define VS_I64   3
+#define VS_U16   4
+#define VS_U8    5
+#define VS_NONE -1           /* "no values": binary (bag-of-token) index                              */
+
+/* index kinds (IndexType, index.py:20-23) */
+#define VS_KIND_DENSE 0
+#define VS_KIND_CSR   1      /* SparseIndex / BoTIndex                                                */
+
+typedef struct vs_index vs_index;
+
+typedef struct vs_index_info_t {
+    int32_t kind;            /* VS_KIND_*                                                             */
+    int32_t store_dtype;     /* VS_F32 | VS_F16 | VS_NONE (binary)                                    */
+    int64_t n_rows;
+    int32_t n_cols;
+    int32_t device;
+    int64_t nnz;             /* logical non-zeros (CSR) or n_rows*n_cols (dense)                      */
+    int64_t n_packets;       /* CSR device format: 8-nnz packets incl. row padding                    */
+    int64_t device_bytes;    /* bytes of the device-resident index                                    */
+    int64_t bytes_per_pass;  /* algorithmic HBM bytes one scoring pass streams      */
+    int32_t lanes_per_row;   /* CSR scan geometry                                                     */
+    int32_t queries_per_pass;/* Qt of the scan kernel that search() would pick                        */
+} vs_index_info_t;
+
+/* ---- library ------------------------------------------------------------------------------- */
+VS_API int          vs_version(void);
+VS_API const char*  vs_last_error(void);
+VS_API int          vs_device_count(int32_t* out);
+
+/* ---- index containers: Index / SparseIndex / BoTIndex (index.py:25-218) ---------------------- */
+
+/* Builds the device-resident CSR index from a torch/scipy-style CSR (what SparseIndex.init_index
+ * assembles at index.py:163-179 and build_index at retriever.py:299-312).  Inputs are copied; the
+ * library owns its own device format (row-padded 8-nnz packets: uint16 column ids, fp32/fp16/no
+ * values, uint32 packet row pointers).
+ *   rowptr_dtype, col_dtype: VS_I32 | VS_I64.   val_dtype: VS_F32 | VS_F16; values == NULL -> binary.
+ *   store_dtype: VS_F32 | VS_F16 | VS_NONE -- dtype streamed by search (fp16 = the reference's
+ *   `fp16=True` load default, index.py:135,176; VS_NONE asserts every value == 1).              */
+VS_API int vs_index_create_csr(const void* rowptr, int rowptr_dtype, const void* colidx, int col_dtype,
+                               const void* values, int val_dtype, int store_dtype,
+                               int64_t n_rows, int32_t n_cols, int device, vs_index** out);
+
+/* Dense index (Index.vector = [n_rows, n_cols], index.py:25-44, retriever.py:292-297). */
+VS_API int vs_index_create_dense(const void* mat, int dtype, int store_dtype, int64_t n_rows, int32_t n_cols,
+                                 int64_t ld, int device, vs_index** out);
+
+/* Synthetic corpus generated straight into the device format (bench / tests; no reference
+ * counterpart).  Rows are the pure function of (seed, global row id) defined in
+ * vsearch_amd/synth.py; this shard holds rows [row0, row0 + n_rows).
+ *   kind: 0 = fixed `nnz` per row with values, 1 = bag-of-token lengths (binary).               */
+VS_API int vs_index_create_synthetic(uint64_t seed, int64_t row0, int64_t n_rows, int32_t n_cols, int32_t nnz,
+                                     int kind, int val_law, int store_dtype, int device, vs_index** out);
+
+/* Index.search (index.py:88-94):  q.to(device).type(vector.dtype); matmul(q, vector.t()); topk(k).
+ *   q: dense [B, n_cols] row-major with leading dimension ldq (elements), q_dtype VS_F32 | VS_F16.
+ *   out_ids [B,k] int64 (row ids + id_offset), out_scores [B,k] fp32, descending.
+ *   Returns VS_ERANGE when k > n_rows (the reference raises RuntimeError there).                 */
+VS_API int vs_index_search(vs_index* index, const void* q, int q_dtype, int64_t ldq, int32_t B, int32_t k,
+                           int64_t id_offset, int64_t* out_ids, float* out_scores, void* stream);
+
+/* Dense score matrix [B, n_rows] fp32 -- the intermediate index.py:91 materialises.  Used by the
+ * parity tests to check every score, not just the top-k.                                         */
+VS_API int vs_index_scores(vs_index* index, const void* q, int q_dtype, int64_t ldq, int32_t B,
+                           float* out_scores, void* stream);
+
+VS_API int  vs_index_info(const vs_index* index, vs_index_info_t* out);
+
+/* SparseIndex.save (index.py:181-202) needs crow/col/values back: int64 rowptr [n_rows+1], int64
+ * colidx [nnz], values [nnz] as val_dtype (VS_F32 | VS_F16).  Pass NULL colidx/values to get rowptr
+ * only (to size the other two).                                                                  */
+VS_API int  vs_index_export_csr(const vs_index* index, int64_t* rowptr, int64_t* colidx, void* values, int val_dtype);
+VS_API int  vs_index_export_dense(const vs_index* index, void* mat, int dtype, int64_t ld);
+VS_API void vs_index_destroy(vs_index* index);
+
+/* Row-sharded search, merge step (new in this build): candidates gathered from
+ * all shards ([B, n_cand] global ids + scores, e.g. after an RCCL all-gather) -> canonical top-k. */
+VS_API int vs_merge_topk(const int64_t* cand_ids, const float* cand_scores, int32_t B, int64_t n_cand, int32_t k,
+                         int64_t* out_ids, float* out_scores, int device, void* stream);
+
+/* ---- sparsify: src/ir/utils/sparse.py + the tail of VDREncoder.embed (vdr.py:152-169) -------- */
+
+/* build_topk_mask (sparse.py:8-14): mask[b, c] = 1 iff x[b, c] is among the k largest of row b
+ * (ties at the k-th value: lower column wins).  x: [B, V] fp32 device/host, mask: [B, V] uint8.    */
+VS_API int vs_topk_mask(const float* x, int32_t B, int32_t V, int64_t ld, int32_t k, uint8_t* mask, int device, void* stream);
+
+/* build_bow_mask (sparse.py:21-29): multi-hot of token ids over `vocab`, first `shift` columns
+ * dropped, optional L2 row norm.  ids: [B, L] int64; out: [B, vocab - shift] fp32.               */
+VS_API int vs_bow_mask(const int64_t* ids, int32_t B, int32_t L, int32_t vocab, int32_t shift, int norm,
+                       float* out, int device, void* stream);
+
+/* embed()'s mask stage (vdr.py:152-169), in place on emb [B, V = vocab - shift] (leading dim ld):
+ *   bow != 0          -> emb = bow_mask(ids)
+ *   topk == 0         -> keep only lexical dims;  topk < 0 -> keep all;  else keep top-k
+ *   activate_lexical  -> mask |= bow_mask(ids)                                                   */
+VS_API int vs_embed_mask(float* emb, int64_t ld, const int64_t* ids, int32_t B, int32_t L, int32_t vocab, int32_t shift,
+                         int32_t topk, int activate_lexical, int bow, int device, void* stream);
+
+/* Tensor.to_sparse_csr() (retriever.py:304): non-zeros of dense x [B, V] as CSR -- int64 rowptr
+ * [B+1], int32 cols / fp32 vals with room for `cap` entries.  cols == NULL: rowptr only (two-call
+ * protocol), so build_index can emit CSR batch by batch and never hold the dense [N, V] matrix
+ * (retriever.py:281).                                                                            */
+VS_API int vs_dense_to_csr(const float* x, int32_t B, int32_t V, int64_t ld, int64_t* rowptr, int32_t* cols, float* vals,
+                           int64_t cap, int device, void* stream);
+
+/* Encoder head tail (vdr.py:73-75): elu1p then max over L of logits [B, L, V] -> out [B, V]
+ * (computed as elu1p(max) -- elu1p is monotone; pad positions are pooled like the reference).    */
+VS_API int vs_head_pool(const float* logits, int32_t B, int32_t L, int32_t V, float* out, int device, void* stream);
+
+/* elu1p (sparse.py:6) elementwise. */
+VS_API int vs_elu1p(const float* x, int64_t n, float* out, int device, void* stream);
+
+/* ---- bag-of-token builder: Retriever._build_bot_vectors (retriever.py:208-253) --------------- */
+/* tokens: flat int32 token ids of all docs (already truncated by the tokenizer), offsets [n_docs+1].
+ * Per doc: first-`max_token`-unique cap (0 = off; counts every id incl. [CLS], index_utils.py:11-21),
+ * multi-hot, drop ids < shift, sorted columns.  Two-call protocol: out_cols == NULL fills only
+ * out_rowptr (int64 [n_docs+1]).  Host pointers only (tokenisation is host work in the reference). */
+VS_API int vs_bot_build(const int32_t* tokens, const int64_t* offsets, int64_t n_docs, int32_t vocab, int32_t shift,
+                        int32_t max_token, int64_t* out_rowptr, int32_t* out_cols);
+
+/* ---- measurement hooks (bench.py) ----------------------------------------------------------- */
+/* When enabled, every launch of the scoring kernels is bracketed by hipEvents on the launch
+ * stream; vs_profile_read returns accumulated device time and launch count per kernel name.      */
+VS_API int vs_profile_enable(int on);
+VS_API int vs_profile_reset(void);
+VS_API int vs_profile_read(const char* kernel, double* total_ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VSEARCH_HIP_H */

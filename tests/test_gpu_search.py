@@ -1,0 +1,205 @@
+"""GPU parity tests of the search hot path (index.py:88-94) through the C ABI -- run on MI355X.
+
+HIP path vs (a) the committed golden vectors captured from the reference and (b) the CPU oracle on
+the same seeded inputs.  Bars: binary index x dyadic queries bit-exact; fp32 paths 1e-4 relative
+(north_star), ids identical modulo (near-)ties.
+"""
+import numpy as np
+import pytest
+
+import oracle
+from oracle import compare
+from conftest import V
+from vsearch_amd import synth
+from vsearch_amd import _native as nat
+from vsearch_amd.device_index import DeviceIndex, merge_topk
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4   # fp32 score tolerance stated by BASELINE.json north_star
+
+
+@pytest.fixture(scope="module")
+def sparse2000():
+    ip, ix, d = oracle.synth_csr(0, 0, 2000)
+    return ip, ix, d, DeviceIndex.from_csr(ip, ix, d, V)
+
+
+def test_library_reports_gfx950_device():
+    assert nat.device_count() >= 1
+    assert nat.lib().vs_version() >= 100
+
+
+@pytest.mark.parametrize("k", [1, 100, 128, 129, 2000])
+def test_sparse_fp32_vs_golden_and_oracle(golden, sparse2000, k):
+    ip, ix, d, idx = sparse2000
+    g = golden("search_sparse_n2000")
+    q = oracle.synth_queries(1, 8)
+    ids, sc = idx.search(q, k)
+    o_ids, o_sc, allsc = oracle.csr_search(ip, ix, d, V, q, k, acc64=True, return_all=True)
+    compare.check_topk_valid(allsc, ids, sc, rtol=RTOL)
+    compare.compare_topk(o_ids, o_sc, ids, sc, rtol=RTOL)
+    if f"ids_k{k}" in g.files:
+        compare.compare_topk(g[f"ids_k{k}"], g[f"scores_k{k}"], ids, sc, rtol=RTOL)
+        assert compare.recall_at_k(g[f"ids_k{k}"], ids) >= 0.999
+
+
+def test_sparse_all_scores_match_oracle(sparse2000):
+    ip, ix, d, idx = sparse2000
+    q = oracle.synth_queries(1, 8)
+    got = idx.scores(q)
+    _, _, want = oracle.csr_search(ip, ix, d, V, q, 1, acc64=True, return_all=True)
+    np.testing.assert_allclose(got, want, rtol=2e-6, atol=1e-6)
+
+
+def test_sparse_n20000_golden(golden):
+    g = golden("search_sparse_n20000")
+    ip, ix, d = oracle.synth_csr(0, 0, 20000)
+    idx = DeviceIndex.from_csr(ip, ix, d, V)
+    q = oracle.synth_queries(1, 32)
+    ids, sc = idx.search(q, 100)
+    compare.compare_topk(g["ids_k100"], g["scores_k100"], ids, sc, rtol=RTOL)
+    _, _, allsc = oracle.csr_search(ip, ix, d, V, q, 100, acc64=True, return_all=True)
+    compare.check_topk_valid(allsc, ids, sc, rtol=RTOL)
+
+
+def test_k_gt_n_raises_like_topk(sparse2000):
+    *_, idx = sparse2000
+    with pytest.raises(RuntimeError, match="out of range"):
+        idx.search(oracle.synth_queries(1, 2), 2001)
+
+
+def test_multipass_large_k():
+    """k > 2048: repeated passes with an exclusive upper-bound key; result = full canonical ranking."""
+    n = 5000
+    ip, ix, d = oracle.synth_csr(2, 0, n, V, 64)
+    idx = DeviceIndex.from_csr(ip, ix, d, V)
+    q = oracle.synth_queries(6, 3)
+    ids, sc = idx.search(q, n)
+    _, _, allsc = oracle.csr_search(ip, ix, d, V, q, 1, acc64=True, return_all=True)
+    compare.check_topk_valid(allsc, ids, sc, rtol=RTOL)
+    assert all(len(set(r.tolist())) == n for r in ids)
+
+
+@pytest.mark.parametrize("tag,exact", [("f32", False), ("dyadic", True)])
+def test_bot_binary_index(golden, tag, exact):
+    g = golden("search_bot")
+    n, b = int(g["n"]), int(g["b"])
+    ip, ix, _ = oracle.synth_csr(int(g["index_seed"]), 0, n, V, int(g["nnz"]), synth.KIND_BOT)
+    idx = DeviceIndex.from_csr(ip, ix, None, V)
+    assert idx.info().store_dtype == nat.VS_NONE
+    seed = int(g["query_seeds"][1 if exact else 0])
+    q = oracle.synth_queries(seed, b, val_law=synth.VAL_DYADIC if exact else synth.VAL_GRID)
+    for k in (10, 100):
+        ids, sc = idx.search(q, k)
+        compare.compare_topk(g[f"{tag}_ids_k{k}"], g[f"{tag}_scores_k{k}"], ids, sc, rtol=RTOL, exact=exact)
+        o_ids, o_sc, allsc = oracle.csr_search(ip, ix, None, V, q, k, return_all=True)
+        compare.check_topk_valid(allsc, ids, sc, rtol=RTOL, exact=exact, canonical=exact)
+        if exact:       # bit-exact scores AND identical ids in canonical order
+            assert (ids == o_ids).all() and (sc == o_sc).all()
+    if exact:
+        assert (idx.scores(q) == allsc).all()
+
+
+def test_fp16_index_rounds_query_and_values():
+    """fp16 store = the reference's `fp16=True` load default (index.py:135,176) + q.type(fp16) (index.py:89)."""
+    n = 3000
+    ip, ix, d = oracle.synth_csr(4, 0, n)
+    idx = DeviceIndex.from_csr(ip, ix, d, V, store_dtype=nat.VS_F16)
+    q = oracle.synth_queries(5, 4)
+    ids, sc = idx.search(q, 50)
+    d16 = d.astype(np.float16).astype(np.float32)
+    q16 = q.astype(np.float16).astype(np.float32)
+    o_ids, o_sc, allsc = oracle.csr_search(ip, ix, d16, V, q16, 50, acc64=True, return_all=True)
+    compare.check_topk_valid(allsc, ids, sc, rtol=RTOL)
+    compare.compare_topk(o_ids, o_sc, ids, sc, rtol=RTOL)
+
+
+def test_export_roundtrip_and_ragged_rows():
+    rng = np.random.default_rng(0)
+    lens = rng.integers(0, 40, size=300)
+    lens[[0, 17, 299]] = 0                                   # empty rows, incl. first and last
+    lens[5] = 1000
+    ip = np.zeros(301, np.int64)
+    np.cumsum(lens, out=ip[1:])
+    ix = np.concatenate([np.sort(rng.choice(V, size=l, replace=False)) for l in lens]).astype(np.int32)
+    d = rng.uniform(-2, 2, size=ix.size).astype(np.float32)
+    idx = DeviceIndex.from_csr(ip, ix, d, V)
+    e_ip, e_ix, e_d = idx.export_csr()
+    assert (e_ip == ip).all() and (e_ix == ix).all() and (e_d == d).all()
+    q = rng.uniform(-1, 1, size=(5, V)).astype(np.float32)   # dense query with negative weights
+    ids, sc = idx.search(q, 300)
+    _, _, allsc = oracle.csr_search(ip, ix, d, V, q, 1, acc64=True, return_all=True)
+    np.testing.assert_allclose(idx.scores(q), allsc, rtol=1e-5, atol=1e-5)
+    compare.check_topk_valid(allsc, ids, sc, rtol=RTOL)
+    # int64 indices / int32 indptr variants
+    idx2 = DeviceIndex.from_csr(ip.astype(np.int32), ix.astype(np.int64), d, V)
+    assert (idx2.export_csr()[1] == ix).all()
+
+
+def test_create_rejects_bad_input():
+    ip = np.array([0, 2], np.int64)
+    with pytest.raises(ValueError):
+        DeviceIndex.from_csr(ip, np.array([0, V], np.int32), np.ones(2, np.float32), V)     # column out of range
+    with pytest.raises(NotImplementedError):
+        DeviceIndex.from_csr(ip, np.array([0, 1], np.int32), np.ones(2, np.float32), 70000)  # uint16 column ids
+    with pytest.raises(ValueError):
+        DeviceIndex.from_csr(ip, np.array([0, 1], np.int32), np.array([1, 2], np.float32), V, store_dtype=nat.VS_NONE)
+
+
+@pytest.mark.parametrize("kind,nnz,law,store", [(synth.KIND_VDR, 768, synth.VAL_GRID, nat.VS_F32),
+                                                (synth.KIND_BOT, 86, synth.VAL_ONE, nat.VS_NONE),
+                                                (synth.KIND_VDR, 100, synth.VAL_DYADIC, nat.VS_F32)])
+def test_device_synth_matches_host_twins(kind, nnz, law, store):
+    idx = DeviceIndex.synthetic(9, 12345, 700, V, nnz, kind, law, store)
+    ip, ix, d = oracle.synth_csr(9, 12345, 700, V, nnz, kind, law)
+    e_ip, e_ix, e_d = idx.export_csr()
+    assert (e_ip == ip).all() and (e_ix == ix).all() and (e_d == d).all()
+
+
+def test_dense_index_vs_golden(golden):
+    g = golden("search_dense")
+    n, b = int(g["n"]), int(g["b"])
+    ip, ix, d = oracle.synth_csr(0, 0, n)
+    dense = np.zeros((n, V), np.float32)
+    dense[np.repeat(np.arange(n), 768), ix] = d
+    idx = DeviceIndex.from_dense(dense)
+    q = oracle.synth_queries(1, b)
+    for k in (1, 100):
+        ids, sc = idx.search(q, k)
+        compare.compare_topk(g[f"ids_k{k}"], g[f"scores_k{k}"], ids, sc, rtol=RTOL)
+    n2, b2, s1, s2 = g["full_shape"].tolist()
+    m2, q2 = synth.dense_uniform(s1, (n2, V), 0.0, 1.0), synth.dense_uniform(s2, (b2, V), 0.0, 1.0)
+    idx2 = DeviceIndex.from_dense(m2)
+    ids, sc = idx2.search(q2, 50)
+    # 29 523-term fp32 dot products: summation order moves scores by ~1e-6 relative (reference GEMM vs ours)
+    compare.compare_topk(g["full_ids_k50"], g["full_scores_k50"], ids, sc, rtol=RTOL, tie_rtol=5e-6)
+    want = q2.astype(np.float64) @ m2.astype(np.float64).T
+    np.testing.assert_allclose(idx2.scores(q2), want, rtol=2e-5)
+    assert (idx2.export_dense() == m2).all()
+    with pytest.raises(RuntimeError):
+        idx2.search(q2, n2 + 1)
+
+
+def test_merge_topk_matches_oracle():
+    rng = np.random.default_rng(3)
+    B, n, k = 7, 800, 100
+    ids = np.stack([rng.permutation(100000)[:n] for _ in range(B)]).astype(np.int64)
+    sc = rng.integers(0, 50, size=(B, n)).astype(np.float32) / 8      # many exact ties
+    got = merge_topk(ids, sc, k)
+    want = oracle.merge_topk(ids, sc, k)
+    assert (got[0] == want[0]).all() and (got[1] == want[1]).all()
+
+
+def test_torch_device_tensors_roundtrip(sparse2000):
+    import torch
+    ip, ix, d, idx = sparse2000
+    q = torch.from_numpy(oracle.synth_queries(1, 8)).cuda()
+    ids, sc = idx.search(q, 100)
+    assert ids.is_cuda and ids.dtype == torch.int64 and sc.dtype == torch.float32
+    ids_h, sc_h = idx.search(q.cpu().numpy(), 100)
+    assert (ids.cpu().numpy() == ids_h).all() and (sc.cpu().numpy() == sc_h).all()
+    qh = q.half()                                            # fp16 query input on an fp32 index
+    ids2, sc2 = idx.search(qh, 10)
+    o_ids, o_sc = oracle.csr_search(ip, ix, d, V, qh.float().cpu().numpy(), 10, acc64=True)
+    compare.compare_topk(o_ids, o_sc, ids2.cpu().numpy(), sc2.cpu().numpy(), rtol=RTOL)

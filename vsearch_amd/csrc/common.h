@@ -1,0 +1,188 @@
+// common.h -- host-side plumbing shared by the translation units of libvsearch_hip.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "vsearch_hip.h"
+
+namespace vs {
+
+// ---- error slot (thread-local; the only global mutable state besides the profiler) ------------
+inline char* err_buf() {
+    static thread_local char buf[512] = {0};
+    return buf;
+}
+inline int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(err_buf(), 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define VS_HIP(call)                                                                                  \
+    do {                                                                                              \
+        hipError_t e__ = (call);                                                                      \
+        if (e__ != hipSuccess)                                                                        \
+            return vs::fail(e__ == hipErrorOutOfMemory ? VS_ENOMEM : VS_EHIP, "%s failed: %s (%s:%d)", \
+                            #call, hipGetErrorString(e__), __FILE__, __LINE__);                       \
+    } while (0)
+
+#define VS_TRY(expr)                 \
+    do {                             \
+        int rc__ = (expr);           \
+        if (rc__ != VS_OK) return rc__; \
+    } while (0)
+
+inline size_t dtype_size(int dt) {
+    switch (dt) {
+        case VS_F32: case VS_I32: return 4;
+        case VS_F16: case VS_U16: return 2;
+        case VS_I64: return 8;
+        case VS_U8: return 1;
+        default: return 0;
+    }
+}
+
+// true if p is a device (or managed) pointer; host pointers unknown to HIP report false.
+inline bool is_device_ptr(const void* p) {
+    if (!p) return false;
+    hipPointerAttribute_t attr;
+    hipError_t e = hipPointerGetAttributes(&attr, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();  // clear sticky "invalid value" for plain host memory
+        return false;
+    }
+    return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+// RAII device buffer
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    int alloc(size_t n) {
+        release();
+        if (n == 0) return VS_OK;
+        hipError_t e = hipMalloc(&p, n);
+        if (e != hipSuccess) {
+            p = nullptr;
+            return fail(VS_ENOMEM, "hipMalloc(%zu bytes) failed: %s", n, hipGetErrorString(e));
+        }
+        bytes = n;
+        return VS_OK;
+    }
+    int reserve(size_t n) { return n <= bytes ? VS_OK : alloc(n); }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// Copies `bytes` from src (host or device) into a device staging buffer if needed and returns a
+// device pointer usable on `stream`.
+inline int to_device(const void* src, size_t bytes, DevBuf& stage, hipStream_t stream, const void** out) {
+    if (is_device_ptr(src)) {
+        *out = src;
+        return VS_OK;
+    }
+    VS_TRY(stage.reserve(bytes));
+    VS_HIP(hipMemcpyAsync(stage.p, src, bytes, hipMemcpyHostToDevice, stream));
+    *out = stage.p;
+    return VS_OK;
+}
+
+// ---- profiler: hipEvent pairs around named kernel launches --------------------------------------
+struct Profiler {
+    struct Pending { std::string name; hipEvent_t a, b; };
+    struct Acc { double ms = 0; int64_t n = 0; };
+    bool on = false;
+    std::mutex mu;
+    std::vector<Pending> pending;
+    std::map<std::string, Acc> acc;
+    static Profiler& get() {
+        static Profiler p;
+        return p;
+    }
+    void begin(const char* name, hipStream_t s) {
+        if (!on) return;
+        Pending p;
+        p.name = name;
+        (void)hipEventCreate(&p.a);
+        (void)hipEventCreate(&p.b);
+        (void)hipEventRecord(p.a, s);
+        std::lock_guard<std::mutex> g(mu);
+        pending.push_back(p);
+    }
+    void end(hipStream_t s) {
+        if (!on) return;
+        std::lock_guard<std::mutex> g(mu);
+        if (!pending.empty()) (void)hipEventRecord(pending.back().b, s);
+    }
+    void drain() {
+        std::lock_guard<std::mutex> g(mu);
+        for (auto& p : pending) {
+            float ms = 0;
+            if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+                acc[p.name].ms += ms;
+                acc[p.name].n += 1;
+            }
+            (void)hipEventDestroy(p.a);
+            (void)hipEventDestroy(p.b);
+        }
+        pending.clear();
+    }
+};
+
+struct ProfScope {
+    hipStream_t s;
+    ProfScope(const char* name, hipStream_t st) : s(st) { Profiler::get().begin(name, st); }
+    ~ProfScope() { Profiler::get().end(s); }
+};
+
+inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+inline uint32_t pow2_ceil(uint32_t x) {
+    uint32_t p = 1;
+    while (p < x) p <<= 1;
+    return p;
+}
+
+}  // namespace vs
+
+// ---- the index handle ---------------------------------------------------------------------------
+struct vs_index {
+    int kind = VS_KIND_CSR;
+    int device = 0;
+    int store_dtype = VS_F32;
+    int64_t n_rows = 0;
+    int32_t n_cols = 0;
+    int64_t nnz = 0;
+    // CSR device format ("packets": 8 nnz, rows padded with column id n_cols whose query weight is 0)
+    int64_t n_packets = 0;
+    int lanes_per_row = 32;
+    vs::DevBuf pk_ptr;   // uint32 [n_rows + 1]
+    vs::DevBuf cols;     // uint16 [n_packets * 8]
+    vs::DevBuf vals;     // fp32 / fp16 [n_packets * 8] (absent for binary)
+    // dense
+    vs::DevBuf mat;      // [n_rows, n_cols] store_dtype
+    // scratch owned by the handle (grow-only)
+    vs::DevBuf ws_q, ws_cand, ws_out_ids, ws_out_scores, ws_misc;
+    int cu_count = 256;
+};

@@ -1,0 +1,694 @@
+// csr_index.hip -- SparseIndex / BoTIndex device container and its search entry points.
+//   reference: src/ir/retriever/index.py:128-218 (containers), :88-94 (search)
+#include "common.h"
+#include "csr_scan.h"
+#include "synth_device.h"
+
+#include <algorithm>
+
+using namespace vs;
+
+// =================================================================================================
+// format conversion kernels
+// =================================================================================================
+namespace {
+
+template <class T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<__half>(__half v) { return __half2float(v); }
+
+// One wave per row: copies the row's (col, val) run into its packet range and pads the tail.
+// flags[0] |= 1: column out of range;  flags[0] |= 2: non-unit value for a binary index.
+template <class RP, class CI, class VT>
+__global__ void fill_packets_kernel(const RP* rowptr, const CI* colidx, const VT* values, int64_t row_begin,
+                                    int64_t row_end, int64_t src_base, const uint32_t* pk_ptr, uint16_t* cols,
+                                    void* vals, int store_dtype, int32_t n_cols, int* flags) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = row_begin + (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= row_end) return;
+    const int64_t s0 = (int64_t)rowptr[row - row_begin] - src_base;
+    const int64_t len = (int64_t)rowptr[row - row_begin + 1] - (int64_t)rowptr[row - row_begin];
+    const int64_t d0 = (int64_t)pk_ptr[row] * 8;
+    const int64_t dn = ((int64_t)pk_ptr[row + 1] - pk_ptr[row]) * 8;
+    int bad = 0;
+    for (int64_t j = lane; j < dn; j += 64) {
+        uint16_t c = (uint16_t)n_cols;
+        float v = 0.f;
+        if (j < len) {
+            const int64_t ci = (int64_t)colidx[s0 + j];
+            if (ci < 0 || ci >= n_cols) bad |= 1;
+            c = (uint16_t)ci;
+            v = values ? to_f32<VT>(values[s0 + j]) : 1.0f;
+            if (store_dtype == VS_NONE && v != 1.0f) bad |= 2;
+        }
+        cols[d0 + j] = c;
+        if (store_dtype == VS_F32) reinterpret_cast<float*>(vals)[d0 + j] = v;
+        else if (store_dtype == VS_F16) reinterpret_cast<__half*>(vals)[d0 + j] = __float2half_rn(v);
+    }
+    if (bad) atomicOr(flags, bad);
+}
+
+// true nnz per row = entries whose column id is not the pad id
+__global__ void row_nnz_kernel(const uint32_t* pk_ptr, const uint16_t* cols, int64_t n_rows, int32_t n_cols, int64_t* out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const int64_t d0 = (int64_t)pk_ptr[row] * 8, d1 = (int64_t)pk_ptr[row + 1] * 8;
+    int cnt = 0;
+    for (int64_t j = d0 + lane; j < d1; j += 64) cnt += cols[j] != (uint16_t)n_cols;
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    if (lane == 0) out[row] = cnt;
+}
+
+template <class VT>
+__global__ void export_rows_kernel(const uint32_t* pk_ptr, const uint16_t* cols, const void* vals, int store_dtype,
+                                   const int64_t* rowptr, int64_t row_begin, int64_t row_end, int64_t dst_base,
+                                   int64_t* colidx, VT* values) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = row_begin + (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= row_end) return;
+    const int64_t d0 = (int64_t)pk_ptr[row] * 8;
+    const int64_t s0 = rowptr[row] - dst_base, len = rowptr[row + 1] - rowptr[row];
+    for (int64_t j = lane; j < len; j += 64) {
+        colidx[s0 + j] = cols[d0 + j];
+        float v = 1.0f;
+        if (store_dtype == VS_F32) v = reinterpret_cast<const float*>(vals)[d0 + j];
+        else if (store_dtype == VS_F16) v = __half2float(reinterpret_cast<const __half*>(vals)[d0 + j]);
+        if constexpr (sizeof(VT) == 4) values[s0 + j] = v;
+        else values[s0 + j] = __float2half_rn(v);
+    }
+}
+
+// Synthetic rows, one wave per row: set the row's distinct columns in an LDS bitmap, then emit them
+// in ascending order by bitmap scan (no sort).  4 waves per workgroup, each with its own bitmap.
+constexpr int kSynthWaves = 4;
+__global__ __launch_bounds__(kSynthWaves * 64) void synth_rows_kernel(uint64_t seed, int64_t row0, int64_t n_rows,
+                                                                     int32_t n_cols, int32_t nnz, int kind, int val_law,
+                                                                     const uint32_t* pk_ptr, uint16_t* cols, void* vals,
+                                                                     int store_dtype) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int words = (n_cols + 31) / 32;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t* bm = reinterpret_cast<uint32_t*>(smem) + (size_t)w * words;
+    const int wpl = (words + 63) / 64;                       // bitmap words per lane
+    for (int64_t r = (int64_t)blockIdx.x * kSynthWaves + w; r < n_rows; r += (int64_t)gridDim.x * kSynthWaves) {
+        const int64_t row = row0 + r;
+        const int64_t len = synth_row_len(seed, row, kind, nnz, n_cols);
+        const uint64_t key = hash3(seed, (uint64_t)row, 0x4B4559ull);
+        for (int i = lane; i < words; i += 64) bm[i] = 0;
+        __builtin_amdgcn_wave_barrier();
+        for (int64_t j = lane; j < len; j += 64) {
+            const uint32_t c = perm_col(key, (uint32_t)j, (uint32_t)n_cols);
+            atomicOr(&bm[c >> 5], 1u << (c & 31));
+        }
+        __builtin_amdgcn_wave_barrier();
+        // lane owns words [lane*wpl, lane*wpl + wpl): count, exclusive-scan across lanes, emit
+        const int wb = lane * wpl, we = min(words, wb + wpl);
+        int mine = 0;
+        for (int i = wb; i < we; ++i) mine += __popc(bm[i]);
+        int incl = mine;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        int pos = incl - mine;
+        const int64_t d0 = (int64_t)pk_ptr[r] * 8;
+        const int64_t dn = ((int64_t)pk_ptr[r + 1] - pk_ptr[r]) * 8;
+        for (int i = wb; i < we; ++i) {
+            uint32_t bits = bm[i];
+            while (bits) {
+                const int b = __ffs(bits) - 1;
+                bits &= bits - 1;
+                const uint32_t c = (uint32_t)i * 32 + b;
+                cols[d0 + pos] = (uint16_t)c;
+                const float v = kind == 1 ? 1.0f : synth_val(seed, row, c, val_law);
+                if (store_dtype == VS_F32) reinterpret_cast<float*>(vals)[d0 + pos] = v;
+                else if (store_dtype == VS_F16) reinterpret_cast<__half*>(vals)[d0 + pos] = __float2half_rn(v);
+                ++pos;
+            }
+        }
+        for (int64_t j = len + lane; j < dn; j += 64) {
+            cols[d0 + j] = (uint16_t)n_cols;
+            if (store_dtype == VS_F32) reinterpret_cast<float*>(vals)[d0 + j] = 0.f;
+            else if (store_dtype == VS_F16) reinterpret_cast<__half*>(vals)[d0 + j] = __float2half_rn(0.f);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// q (fp32 | fp16, leading dim ldq) -> contiguous fp32 [B, n_cols]; round_f16: emulate
+// `q_embs.type(self.vector.dtype)` for an fp16 index (index.py:89).
+template <class T>
+__global__ void prep_queries_kernel(const T* q, int64_t ldq, int32_t B, int32_t n_cols, int round_f16, float* out) {
+    const int64_t n = (int64_t)B * n_cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / n_cols, c = i % n_cols;
+        float v = to_f32<T>(q[b * ldq + c]);
+        if (round_f16) v = __half2float(__float2half_rn(v));
+        out[i] = v;
+    }
+}
+
+__global__ void keys_from_pairs_kernel(const int64_t* ids, const float* scores, int64_t n, uint64_t* keys) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        keys[i] = make_key(scores[i], (uint32_t)ids[i]);
+}
+
+int pick_lanes_per_row(int64_t n_packets, int64_t n_rows) {
+    const double mp = n_rows > 0 ? (double)n_packets / (double)n_rows : 1.0;   // packets per row
+    int g = 4;
+    while (g < 64 && mp / g > 4.0) g <<= 1;   // aim at <= 4 packets per lane per row: 96 packets -> 32 lanes, 11 -> 4
+    return g;
+}
+
+int new_index(int device, vs_index** out) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        (void)hipGetLastError();
+        return fail(VS_ENODEVICE, "no HIP device visible: libvsearch_hip has no CPU fallback");
+    }
+    if (device < 0 || device >= ndev) return fail(VS_EINVAL, "device %d out of range (have %d)", device, ndev);
+    VS_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    VS_HIP(hipGetDeviceProperties(&prop, device));
+    vs_index* idx = new (std::nothrow) vs_index();
+    if (!idx) return fail(VS_ENOMEM, "host allocation failed");
+    idx->device = device;
+    idx->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    *out = idx;
+    return VS_OK;
+}
+
+int alloc_csr_storage(vs_index* idx) {
+    VS_TRY(idx->pk_ptr.alloc((size_t)(idx->n_rows + 1) * 4));
+    VS_TRY(idx->cols.alloc(std::max<size_t>((size_t)idx->n_packets * 16, 16)));
+    if (idx->store_dtype == VS_F32) VS_TRY(idx->vals.alloc(std::max<size_t>((size_t)idx->n_packets * 32, 32)));
+    if (idx->store_dtype == VS_F16) VS_TRY(idx->vals.alloc(std::max<size_t>((size_t)idx->n_packets * 16, 16)));
+    idx->lanes_per_row = pick_lanes_per_row(idx->n_packets, idx->n_rows);
+    return VS_OK;
+}
+
+template <class F>
+int dispatch_rp_ci(int rp_dt, int ci_dt, F&& f) {
+    if (rp_dt == VS_I64 && ci_dt == VS_I64) return f((const int64_t*)nullptr, (const int64_t*)nullptr);
+    if (rp_dt == VS_I64 && ci_dt == VS_I32) return f((const int64_t*)nullptr, (const int32_t*)nullptr);
+    if (rp_dt == VS_I32 && ci_dt == VS_I64) return f((const int32_t*)nullptr, (const int64_t*)nullptr);
+    if (rp_dt == VS_I32 && ci_dt == VS_I32) return f((const int32_t*)nullptr, (const int32_t*)nullptr);
+    return fail(VS_EINVAL, "rowptr/colidx dtype must be VS_I32 or VS_I64");
+}
+
+}  // namespace
+
+// =================================================================================================
+// creation
+// =================================================================================================
+extern "C" int vs_index_create_csr(const void* rowptr, int rowptr_dtype, const void* colidx, int col_dtype,
+                                   const void* values, int val_dtype, int store_dtype, int64_t n_rows, int32_t n_cols,
+                                   int device, vs_index** out) {
+    if (!out) return fail(VS_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (!rowptr || n_rows < 0 || n_cols <= 0) return fail(VS_EINVAL, "bad rowptr / shape");
+    if (n_cols > 65535) return fail(VS_EUNSUPPORTED, "n_cols = %d > 65535: column ids are stored as uint16", n_cols);
+    if (n_rows >= (1ll << 32) - 1) return fail(VS_EUNSUPPORTED, "n_rows must fit in 32 bits");
+    if (store_dtype != VS_F32 && store_dtype != VS_F16 && store_dtype != VS_NONE) return fail(VS_EINVAL, "bad store_dtype");
+    if (values && val_dtype != VS_F32 && val_dtype != VS_F16) return fail(VS_EINVAL, "val_dtype must be VS_F32 or VS_F16");
+    if ((rowptr_dtype != VS_I32 && rowptr_dtype != VS_I64) || (col_dtype != VS_I32 && col_dtype != VS_I64))
+        return fail(VS_EINVAL, "rowptr/colidx dtype must be VS_I32 or VS_I64");
+    vs_index* idx = nullptr;
+    VS_TRY(new_index(device, &idx));
+    struct Guard { vs_index* p; ~Guard() { if (p) vs_index_destroy(p); } } guard{idx};
+    idx->kind = VS_KIND_CSR;
+    idx->store_dtype = store_dtype;
+    idx->n_rows = n_rows;
+    idx->n_cols = n_cols;
+
+    // row pointers on the host (they size everything)
+    const size_t rps = dtype_size(rowptr_dtype);
+    std::vector<char> rp_host((size_t)(n_rows + 1) * rps);
+    if (is_device_ptr(rowptr)) VS_HIP(hipMemcpy(rp_host.data(), rowptr, rp_host.size(), hipMemcpyDeviceToHost));
+    else memcpy(rp_host.data(), rowptr, rp_host.size());
+    auto rp_at = [&](int64_t i) -> int64_t {
+        return rowptr_dtype == VS_I64 ? reinterpret_cast<const int64_t*>(rp_host.data())[i]
+                                      : (int64_t) reinterpret_cast<const int32_t*>(rp_host.data())[i];
+    };
+    std::vector<uint32_t> pk((size_t)n_rows + 1);
+    int64_t acc = 0;
+    pk[0] = 0;
+    for (int64_t r = 0; r < n_rows; ++r) {
+        const int64_t len = rp_at(r + 1) - rp_at(r);
+        if (len < 0 || len > n_cols) return fail(VS_EINVAL, "row %lld has %lld entries (n_cols = %d)", (long long)r, (long long)len, n_cols);
+        acc += (len + 7) / 8;
+        if (acc >= (1ll << 32)) return fail(VS_EUNSUPPORTED, "index exceeds 2^32 packets on one device");
+        pk[r + 1] = (uint32_t)acc;
+    }
+    idx->nnz = rp_at(n_rows) - rp_at(0);
+    idx->n_packets = acc;
+    if (idx->nnz > 0 && !colidx) return fail(VS_EINVAL, "colidx is NULL");
+    VS_TRY(alloc_csr_storage(idx));
+    VS_HIP(hipMemcpy(idx->pk_ptr.p, pk.data(), pk.size() * 4, hipMemcpyHostToDevice));
+
+    DevBuf flags;
+    VS_TRY(flags.alloc(4));
+    VS_HIP(hipMemset(flags.p, 0, 4));
+
+    const bool src_dev = is_device_ptr(colidx);
+    const size_t cis = dtype_size(col_dtype), vsz = values ? dtype_size(val_dtype) : 0;
+    const int64_t kMaxChunkNnz = 32ll << 20;
+    DevBuf st_rp, st_ci, st_v;
+    int64_t r = 0;
+    while (r < n_rows) {
+        int64_t r_end = r + 1;
+        while (r_end < n_rows && rp_at(r_end + 1) - rp_at(r) <= kMaxChunkNnz && r_end - r < (1 << 22)) ++r_end;
+        const int64_t base = rp_at(r), cnt = rp_at(r_end) - base;
+        const void *d_rp = nullptr, *d_ci = nullptr, *d_v = nullptr;
+        // rowptr slice always re-uploaded from the host copy (cheap) so the kernel can index it from 0
+        VS_TRY(st_rp.reserve((size_t)(r_end - r + 1) * rps));
+        VS_HIP(hipMemcpy(st_rp.p, rp_host.data() + (size_t)r * rps, (size_t)(r_end - r + 1) * rps, hipMemcpyHostToDevice));
+        d_rp = st_rp.p;
+        int64_t src_base = base;
+        if (src_dev) {
+            d_ci = colidx;
+            d_v = values;
+            src_base = rp_at(0);                                   // device arrays are indexed absolutely
+        } else if (cnt > 0) {
+            VS_TRY(st_ci.reserve((size_t)cnt * cis));
+            VS_HIP(hipMemcpy(st_ci.p, (const char*)colidx + (size_t)(base - rp_at(0)) * cis, (size_t)cnt * cis, hipMemcpyHostToDevice));
+            d_ci = st_ci.p;
+            if (values) {
+                VS_TRY(st_v.reserve((size_t)cnt * vsz));
+                VS_HIP(hipMemcpy(st_v.p, (const char*)values + (size_t)(base - rp_at(0)) * vsz, (size_t)cnt * vsz, hipMemcpyHostToDevice));
+                d_v = st_v.p;
+            }
+        }
+        const int wpb = 4;
+        const unsigned grid = (unsigned)ceil_div64(r_end - r, wpb);
+        int rc = dispatch_rp_ci(rowptr_dtype, col_dtype, [&](auto* rp_t, auto* ci_t) -> int {
+            using RP = std::remove_cv_t<std::remove_pointer_t<decltype(rp_t)>>;
+            using CI = std::remove_cv_t<std::remove_pointer_t<decltype(ci_t)>>;
+            if (values && val_dtype == VS_F16)
+                hipLaunchKernelGGL((fill_packets_kernel<RP, CI, __half>), dim3(grid), dim3(wpb * 64), 0, 0, (const RP*)d_rp, (const CI*)d_ci,
+                                   (const __half*)d_v, r, r_end, src_base, idx->pk_ptr.as<uint32_t>(), idx->cols.as<uint16_t>(),
+                                   idx->vals.p, store_dtype, n_cols, flags.as<int>());
+            else
+                hipLaunchKernelGGL((fill_packets_kernel<RP, CI, float>), dim3(grid), dim3(wpb * 64), 0, 0, (const RP*)d_rp, (const CI*)d_ci,
+                                   (const float*)d_v, r, r_end, src_base, idx->pk_ptr.as<uint32_t>(), idx->cols.as<uint16_t>(),
+                                   idx->vals.p, store_dtype, n_cols, flags.as<int>());
+            return VS_OK;
+        });
+        VS_TRY(rc);
+        VS_HIP(hipGetLastError());
+        VS_HIP(hipDeviceSynchronize());       // staging buffers are reused by the next chunk
+        r = r_end;
+    }
+    int hflags = 0;
+    VS_HIP(hipMemcpy(&hflags, flags.p, 4, hipMemcpyDeviceToHost));
+    if (hflags & 1) return fail(VS_EINVAL, "column index out of range [0, %d)", n_cols);
+    if (hflags & 2) return fail(VS_EINVAL, "store_dtype VS_NONE (binary index) requires every value == 1");
+    guard.p = nullptr;
+    *out = idx;
+    return VS_OK;
+}
+
+extern "C" int vs_index_create_synthetic(uint64_t seed, int64_t row0, int64_t n_rows, int32_t n_cols, int32_t nnz, int kind,
+                                         int val_law, int store_dtype, int device, vs_index** out) {
+    if (!out) return fail(VS_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (n_rows < 0 || n_cols <= 0 || n_cols > 65535 || nnz <= 0 || nnz > n_cols) return fail(VS_EINVAL, "bad synthetic shape");
+    if (kind != 0 && kind != 1) return fail(VS_EINVAL, "kind must be 0 (fixed nnz) or 1 (bag-of-token)");
+    if (kind == 1) store_dtype = VS_NONE;
+    vs_index* idx = nullptr;
+    VS_TRY(new_index(device, &idx));
+    struct Guard { vs_index* p; ~Guard() { if (p) vs_index_destroy(p); } } guard{idx};
+    idx->kind = VS_KIND_CSR;
+    idx->store_dtype = store_dtype;
+    idx->n_rows = n_rows;
+    idx->n_cols = n_cols;
+    std::vector<uint32_t> pk((size_t)n_rows + 1);
+    int64_t acc = 0, nz = 0;
+    pk[0] = 0;
+    for (int64_t r = 0; r < n_rows; ++r) {
+        const int64_t len = synth_row_len(seed, row0 + r, kind, nnz, n_cols);
+        nz += len;
+        acc += (len + 7) / 8;
+        if (acc >= (1ll << 32)) return fail(VS_EUNSUPPORTED, "index exceeds 2^32 packets on one device");
+        pk[r + 1] = (uint32_t)acc;
+    }
+    idx->nnz = nz;
+    idx->n_packets = acc;
+    VS_TRY(alloc_csr_storage(idx));
+    VS_HIP(hipMemcpy(idx->pk_ptr.p, pk.data(), pk.size() * 4, hipMemcpyHostToDevice));
+    const int words = (n_cols + 31) / 32;
+    const size_t lds = (size_t)kSynthWaves * words * 4;
+    const unsigned grid = (unsigned)std::min<int64_t>(std::max<int64_t>(1, ceil_div64(n_rows, kSynthWaves)), (int64_t)idx->cu_count * 32);
+    hipLaunchKernelGGL(synth_rows_kernel, dim3(grid), dim3(kSynthWaves * 64), lds, 0, seed, row0, n_rows, n_cols, nnz, kind, val_law,
+                       idx->pk_ptr.as<uint32_t>(), idx->cols.as<uint16_t>(), idx->vals.p, store_dtype);
+    VS_HIP(hipGetLastError());
+    VS_HIP(hipDeviceSynchronize());
+    guard.p = nullptr;
+    *out = idx;
+    return VS_OK;
+}
+
+// =================================================================================================
+// info / export / destroy
+// =================================================================================================
+static int64_t csr_bytes_per_pass(const vs_index* idx) {
+    const int64_t per_packet = 16 + (idx->store_dtype == VS_F32 ? 32 : idx->store_dtype == VS_F16 ? 16 : 0);
+    return idx->n_packets * per_packet + (idx->n_rows + 1) * 4;
+}
+
+extern "C" int vs_index_info(const vs_index* idx, vs_index_info_t* o) {
+    if (!idx || !o) return fail(VS_EINVAL, "NULL argument");
+    memset(o, 0, sizeof(*o));
+    o->kind = idx->kind;
+    o->store_dtype = idx->store_dtype;
+    o->n_rows = idx->n_rows;
+    o->n_cols = idx->n_cols;
+    o->device = idx->device;
+    o->nnz = idx->nnz;
+    o->n_packets = idx->n_packets;
+    if (idx->kind == VS_KIND_CSR) {
+        o->bytes_per_pass = csr_bytes_per_pass(idx);
+        o->device_bytes = (int64_t)(idx->pk_ptr.bytes + idx->cols.bytes + idx->vals.bytes);
+        o->lanes_per_row = idx->lanes_per_row;
+        o->queries_per_pass = 1;
+    } else {
+        o->bytes_per_pass = idx->n_rows * (int64_t)idx->n_cols * (idx->store_dtype == VS_F16 ? 2 : 4);
+        o->device_bytes = (int64_t)idx->mat.bytes;
+        o->queries_per_pass = 0;
+    }
+    return VS_OK;
+}
+
+extern "C" void vs_index_destroy(vs_index* idx) {
+    if (!idx) return;
+    (void)hipSetDevice(idx->device);
+    delete idx;
+}
+
+extern "C" int vs_index_export_csr(const vs_index* idx, int64_t* rowptr, int64_t* colidx, void* values, int val_dtype) {
+    if (!idx || !rowptr) return fail(VS_EINVAL, "NULL argument");
+    if (idx->kind != VS_KIND_CSR) return fail(VS_EINVAL, "not a CSR index");
+    if (values && val_dtype != VS_F32 && val_dtype != VS_F16) return fail(VS_EINVAL, "val_dtype must be VS_F32 or VS_F16");
+    VS_HIP(hipSetDevice(idx->device));
+    const int64_t n = idx->n_rows;
+    DevBuf d_len;
+    VS_TRY(d_len.alloc(std::max<size_t>((size_t)n * 8, 8)));
+    if (n > 0) {
+        hipLaunchKernelGGL(row_nnz_kernel, dim3((unsigned)ceil_div64(n, 4)), dim3(256), 0, 0, idx->pk_ptr.as<uint32_t>(),
+                           idx->cols.as<uint16_t>(), n, idx->n_cols, d_len.as<int64_t>());
+        VS_HIP(hipGetLastError());
+    }
+    std::vector<int64_t> rp((size_t)n + 1);
+    VS_HIP(hipMemcpy(rp.data() + 1, d_len.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+    rp[0] = 0;
+    for (int64_t r = 0; r < n; ++r) rp[r + 1] += rp[r];
+    if (is_device_ptr(rowptr)) VS_HIP(hipMemcpy(rowptr, rp.data(), rp.size() * 8, hipMemcpyHostToDevice));
+    else memcpy(rowptr, rp.data(), rp.size() * 8);
+    if (!colidx) return VS_OK;
+    const int64_t nnz = rp[n];
+    DevBuf d_rp;
+    VS_TRY(d_rp.alloc(rp.size() * 8));
+    VS_HIP(hipMemcpy(d_rp.p, rp.data(), rp.size() * 8, hipMemcpyHostToDevice));
+    const bool dst_dev = is_device_ptr(colidx);
+    const size_t vsz = values ? dtype_size(val_dtype) : 4;
+    DevBuf st_ci, st_v;
+    const int64_t kMaxChunkNnz = 32ll << 20;
+    int64_t r = 0;
+    while (r < n) {
+        int64_t r_end = r + 1;
+        while (r_end < n && rp[r_end + 1] - rp[r] <= kMaxChunkNnz) ++r_end;
+        const int64_t base = rp[r], cnt = rp[r_end] - base;
+        int64_t* o_ci;
+        void* o_v;
+        int64_t dst_base;
+        if (dst_dev) {
+            o_ci = colidx;
+            o_v = values;
+            dst_base = 0;
+        } else {
+            VS_TRY(st_ci.reserve(std::max<size_t>((size_t)cnt * 8, 8)));
+            VS_TRY(st_v.reserve(std::max<size_t>((size_t)cnt * vsz, 8)));
+            o_ci = st_ci.as<int64_t>();
+            o_v = st_v.p;
+            dst_base = base;
+        }
+        DevBuf dummy;
+        if (!values && dst_dev) { VS_TRY(dummy.alloc(std::max<size_t>((size_t)nnz * 4, 8))); o_v = dummy.p; dst_base = 0; }
+        const unsigned grid = (unsigned)ceil_div64(r_end - r, 4);
+        if (values && val_dtype == VS_F16)
+            hipLaunchKernelGGL((export_rows_kernel<__half>), dim3(grid), dim3(256), 0, 0, idx->pk_ptr.as<uint32_t>(), idx->cols.as<uint16_t>(),
+                               idx->vals.p, idx->store_dtype, d_rp.as<int64_t>(), r, r_end, dst_base, o_ci, (__half*)o_v);
+        else
+            hipLaunchKernelGGL((export_rows_kernel<float>), dim3(grid), dim3(256), 0, 0, idx->pk_ptr.as<uint32_t>(), idx->cols.as<uint16_t>(),
+                               idx->vals.p, idx->store_dtype, d_rp.as<int64_t>(), r, r_end, dst_base, o_ci, (float*)o_v);
+        VS_HIP(hipGetLastError());
+        VS_HIP(hipDeviceSynchronize());
+        if (!dst_dev && cnt > 0) {
+            VS_HIP(hipMemcpy(colidx + base, st_ci.p, (size_t)cnt * 8, hipMemcpyDeviceToHost));
+            if (values) VS_HIP(hipMemcpy((char*)values + (size_t)base * vsz, st_v.p, (size_t)cnt * vsz, hipMemcpyDeviceToHost));
+        }
+        r = r_end;
+    }
+    return VS_OK;
+}
+
+// =================================================================================================
+// search
+// =================================================================================================
+namespace {
+
+struct ScanPlan {
+    int nchunk;
+    int64_t rows_per_chunk;
+    int grid;
+};
+
+ScanPlan plan_scan(const vs_index* idx, int B) {
+    ScanPlan p;
+    const int64_t min_rows = 512;
+    int64_t rpc = std::max<int64_t>(min_rows, ceil_div64(idx->n_rows, idx->cu_count));
+    p.rows_per_chunk = rpc;
+    p.nchunk = (int)std::max<int64_t>(1, ceil_div64(idx->n_rows, rpc));
+    p.grid = (int)std::min<int64_t>((int64_t)B * p.nchunk, idx->cu_count);
+    return p;
+}
+
+template <int G, int VM>
+int launch_scan_g(int mode, const ScanArgs& a, int grid, size_t lds, hipStream_t s) {
+    // mode 0: scores, 1: wave top-k, 2: shared top-k
+    auto set_lds = [&](const void* f) -> int {
+        VS_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        return VS_OK;
+    };
+    if (mode == 0) {
+        VS_TRY(set_lds((const void*)csr_scan_scores<G, VM>));
+        hipLaunchKernelGGL((csr_scan_scores<G, VM>), dim3(grid), dim3(kScanThreads), lds, s, a);
+    } else if (mode == 1) {
+        VS_TRY(set_lds((const void*)csr_scan_topk_wave<G, VM>));
+        hipLaunchKernelGGL((csr_scan_topk_wave<G, VM>), dim3(grid), dim3(kScanThreads), lds, s, a);
+    } else {
+        VS_TRY(set_lds((const void*)csr_scan_topk_shared<G, VM>));
+        hipLaunchKernelGGL((csr_scan_topk_shared<G, VM>), dim3(grid), dim3(kScanThreads), lds, s, a);
+    }
+    VS_HIP(hipGetLastError());
+    return VS_OK;
+}
+
+template <int VM>
+int launch_scan_vm(int g, int mode, const ScanArgs& a, int grid, size_t lds, hipStream_t s) {
+    switch (g) {
+        case 4: return launch_scan_g<4, VM>(mode, a, grid, lds, s);
+        case 8: return launch_scan_g<8, VM>(mode, a, grid, lds, s);
+        case 16: return launch_scan_g<16, VM>(mode, a, grid, lds, s);
+        case 32: return launch_scan_g<32, VM>(mode, a, grid, lds, s);
+        default: return launch_scan_g<64, VM>(mode, a, grid, lds, s);
+    }
+}
+
+int launch_scan(const vs_index* idx, int mode, const ScanArgs& a, int grid, hipStream_t s) {
+    const size_t lds = scan_lds_bytes(idx->n_cols);
+    if (lds > 160 * 1024) return fail(VS_EUNSUPPORTED, "n_cols = %d needs %zu B of LDS (> 160 KiB)", idx->n_cols, lds);
+    ProfScope prof(mode == 0 ? "csr_scan_scores" : "csr_scan_topk", s);
+    if (idx->store_dtype == VS_F32) return launch_scan_vm<VM_F32>(idx->lanes_per_row, mode, a, grid, lds, s);
+    if (idx->store_dtype == VS_F16) return launch_scan_vm<VM_F16>(idx->lanes_per_row, mode, a, grid, lds, s);
+    return launch_scan_vm<VM_BIN>(idx->lanes_per_row, mode, a, grid, lds, s);
+}
+
+int prep_queries(vs_index* idx, const void* q, int q_dtype, int64_t ldq, int B, hipStream_t s, const float** out) {
+    if (q_dtype != VS_F32 && q_dtype != VS_F16) return fail(VS_EINVAL, "q_dtype must be VS_F32 or VS_F16");
+    const size_t esz = dtype_size(q_dtype);
+    const void* dq = q;
+    if (!is_device_ptr(q)) {
+        // host queries: upload the [B, ldq] block
+        const size_t bytes = ((size_t)(B - 1) * ldq + idx->n_cols) * esz;
+        VS_TRY(idx->ws_misc.reserve(bytes));
+        VS_HIP(hipMemcpyAsync(idx->ws_misc.p, q, bytes, hipMemcpyHostToDevice, s));
+        dq = idx->ws_misc.p;
+    }
+    VS_TRY(idx->ws_q.reserve((size_t)B * idx->n_cols * 4));
+    const int round_f16 = idx->store_dtype == VS_F16;
+    const int64_t n = (int64_t)B * idx->n_cols;
+    const unsigned grid = (unsigned)std::min<int64_t>(ceil_div64(n, 256), 4096);
+    if (q_dtype == VS_F32)
+        hipLaunchKernelGGL((prep_queries_kernel<float>), dim3(grid), dim3(256), 0, s, (const float*)dq, ldq, B, idx->n_cols, round_f16, idx->ws_q.as<float>());
+    else
+        hipLaunchKernelGGL((prep_queries_kernel<__half>), dim3(grid), dim3(256), 0, s, (const __half*)dq, ldq, B, idx->n_cols, round_f16, idx->ws_q.as<float>());
+    VS_HIP(hipGetLastError());
+    *out = idx->ws_q.as<float>();
+    return VS_OK;
+}
+
+}  // namespace
+
+int vs_csr_search(vs_index* idx, const void* q, int q_dtype, int64_t ldq, int32_t B, int32_t k, int64_t id_offset,
+                  int64_t* out_ids, float* out_scores, hipStream_t s) {
+    const float* dq = nullptr;
+    VS_TRY(prep_queries(idx, q, q_dtype, ldq, B, s, &dq));
+    const ScanPlan plan = plan_scan(idx, B);
+    const bool out_dev = is_device_ptr(out_ids);
+    if (out_dev != is_device_ptr(out_scores)) return fail(VS_EINVAL, "out_ids and out_scores must both be host or both device pointers");
+    int64_t* d_ids = out_ids;
+    float* d_scores = out_scores;
+    if (!out_dev) {
+        VS_TRY(idx->ws_out_ids.reserve((size_t)B * k * 8));
+        VS_TRY(idx->ws_out_scores.reserve((size_t)B * k * 4));
+        d_ids = idx->ws_out_ids.as<int64_t>();
+        d_scores = idx->ws_out_scores.as<float>();
+    }
+    const int passes = ceil_div(k, kMaxKShared);
+    DevBuf upper;                                              // [B] exclusive upper-bound keys (multi-pass only)
+    if (passes > 1) {
+        VS_TRY(upper.alloc((size_t)B * 8));
+        VS_HIP(hipMemsetAsync(upper.p, 0xFF, (size_t)B * 8, s));
+    }
+    // bound candidate scratch: process queries in sub-batches
+    const int kk_max = std::min<int>(k, kMaxKShared);
+    const size_t per_q = (size_t)plan.nchunk * kk_max * 8;
+    const int bs_max = (int)std::max<size_t>(1, std::min<size_t>((size_t)B, ((size_t)512 << 20) / per_q));
+    VS_TRY(idx->ws_cand.reserve(per_q * bs_max));
+    for (int pass = 0; pass < passes; ++pass) {
+        const int col0 = pass * kMaxKShared;
+        const int kk = std::min(k - col0, kMaxKShared);
+        for (int b0 = 0; b0 < B; b0 += bs_max) {
+            const int bs = std::min(bs_max, B - b0);
+            ScanArgs a{};
+            a.pk_ptr = idx->pk_ptr.as<uint32_t>();
+            a.cols = idx->cols.as<uint4>();
+            a.vals = idx->vals.p;
+            a.q = dq + (size_t)b0 * idx->n_cols;
+            a.n_rows = idx->n_rows;
+            a.n_cols = idx->n_cols;
+            a.B = bs;
+            a.k = kk;
+            a.nchunk = plan.nchunk;
+            a.rows_per_chunk = plan.rows_per_chunk;
+            a.cand = idx->ws_cand.as<uint64_t>();
+            a.upper = passes > 1 ? upper.as<uint64_t>() + b0 : nullptr;
+            const int grid = (int)std::min<int64_t>((int64_t)bs * plan.nchunk, idx->cu_count);
+            VS_TRY(launch_scan(idx, kk <= kMaxKWave ? 1 : 2, a, grid, s));
+            MergeArgs m{};
+            m.cand = a.cand;
+            m.n_cand = (int64_t)plan.nchunk * kk;
+            m.B = bs;
+            m.k = kk;
+            m.id_offset = id_offset;
+            m.out_ids = d_ids + (size_t)b0 * k;
+            m.out_scores = d_scores + (size_t)b0 * k;
+            m.out_ld = k;
+            m.col0 = col0;
+            m.upper_out = passes > 1 ? upper.as<uint64_t>() + b0 : nullptr;
+            {
+                ProfScope prof("merge_topk", s);
+                hipLaunchKernelGGL(merge_topk_kernel<0>, dim3(std::min(bs, idx->cu_count * 2)), dim3(kScanThreads), 0, s, m);
+            }
+            VS_HIP(hipGetLastError());
+        }
+    }
+    if (!out_dev) {
+        VS_HIP(hipMemcpyAsync(out_ids, d_ids, (size_t)B * k * 8, hipMemcpyDeviceToHost, s));
+        VS_HIP(hipMemcpyAsync(out_scores, d_scores, (size_t)B * k * 4, hipMemcpyDeviceToHost, s));
+        VS_HIP(hipStreamSynchronize(s));
+    }
+    if (passes > 1) VS_HIP(hipStreamSynchronize(s));          // `upper` is freed on return
+    return VS_OK;
+}
+
+int vs_csr_scores(vs_index* idx, const void* q, int q_dtype, int64_t ldq, int32_t B, float* out_scores, hipStream_t s) {
+    const float* dq = nullptr;
+    VS_TRY(prep_queries(idx, q, q_dtype, ldq, B, s, &dq));
+    const ScanPlan plan = plan_scan(idx, B);
+    const bool out_dev = is_device_ptr(out_scores);
+    float* d_scores = out_scores;
+    const size_t bytes = (size_t)B * idx->n_rows * 4;
+    if (!out_dev) {
+        VS_TRY(idx->ws_out_scores.reserve(bytes));
+        d_scores = idx->ws_out_scores.as<float>();
+    }
+    ScanArgs a{};
+    a.pk_ptr = idx->pk_ptr.as<uint32_t>();
+    a.cols = idx->cols.as<uint4>();
+    a.vals = idx->vals.p;
+    a.q = dq;
+    a.n_rows = idx->n_rows;
+    a.n_cols = idx->n_cols;
+    a.B = B;
+    a.k = 0;
+    a.nchunk = plan.nchunk;
+    a.rows_per_chunk = plan.rows_per_chunk;
+    a.all_scores = d_scores;
+    VS_TRY(launch_scan(idx, 0, a, plan.grid, s));
+    if (!out_dev) {
+        VS_HIP(hipMemcpyAsync(out_scores, d_scores, bytes, hipMemcpyDeviceToHost, s));
+        VS_HIP(hipStreamSynchronize(s));
+    }
+    return VS_OK;
+}
+
+extern "C" int vs_merge_topk(const int64_t* cand_ids, const float* cand_scores, int32_t B, int64_t n_cand, int32_t k,
+                             int64_t* out_ids, float* out_scores, int device, void* stream) {
+    if (!cand_ids || !cand_scores || !out_ids || !out_scores) return fail(VS_EINVAL, "NULL argument");
+    if (B <= 0 || k <= 0) return fail(VS_EINVAL, "B and k must be positive");
+    if (k > n_cand) return fail(VS_ERANGE, "selected index k out of range (k = %d > %lld candidates)", k, (long long)n_cand);
+    if (k > kMaxKShared) return fail(VS_EUNSUPPORTED, "vs_merge_topk supports k <= %d", kMaxKShared);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { (void)hipGetLastError(); return fail(VS_ENODEVICE, "no HIP device visible"); }
+    VS_HIP(hipSetDevice(device));
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n = (size_t)B * n_cand;
+    DevBuf st_ids, st_sc, keys, o_ids, o_sc;
+    const void *d_ids = nullptr, *d_sc = nullptr;
+    VS_TRY(to_device(cand_ids, n * 8, st_ids, s, &d_ids));
+    VS_TRY(to_device(cand_scores, n * 4, st_sc, s, &d_sc));
+    VS_TRY(keys.alloc(n * 8));
+    hipLaunchKernelGGL(keys_from_pairs_kernel, dim3((unsigned)std::min<int64_t>(ceil_div64((int64_t)n, 256), 4096)), dim3(256), 0, s,
+                       (const int64_t*)d_ids, (const float*)d_sc, (int64_t)n, keys.as<uint64_t>());
+    VS_HIP(hipGetLastError());
+    const bool out_dev = is_device_ptr(out_ids);
+    int64_t* di = out_ids;
+    float* ds = out_scores;
+    if (!out_dev) {
+        VS_TRY(o_ids.alloc((size_t)B * k * 8));
+        VS_TRY(o_sc.alloc((size_t)B * k * 4));
+        di = o_ids.as<int64_t>();
+        ds = o_sc.as<float>();
+    }
+    MergeArgs m{};
+    m.cand = keys.as<uint64_t>();
+    m.n_cand = n_cand;
+    m.B = B;
+    m.k = k;
+    m.id_offset = 0;
+    m.out_ids = di;
+    m.out_scores = ds;
+    m.out_ld = k;
+    m.col0 = 0;
+    hipLaunchKernelGGL(merge_topk_kernel<0>, dim3(std::min(B, 512)), dim3(kScanThreads), 0, s, m);
+    VS_HIP(hipGetLastError());
+    if (!out_dev) {
+        VS_HIP(hipMemcpyAsync(out_ids, di, (size_t)B * k * 8, hipMemcpyDeviceToHost, s));
+        VS_HIP(hipMemcpyAsync(out_scores, ds, (size_t)B * k * 4, hipMemcpyDeviceToHost, s));
+    }
+    VS_HIP(hipStreamSynchronize(s));                          // temporaries die here
+    return VS_OK;
+}

@@ -1,0 +1,290 @@
+// dense.hip -- dense Index container and search (index.py:25-44, :88-94; build: retriever.py:292-297)
+//   scores[B, N] = Q[B, V] . P[N, V]^T  on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32
+//   products accumulated like an fmaf chain), scores leave the kernel as 64-bit order keys and the
+//   shared top-k merge selects per query.
+#include "common.h"
+#include "csr_scan.h"
+
+#include <algorithm>
+
+using namespace vs;
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kDenseKC = 32;   // columns per K-chunk: each half-wave loads 16 contiguous floats per row
+
+// copy [n_rows, n_cols] (fp32 | fp16, leading dim ld) -> padded fp32 [n_rows, ldp], tail zeroed;
+// round_f16 emulates storing / casting to fp16 (index.py:42,89).
+template <class T>
+__global__ void pad_rows_kernel(const T* src, int64_t ld, int64_t n_rows, int32_t n_cols, int32_t ldp, int round_f16, float* dst) {
+    const int64_t n = n_rows * ldp;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / ldp;
+        const int32_t c = (int32_t)(i % ldp);
+        float v = 0.f;
+        if (c < n_cols) {
+            if constexpr (sizeof(T) == 4) v = src[r * ld + c];
+            else v = __half2float(src[r * ld + c]);
+            if (round_f16) v = __half2float(__float2half_rn(v));
+        }
+        dst[i] = v;
+    }
+}
+
+template <class T>
+__global__ void unpad_rows_kernel(const float* src, int32_t ldp, int64_t n_rows, int32_t n_cols, int64_t ld, T* dst) {
+    const int64_t n = n_rows * n_cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / n_cols;
+        const int32_t c = (int32_t)(i % n_cols);
+        if constexpr (sizeof(T) == 4) dst[r * ld + c] = src[r * ldp + c];
+        else dst[r * ld + c] = __float2half_rn(src[r * ldp + c]);
+    }
+}
+
+// One wave = one 32 (queries) x 32 (docs) tile; a workgroup of 4 waves = 64 x 64.
+// Lane l feeds A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31] of each 32x32x2 MFMA; the K order is
+// permuted so that half-wave h owns columns c0 + 16h .. c0 + 16h + 15 of the chunk: every lane
+// streams 64 contiguous bytes of its row per chunk straight from global memory (L1/L2 serve the
+// 2x reuse inside the workgroup).  Rows are padded to ldp (multiple of kDenseKC) with zeros.
+__global__ __launch_bounds__(256) void dense_scores_kernel(const float* __restrict__ Q, const float* __restrict__ P, int32_t B,
+                                                           int64_t N, int32_t ldp, uint64_t* keys, float* scores) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t n0 = (int64_t)blockIdx.x * 64 + (w & 1) * 32;
+    const int b0 = blockIdx.y * 64 + (w >> 1) * 32;
+    const int h = lane >> 5, l31 = lane & 31;
+    const int qi = min(b0 + l31, B - 1);
+    const int64_t ni = min(n0 + l31, N - 1);
+    const float4* qa = reinterpret_cast<const float4*>(Q + (size_t)qi * ldp + h * 16);
+    const float4* pb = reinterpret_cast<const float4*>(P + (size_t)ni * ldp + h * 16);
+    // Two-level summation: products are chained inside 512-column blocks (two independent MFMA
+    // accumulators), block sums are added to `tot` -- keeps the fp32 error of a 29 523-term dot
+    // product near 1e-6 relative instead of ~1e-5 for one long chain.
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    f32x16 tot = zero, acc0 = zero, acc1 = zero;
+    const int chunks = ldp / kDenseKC;
+    for (int c = 0; c < chunks; ++c) {
+        float4 a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            a[i] = qa[c * (kDenseKC / 4) + i];
+            b[i] = pb[c * (kDenseKC / 4) + i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i += 2) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[i].x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i + 1].x, b[i + 1].x, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[i].y, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i + 1].y, b[i + 1].y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[i].z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i + 1].z, b[i + 1].z, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[i].w, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i + 1].w, b[i + 1].w, acc1, 0, 0, 0);
+        }
+        if ((c & 15) == 15 || c == chunks - 1) {
+            tot += acc0 + acc1;
+            acc0 = zero;
+            acc1 = zero;
+        }
+    }
+    const f32x16 acc = tot;
+    // C/D layout: col j = lane & 31 (doc), row i = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (query)
+    const int64_t n = n0 + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int b = b0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (b < B && n < N) {
+            if (keys) keys[(size_t)b * N + n] = make_key(acc[r], (uint32_t)n);
+            if (scores) scores[(size_t)b * N + n] = acc[r];
+        }
+    }
+}
+
+int prep_dense_queries(vs_index* idx, const void* q, int q_dtype, int64_t ldq, int B, int ldp, hipStream_t s, const float** out) {
+    if (q_dtype != VS_F32 && q_dtype != VS_F16) return fail(VS_EINVAL, "q_dtype must be VS_F32 or VS_F16");
+    const size_t esz = dtype_size(q_dtype);
+    const void* dq = q;
+    if (!is_device_ptr(q)) {
+        const size_t bytes = ((size_t)(B - 1) * ldq + idx->n_cols) * esz;
+        VS_TRY(idx->ws_misc.reserve(bytes));
+        VS_HIP(hipMemcpyAsync(idx->ws_misc.p, q, bytes, hipMemcpyHostToDevice, s));
+        dq = idx->ws_misc.p;
+    }
+    VS_TRY(idx->ws_q.reserve((size_t)B * ldp * 4));
+    const int round_f16 = idx->store_dtype == VS_F16;
+    const unsigned grid = (unsigned)std::min<int64_t>(ceil_div64((int64_t)B * ldp, 256), 8192);
+    if (q_dtype == VS_F32)
+        hipLaunchKernelGGL((pad_rows_kernel<float>), dim3(grid), dim3(256), 0, s, (const float*)dq, ldq, (int64_t)B, idx->n_cols, ldp, round_f16, idx->ws_q.as<float>());
+    else
+        hipLaunchKernelGGL((pad_rows_kernel<__half>), dim3(grid), dim3(256), 0, s, (const __half*)dq, ldq, (int64_t)B, idx->n_cols, ldp, round_f16, idx->ws_q.as<float>());
+    VS_HIP(hipGetLastError());
+    *out = idx->ws_q.as<float>();
+    return VS_OK;
+}
+
+inline int dense_ldp(int32_t n_cols) { return (n_cols + kDenseKC - 1) / kDenseKC * kDenseKC; }
+
+}  // namespace
+
+extern "C" int vs_index_create_dense(const void* mat, int dtype, int store_dtype, int64_t n_rows, int32_t n_cols, int64_t ld,
+                                     int device, vs_index** out) {
+    if (!out) return fail(VS_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (!mat || n_rows <= 0 || n_cols <= 0 || ld < n_cols) return fail(VS_EINVAL, "bad matrix / shape");
+    if (dtype != VS_F32 && dtype != VS_F16) return fail(VS_EINVAL, "dtype must be VS_F32 or VS_F16");
+    if (store_dtype != VS_F32 && store_dtype != VS_F16) return fail(VS_EINVAL, "store_dtype must be VS_F32 or VS_F16");
+    if (n_rows >= (1ll << 32) - 1) return fail(VS_EUNSUPPORTED, "n_rows must fit in 32 bits");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        (void)hipGetLastError();
+        return fail(VS_ENODEVICE, "no HIP device visible: libvsearch_hip has no CPU fallback");
+    }
+    if (device < 0 || device >= ndev) return fail(VS_EINVAL, "device %d out of range", device);
+    VS_HIP(hipSetDevice(device));
+    vs_index* idx = new (std::nothrow) vs_index();
+    if (!idx) return fail(VS_ENOMEM, "host allocation failed");
+    struct Guard { vs_index* p; ~Guard() { if (p) vs_index_destroy(p); } } guard{idx};
+    hipDeviceProp_t prop;
+    VS_HIP(hipGetDeviceProperties(&prop, device));
+    idx->device = device;
+    idx->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    idx->kind = VS_KIND_DENSE;
+    idx->store_dtype = store_dtype;          // fp16 storage is emulated by rounding; the matrix stays fp32 on device (v0)
+    idx->n_rows = n_rows;
+    idx->n_cols = n_cols;
+    idx->nnz = n_rows * (int64_t)n_cols;
+    const int ldp = dense_ldp(n_cols);
+    VS_TRY(idx->mat.alloc((size_t)n_rows * ldp * 4));
+    const size_t esz = dtype_size(dtype);
+    const int64_t rows_per_chunk = std::max<int64_t>(1, ((int64_t)256 << 20) / ((int64_t)ld * (int64_t)esz));
+    DevBuf stage;
+    for (int64_t r = 0; r < n_rows; r += rows_per_chunk) {
+        const int64_t nr = std::min(rows_per_chunk, n_rows - r);
+        const char* src = (const char*)mat + (size_t)r * ld * esz;
+        const void* dsrc = src;
+        if (!is_device_ptr(mat)) {
+            const size_t bytes = ((size_t)(nr - 1) * ld + n_cols) * esz;
+            VS_TRY(stage.reserve(bytes));
+            VS_HIP(hipMemcpy(stage.p, src, bytes, hipMemcpyHostToDevice));
+            dsrc = stage.p;
+        }
+        const unsigned grid = (unsigned)std::min<int64_t>(ceil_div64(nr * ldp, 256), 16384);
+        float* dst = idx->mat.as<float>() + (size_t)r * ldp;
+        if (dtype == VS_F32)
+            hipLaunchKernelGGL((pad_rows_kernel<float>), dim3(grid), dim3(256), 0, 0, (const float*)dsrc, ld, nr, n_cols, ldp, store_dtype == VS_F16, dst);
+        else
+            hipLaunchKernelGGL((pad_rows_kernel<__half>), dim3(grid), dim3(256), 0, 0, (const __half*)dsrc, ld, nr, n_cols, ldp, store_dtype == VS_F16, dst);
+        VS_HIP(hipGetLastError());
+        VS_HIP(hipDeviceSynchronize());
+    }
+    guard.p = nullptr;
+    *out = idx;
+    return VS_OK;
+}
+
+extern "C" int vs_index_export_dense(const vs_index* idx, void* mat, int dtype, int64_t ld) {
+    if (!idx || !mat) return fail(VS_EINVAL, "NULL argument");
+    if (idx->kind != VS_KIND_DENSE) return fail(VS_EINVAL, "not a dense index");
+    if (dtype != VS_F32 && dtype != VS_F16) return fail(VS_EINVAL, "dtype must be VS_F32 or VS_F16");
+    if (ld < idx->n_cols) return fail(VS_EINVAL, "ld < n_cols");
+    VS_HIP(hipSetDevice(idx->device));
+    const int ldp = dense_ldp(idx->n_cols);
+    const size_t esz = dtype_size(dtype);
+    const bool dst_dev = is_device_ptr(mat);
+    const int64_t rows_per_chunk = std::max<int64_t>(1, ((int64_t)256 << 20) / ((int64_t)ld * (int64_t)esz));
+    DevBuf stage;
+    for (int64_t r = 0; r < idx->n_rows; r += rows_per_chunk) {
+        const int64_t nr = std::min(rows_per_chunk, idx->n_rows - r);
+        void* ddst = (char*)mat + (size_t)r * ld * esz;
+        if (!dst_dev) {
+            VS_TRY(stage.reserve((size_t)nr * ld * esz));
+            ddst = stage.p;
+        }
+        const unsigned grid = (unsigned)std::min<int64_t>(ceil_div64(nr * idx->n_cols, 256), 16384);
+        const float* src = idx->mat.as<float>() + (size_t)r * ldp;
+        if (dtype == VS_F32) hipLaunchKernelGGL((unpad_rows_kernel<float>), dim3(grid), dim3(256), 0, 0, src, ldp, nr, idx->n_cols, ld, (float*)ddst);
+        else hipLaunchKernelGGL((unpad_rows_kernel<__half>), dim3(grid), dim3(256), 0, 0, src, ldp, nr, idx->n_cols, ld, (__half*)ddst);
+        VS_HIP(hipGetLastError());
+        VS_HIP(hipDeviceSynchronize());
+        if (!dst_dev) {
+            // rows are written with stride ld inside the stage; copy the used span
+            const size_t bytes = ((size_t)(nr - 1) * ld + idx->n_cols) * esz;
+            VS_HIP(hipMemcpy((char*)mat + (size_t)r * ld * esz, stage.p, bytes, hipMemcpyDeviceToHost));
+        }
+    }
+    return VS_OK;
+}
+
+int vs_dense_search(vs_index* idx, const void* q, int q_dtype, int64_t ldq, int32_t B, int32_t k, int64_t id_offset,
+                    int64_t* out_ids, float* out_scores, hipStream_t s) {
+    if (k > kMaxKShared) return fail(VS_EUNSUPPORTED, "dense search supports k <= %d", kMaxKShared);
+    const int ldp = dense_ldp(idx->n_cols);
+    const float* dq = nullptr;
+    VS_TRY(prep_dense_queries(idx, q, q_dtype, ldq, B, ldp, s, &dq));
+    const bool out_dev = is_device_ptr(out_ids);
+    if (out_dev != is_device_ptr(out_scores)) return fail(VS_EINVAL, "out_ids and out_scores must both be host or both device pointers");
+    int64_t* d_ids = out_ids;
+    float* d_scores = out_scores;
+    if (!out_dev) {
+        VS_TRY(idx->ws_out_ids.reserve((size_t)B * k * 8));
+        VS_TRY(idx->ws_out_scores.reserve((size_t)B * k * 4));
+        d_ids = idx->ws_out_ids.as<int64_t>();
+        d_scores = idx->ws_out_scores.as<float>();
+    }
+    const int64_t N = idx->n_rows;
+    const int bs_max = (int)std::max<int64_t>(1, std::min<int64_t>(B, ((int64_t)1 << 30) / (N * 8)));
+    VS_TRY(idx->ws_cand.reserve((size_t)bs_max * N * 8));
+    for (int b0 = 0; b0 < B; b0 += bs_max) {
+        const int bs = std::min(bs_max, B - b0);
+        {
+            ProfScope prof("dense_scores", s);
+            hipLaunchKernelGGL(dense_scores_kernel, dim3((unsigned)ceil_div64(N, 64), (unsigned)ceil_div(bs, 64)), dim3(256), 0, s,
+                               dq + (size_t)b0 * ldp, idx->mat.as<float>(), bs, N, ldp, idx->ws_cand.as<uint64_t>(), (float*)nullptr);
+        }
+        VS_HIP(hipGetLastError());
+        MergeArgs m{};
+        m.cand = idx->ws_cand.as<uint64_t>();
+        m.n_cand = N;
+        m.B = bs;
+        m.k = k;
+        m.id_offset = id_offset;
+        m.out_ids = d_ids + (size_t)b0 * k;
+        m.out_scores = d_scores + (size_t)b0 * k;
+        m.out_ld = k;
+        m.col0 = 0;
+        {
+            ProfScope prof("merge_topk", s);
+            hipLaunchKernelGGL(merge_topk_kernel<0>, dim3(std::min(bs, idx->cu_count * 2)), dim3(kScanThreads), 0, s, m);
+        }
+        VS_HIP(hipGetLastError());
+    }
+    if (!out_dev) {
+        VS_HIP(hipMemcpyAsync(out_ids, d_ids, (size_t)B * k * 8, hipMemcpyDeviceToHost, s));
+        VS_HIP(hipMemcpyAsync(out_scores, d_scores, (size_t)B * k * 4, hipMemcpyDeviceToHost, s));
+        VS_HIP(hipStreamSynchronize(s));
+    }
+    return VS_OK;
+}
+
+int vs_dense_scores(vs_index* idx, const void* q, int q_dtype, int64_t ldq, int32_t B, float* out_scores, hipStream_t s) {
+    const int ldp = dense_ldp(idx->n_cols);
+    const float* dq = nullptr;
+    VS_TRY(prep_dense_queries(idx, q, q_dtype, ldq, B, ldp, s, &dq));
+    const bool out_dev = is_device_ptr(out_scores);
+    float* d_scores = out_scores;
+    const int64_t N = idx->n_rows;
+    if (!out_dev) {
+        VS_TRY(idx->ws_out_scores.reserve((size_t)B * N * 4));
+        d_scores = idx->ws_out_scores.as<float>();
+    }
+    hipLaunchKernelGGL(dense_scores_kernel, dim3((unsigned)ceil_div64(N, 64), (unsigned)ceil_div(B, 64)), dim3(256), 0, s, dq,
+                       idx->mat.as<float>(), B, N, ldp, (uint64_t*)nullptr, d_scores);
+    VS_HIP(hipGetLastError());
+    if (!out_dev) {
+        VS_HIP(hipMemcpyAsync(out_scores, d_scores, (size_t)B * N * 4, hipMemcpyDeviceToHost, s));
+        VS_HIP(hipStreamSynchronize(s));
+    }
+    return VS_OK;
+}

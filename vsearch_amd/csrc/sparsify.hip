@@ -1,0 +1,408 @@
+// sparsify.hip -- src/ir/utils/sparse.py (elu1p, build_topk_mask, build_bow_mask) and the mask
+// stage of VDREncoder.embed (src/ir/encoder/vdr.py:152-169), plus Tensor.to_sparse_csr()
+// (retriever.py:304) and the encoder head's pooling tail (vdr.py:73-75).
+//
+// One workgroup per embedding row: the row (V = 29 523 fp32 = 118 KB) sits in LDS as order keys; the
+// k-th largest value is found by a 4-pass 8-bit radix select on LDS histograms; ties at the threshold
+// go to the lowest column ids (torch.topk leaves them unspecified).
+#include "common.h"
+#include "topk_keys.h"
+
+#include <algorithm>
+
+using namespace vs;
+
+namespace {
+
+constexpr int kSpThreads = 1024;
+
+__device__ __forceinline__ float elu1p_dev(float x) { return x > 0.f ? x + 1.0f : expm1f(x) + 1.0f; }
+
+__global__ void elu1p_kernel(const float* x, int64_t n, float* out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = elu1p_dev(x[i]);
+}
+
+// out[b, c] = elu1p(max_l logits[b, l, c])   (elu1p is monotone: == max_l elu1p(logits), vdr.py:73-75)
+__global__ void head_pool_kernel(const float* logits, int32_t B, int32_t L, int32_t V, float* out) {
+    const int64_t n = (int64_t)B * V;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / V, c = i % V;
+        const float* p = logits + (size_t)b * L * V + c;
+        float m = -INFINITY;
+        for (int l = 0; l < L; ++l) m = fmaxf(m, p[(size_t)l * V]);
+        out[i] = elu1p_dev(m);
+    }
+}
+
+// block-wide exclusive scan of one int per thread (kSpThreads threads); scratch: 16 ints in LDS
+__device__ __forceinline__ int block_excl_scan(int v, int* scratch, int tid, int* total) {
+    const int lane = tid & 63, w = tid >> 6;
+    int incl = v;
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    __syncthreads();
+    if (lane == 63) scratch[w] = incl;
+    __syncthreads();
+    int base = 0, tot = 0;
+    for (int i = 0; i < kSpThreads / 64; ++i) {
+        const int s = scratch[i];
+        if (i < w) base += s;
+        tot += s;
+    }
+    if (total) *total = tot;
+    return base + incl - v;
+}
+
+struct MaskArgs {
+    float* emb;            // [B, V] (ld) in/out; may be null when only `mask` is wanted from x
+    const float* x;        // source values (== emb for in-place)
+    int64_t ld;
+    const int64_t* ids;    // [B, L] token ids or null
+    int32_t B, L, V, vocab, shift;
+    int32_t topk;          // >0: top-k; 0: none; <0: all
+    int activate_lexical;
+    int bow;
+    uint8_t* mask;         // optional [B, V] output (build_topk_mask)
+    int* flags;            // |1: token id out of range
+};
+
+__global__ __launch_bounds__(kSpThreads) void mask_rows_kernel(MaskArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint32_t* keys = reinterpret_cast<uint32_t*>(smem);                       // [V]
+    const int vwords = (a.V + 31) / 32;
+    uint32_t* lex = keys + ((a.V + 3) & ~3);                                   // [vwords] lexical bitmap
+    int* hist = reinterpret_cast<int*>(lex + ((vwords + 3) & ~3));             // [256]
+    int* scratch = hist + 256;                                                 // [32]
+    const int tid = threadIdx.x;
+    const int seg = (a.V + kSpThreads - 1) / kSpThreads;
+
+    for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+        __syncthreads();
+        const float* xr = a.x ? a.x + (size_t)b * a.ld : nullptr;
+        const bool need_keys = !a.bow && a.topk > 0;
+        if (need_keys) for (int i = tid; i < a.V; i += kSpThreads) keys[i] = flip_f32(xr[i]);
+        for (int i = tid; i < vwords; i += kSpThreads) lex[i] = 0;
+        __syncthreads();
+        int lex_count = 0;
+        if (a.ids && (a.bow || a.activate_lexical)) {
+            int bad = 0;
+            for (int l = tid; l < a.L; l += kSpThreads) {
+                const int64_t t = a.ids[(size_t)b * a.L + l];
+                if (t < 0 || t >= a.vocab) bad = 1;
+                else if (t >= a.shift) atomicOr(&lex[(t - a.shift) >> 5], 1u << ((t - a.shift) & 31));
+            }
+            if (bad) atomicOr(a.flags, 1);
+        }
+        __syncthreads();
+        (void)lex_count;
+
+        // ---- radix select of the k-th largest key ----
+        uint32_t T = 0;          // threshold key
+        int r_eq = 0;            // how many elements equal to T are selected (lowest columns first)
+        if (need_keys) {
+            uint32_t prefix = 0, pmask = 0;
+            int remaining = a.topk;
+            for (int shift = 24; shift >= 0; shift -= 8) {
+                for (int i = tid; i < 256; i += kSpThreads) hist[i] = 0;
+                __syncthreads();
+                for (int i = tid; i < a.V; i += kSpThreads) {
+                    const uint32_t kx = keys[i];
+                    if ((kx & pmask) == prefix) atomicAdd(&hist[(kx >> shift) & 255], 1);
+                }
+                __syncthreads();
+                // every thread walks the 256 bins from the top (uniform result, no extra barrier data)
+                int acc = 0, digit = 0;
+                for (int d = 255; d >= 0; --d) {
+                    const int h = hist[d];
+                    if (acc + h >= remaining) { digit = d; break; }
+                    acc += h;
+                }
+                remaining -= acc;
+                prefix |= (uint32_t)digit << shift;
+                pmask |= 255u << shift;
+                __syncthreads();
+            }
+            T = prefix;
+            r_eq = remaining;    // >= 1
+        }
+
+        // ---- rank of equal-to-threshold elements: contiguous segment per thread + block scan ----
+        const int i0 = tid * seg, i1 = min(a.V, i0 + seg);
+        int eq_before = 0;
+        if (need_keys) {
+            int my_eq = 0;
+            for (int i = i0; i < i1; ++i) my_eq += keys[i] == T;
+            eq_before = block_excl_scan(my_eq, scratch, tid, nullptr);
+        }
+        float bow_val = 1.0f;
+        if (a.bow < 0) {         // bow with L2 normalisation: value = 1 / max(sqrt(count), 1e-12)
+            int c = 0;
+            for (int i = tid; i < vwords; i += kSpThreads) c += __popc(lex[i]);
+            int total = 0;
+            block_excl_scan(c, scratch, tid, &total);
+            const float nrm = fmaxf(sqrtf((float)total), 1e-12f);
+            bow_val = 1.0f / nrm;
+        }
+        for (int i = i0; i < i1; ++i) {
+            const bool lx = (lex[i >> 5] >> (i & 31)) & 1u;
+            bool sel;
+            if (a.bow) sel = lx;
+            else {
+                bool tk;
+                if (a.topk == 0) tk = false;
+                else if (a.topk < 0) tk = true;
+                else {
+                    const uint32_t kx = keys[i];
+                    tk = kx > T;
+                    if (kx == T) { tk = eq_before < r_eq; ++eq_before; }
+                }
+                sel = tk || (a.activate_lexical && lx);
+            }
+            if (a.mask) a.mask[(size_t)b * a.V + i] = sel ? 1 : 0;
+            if (a.emb) {
+                float* e = a.emb + (size_t)b * a.ld + i;
+                if (a.bow) *e = sel ? bow_val : 0.f;
+                else if (!sel) *e = *e * 0.f;                  // `emb *= mask` (vdr.py:169)
+            }
+        }
+    }
+}
+
+// ---- Tensor.to_sparse_csr() (retriever.py:304): non-zeros of a dense [B, V] matrix ----------------
+__global__ __launch_bounds__(kSpThreads) void count_nz_kernel(const float* x, int64_t ld, int32_t B, int32_t V, int64_t* counts) {
+    __shared__ int scratch[32];
+    const int tid = threadIdx.x;
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        int c = 0;
+        for (int i = tid; i < V; i += kSpThreads) c += x[(size_t)b * ld + i] != 0.f;
+        int total = 0;
+        block_excl_scan(c, scratch, tid, &total);
+        if (tid == 0) counts[b] = total;
+        __syncthreads();
+    }
+}
+
+__global__ void scan_counts_kernel(const int64_t* counts, int32_t B, int64_t* rowptr) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        int64_t acc = 0;
+        rowptr[0] = 0;
+        for (int b = 0; b < B; ++b) { acc += counts[b]; rowptr[b + 1] = acc; }
+    }
+}
+
+__global__ __launch_bounds__(kSpThreads) void fill_csr_kernel(const float* x, int64_t ld, int32_t B, int32_t V, const int64_t* rowptr,
+                                                              int32_t* cols, float* vals, int64_t cap) {
+    __shared__ int scratch[32];
+    const int tid = threadIdx.x;
+    const int seg = (V + kSpThreads - 1) / kSpThreads;
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        const int i0 = tid * seg, i1 = min(V, i0 + seg);
+        int c = 0;
+        for (int i = i0; i < i1; ++i) c += x[(size_t)b * ld + i] != 0.f;
+        int64_t pos = rowptr[b] + block_excl_scan(c, scratch, tid, nullptr);
+        for (int i = i0; i < i1; ++i) {
+            const float v = x[(size_t)b * ld + i];
+            if (v != 0.f) {
+                if (pos < cap) { cols[pos] = i; vals[pos] = v; }
+                ++pos;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+int check_device(int device) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        (void)hipGetLastError();
+        return fail(VS_ENODEVICE, "no HIP device visible: libvsearch_hip has no CPU fallback");
+    }
+    if (device < 0 || device >= ndev) return fail(VS_EINVAL, "device %d out of range", device);
+    VS_HIP(hipSetDevice(device));
+    return VS_OK;
+}
+
+size_t mask_lds_bytes(int V) {
+    const int vwords = (V + 31) / 32;
+    return ((size_t)((V + 3) & ~3) + ((vwords + 3) & ~3) + 256 + 32) * 4;
+}
+
+// Runs mask_rows_kernel with host/device staging of emb / ids / mask.
+int run_mask(MaskArgs a, const float* x_in, float* emb_io, const int64_t* ids, uint8_t* mask_out, int device, hipStream_t s) {
+    VS_TRY(check_device(device));
+    const size_t lds = mask_lds_bytes(a.V);
+    if (lds > 160 * 1024) return fail(VS_EUNSUPPORTED, "V = %d needs %zu B of LDS (> 160 KiB)", a.V, lds);
+    DevBuf st_x, st_ids, st_mask, flags;
+    VS_TRY(flags.alloc(4));
+    VS_HIP(hipMemsetAsync(flags.p, 0, 4, s));
+    a.flags = flags.as<int>();
+    const size_t row_span = a.B > 0 ? ((size_t)(a.B - 1) * a.ld + a.V) * 4 : 0;
+    const float* src = emb_io ? emb_io : x_in;
+    const bool x_host = src && !is_device_ptr(src);
+    if (src) {
+        const void* d = nullptr;
+        VS_TRY(to_device(src, row_span, st_x, s, &d));
+        a.x = (const float*)d;
+        a.emb = emb_io ? (float*)d : nullptr;
+    }
+    if (ids) {
+        const void* d = nullptr;
+        VS_TRY(to_device(ids, (size_t)a.B * a.L * 8, st_ids, s, &d));
+        a.ids = (const int64_t*)d;
+    }
+    const bool m_host = mask_out && !is_device_ptr(mask_out);
+    if (mask_out) {
+        if (m_host) { VS_TRY(st_mask.alloc((size_t)a.B * a.V)); a.mask = st_mask.as<uint8_t>(); }
+        else a.mask = mask_out;
+    }
+    VS_HIP(hipFuncSetAttribute((const void*)mask_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(mask_rows_kernel, dim3(std::min(a.B, 1024)), dim3(kSpThreads), lds, s, a);
+    VS_HIP(hipGetLastError());
+    if (emb_io && x_host) VS_HIP(hipMemcpyAsync(emb_io, st_x.p, row_span, hipMemcpyDeviceToHost, s));
+    if (m_host) VS_HIP(hipMemcpyAsync(mask_out, st_mask.p, (size_t)a.B * a.V, hipMemcpyDeviceToHost, s));
+    int hflags = 0;
+    VS_HIP(hipMemcpyAsync(&hflags, flags.p, 4, hipMemcpyDeviceToHost, s));
+    VS_HIP(hipStreamSynchronize(s));
+    if (hflags & 1) return fail(VS_EINVAL, "token id out of range [0, %d)", a.vocab);
+    return VS_OK;
+}
+
+}  // namespace
+
+extern "C" int vs_elu1p(const float* x, int64_t n, float* out, int device, void* stream) {
+    if (!x || !out || n < 0) return fail(VS_EINVAL, "bad argument");
+    VS_TRY(check_device(device));
+    hipStream_t s = (hipStream_t)stream;
+    DevBuf st_in, st_out;
+    const void* dx = nullptr;
+    VS_TRY(to_device(x, (size_t)n * 4, st_in, s, &dx));
+    const bool o_host = !is_device_ptr(out);
+    float* dout = out;
+    if (o_host) { VS_TRY(st_out.alloc(std::max<size_t>((size_t)n * 4, 4))); dout = st_out.as<float>(); }
+    if (n > 0) hipLaunchKernelGGL(elu1p_kernel, dim3((unsigned)std::min<int64_t>(ceil_div64(n, 256), 8192)), dim3(256), 0, s, (const float*)dx, n, dout);
+    VS_HIP(hipGetLastError());
+    if (o_host) VS_HIP(hipMemcpyAsync(out, dout, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    if (o_host || !stream || st_in.p) VS_HIP(hipStreamSynchronize(s));
+    return VS_OK;
+}
+
+extern "C" int vs_head_pool(const float* logits, int32_t B, int32_t L, int32_t V, float* out, int device, void* stream) {
+    if (!logits || !out || B <= 0 || L <= 0 || V <= 0) return fail(VS_EINVAL, "bad argument");
+    VS_TRY(check_device(device));
+    hipStream_t s = (hipStream_t)stream;
+    DevBuf st_in, st_out;
+    const void* dx = nullptr;
+    VS_TRY(to_device(logits, (size_t)B * L * V * 4, st_in, s, &dx));
+    const bool o_host = !is_device_ptr(out);
+    float* dout = out;
+    if (o_host) { VS_TRY(st_out.alloc((size_t)B * V * 4)); dout = st_out.as<float>(); }
+    hipLaunchKernelGGL(head_pool_kernel, dim3((unsigned)std::min<int64_t>(ceil_div64((int64_t)B * V, 256), 8192)), dim3(256), 0, s, (const float*)dx, B, L, V, dout);
+    VS_HIP(hipGetLastError());
+    if (o_host) VS_HIP(hipMemcpyAsync(out, dout, (size_t)B * V * 4, hipMemcpyDeviceToHost, s));
+    if (o_host || !stream || st_in.p) VS_HIP(hipStreamSynchronize(s));
+    return VS_OK;
+}
+
+extern "C" int vs_topk_mask(const float* x, int32_t B, int32_t V, int64_t ld, int32_t k, uint8_t* mask, int device, void* stream) {
+    if (!x || !mask || B <= 0 || V <= 0 || ld < V) return fail(VS_EINVAL, "bad argument");
+    if (k < 0 || k > V) return fail(VS_ERANGE, "selected index k out of range (k = %d, V = %d)", k, V);
+    MaskArgs a{};
+    a.ld = ld; a.B = B; a.L = 0; a.V = V; a.vocab = V; a.shift = 0; a.topk = k; a.activate_lexical = 0; a.bow = 0;
+    return run_mask(a, x, nullptr, nullptr, mask, device, (hipStream_t)stream);
+}
+
+extern "C" int vs_bow_mask(const int64_t* ids, int32_t B, int32_t L, int32_t vocab, int32_t shift, int norm, float* out,
+                           int device, void* stream) {
+    if (!ids || !out || B <= 0 || L <= 0 || vocab <= 0 || shift < 0 || shift >= vocab) return fail(VS_EINVAL, "bad argument");
+    MaskArgs a{};
+    a.V = vocab - shift; a.ld = a.V; a.B = B; a.L = L; a.vocab = vocab; a.shift = shift; a.topk = 0; a.activate_lexical = 1;
+    a.bow = norm ? -1 : 1;
+    return run_mask(a, nullptr, out, ids, nullptr, device, (hipStream_t)stream);
+}
+
+extern "C" int vs_embed_mask(float* emb, int64_t ld, const int64_t* ids, int32_t B, int32_t L, int32_t vocab, int32_t shift,
+                             int32_t topk, int activate_lexical, int bow, int device, void* stream) {
+    if (!emb || B <= 0 || vocab <= 0 || shift < 0 || shift >= vocab || ld < vocab - shift) return fail(VS_EINVAL, "bad argument");
+    if ((bow || activate_lexical) && (!ids || L <= 0)) return fail(VS_EINVAL, "token ids required for bow / activate_lexical");
+    const int V = vocab - shift;
+    if (!bow && topk > V) return fail(VS_ERANGE, "selected index k out of range (k = %d, V = %d)", topk, V);
+    MaskArgs a{};
+    a.V = V; a.ld = ld; a.B = B; a.L = L; a.vocab = vocab; a.shift = shift; a.topk = topk; a.activate_lexical = activate_lexical; a.bow = bow ? 1 : 0;
+    return run_mask(a, nullptr, emb, ids, nullptr, device, (hipStream_t)stream);
+}
+
+extern "C" int vs_dense_to_csr(const float* x, int32_t B, int32_t V, int64_t ld, int64_t* rowptr, int32_t* cols, float* vals,
+                               int64_t cap, int device, void* stream) {
+    if (!x || !rowptr || B <= 0 || V <= 0 || ld < V) return fail(VS_EINVAL, "bad argument");
+    VS_TRY(check_device(device));
+    hipStream_t s = (hipStream_t)stream;
+    DevBuf st_x, counts, d_rp, st_c, st_v;
+    const void* dx = nullptr;
+    VS_TRY(to_device(x, ((size_t)(B - 1) * ld + V) * 4, st_x, s, &dx));
+    VS_TRY(counts.alloc((size_t)B * 8));
+    VS_TRY(d_rp.alloc((size_t)(B + 1) * 8));
+    hipLaunchKernelGGL(count_nz_kernel, dim3(std::min(B, 2048)), dim3(kSpThreads), 0, s, (const float*)dx, ld, B, V, counts.as<int64_t>());
+    hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(64), 0, s, counts.as<int64_t>(), B, d_rp.as<int64_t>());
+    VS_HIP(hipGetLastError());
+    std::vector<int64_t> rp((size_t)B + 1);
+    VS_HIP(hipMemcpyAsync(rp.data(), d_rp.p, rp.size() * 8, hipMemcpyDeviceToHost, s));
+    VS_HIP(hipStreamSynchronize(s));
+    if (is_device_ptr(rowptr)) VS_HIP(hipMemcpyAsync(rowptr, d_rp.p, rp.size() * 8, hipMemcpyDeviceToDevice, s));
+    else memcpy(rowptr, rp.data(), rp.size() * 8);
+    if (cols && vals) {
+        const int64_t nnz = rp[B];
+        if (nnz > cap) return fail(VS_EINVAL, "capacity %lld < nnz %lld", (long long)cap, (long long)nnz);
+        const bool o_host = !is_device_ptr(cols);
+        int32_t* dc = cols;
+        float* dv = vals;
+        if (o_host) {
+            VS_TRY(st_c.alloc(std::max<size_t>((size_t)nnz * 4, 4)));
+            VS_TRY(st_v.alloc(std::max<size_t>((size_t)nnz * 4, 4)));
+            dc = st_c.as<int32_t>();
+            dv = st_v.as<float>();
+        }
+        hipLaunchKernelGGL(fill_csr_kernel, dim3(std::min(B, 2048)), dim3(kSpThreads), 0, s, (const float*)dx, ld, B, V, d_rp.as<int64_t>(), dc, dv, nnz);
+        VS_HIP(hipGetLastError());
+        if (o_host && nnz > 0) {
+            VS_HIP(hipMemcpyAsync(cols, dc, (size_t)nnz * 4, hipMemcpyDeviceToHost, s));
+            VS_HIP(hipMemcpyAsync(vals, dv, (size_t)nnz * 4, hipMemcpyDeviceToHost, s));
+        }
+    }
+    VS_HIP(hipStreamSynchronize(s));
+    return VS_OK;
+}
+
+// ---- Retriever._build_bot_vectors (retriever.py:208-253): host-side integer set work ---------------
+extern "C" int vs_bot_build(const int32_t* tokens, const int64_t* offsets, int64_t n_docs, int32_t vocab, int32_t shift,
+                            int32_t max_token, int64_t* out_rowptr, int32_t* out_cols) {
+    if (!offsets || !out_rowptr || n_docs < 0 || vocab <= 0 || shift < 0 || shift > vocab) return fail(VS_EINVAL, "bad argument");
+    if (n_docs > 0 && !tokens && offsets[n_docs] > offsets[0]) return fail(VS_EINVAL, "tokens is NULL");
+    std::vector<uint32_t> stamp((size_t)vocab, 0u);     // last doc (1-based) that touched a token id
+    std::vector<int32_t> uniq;
+    out_rowptr[0] = 0;
+    for (int64_t d = 0; d < n_docs; ++d) {
+        uniq.clear();
+        const uint32_t tag = (uint32_t)(d % 0xFFFFFFFEull) + 1;
+        if (tag == 1 && d > 0) std::fill(stamp.begin(), stamp.end(), 0u);
+        for (int64_t p = offsets[d]; p < offsets[d + 1]; ++p) {
+            const int32_t t = tokens[p];
+            if (t < 0 || t >= vocab) return fail(VS_EINVAL, "token id %d out of range [0, %d) in doc %lld", t, vocab, (long long)d);
+            if (stamp[t] == tag) continue;
+            stamp[t] = tag;
+            uniq.push_back(t);                           // first-unique order (index_utils.py:11-21)
+            if (max_token > 0 && (int32_t)uniq.size() == max_token) break;
+        }
+        int64_t cnt = 0;
+        for (int32_t t : uniq) cnt += t >= shift;
+        out_rowptr[d + 1] = out_rowptr[d] + cnt;
+        if (out_cols) {
+            int32_t* dst = out_cols + out_rowptr[d];
+            int64_t w = 0;
+            for (int32_t t : uniq) if (t >= shift) dst[w++] = t - shift;
+            std::sort(dst, dst + w);
+        }
+    }
+    return VS_OK;
+}
