@@ -1,0 +1,363 @@
+"""GPU parity tests of the Python facade (vsearch_amd.ir == the reference's src.ir surface):
+sparsify helpers, Index / SparseIndex / BoTIndex, Retriever.retrieve / build_index / save / load,
+VDREncoder.embed -- against the reference goldens and the CPU oracle.  Run on MI355X.
+"""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import compare
+from conftest import V, VOCAB, SHIFT
+from vsearch_amd import synth
+from vsearch_amd.ir import BoTIndex, Index, IndexType, Retriever, SearchResults, SparseIndex
+from vsearch_amd.ir.utils import sparse as sp
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+
+
+def csr_tensor(ip, ix, d, n_cols=V):
+    return torch.sparse_csr_tensor(torch.from_numpy(ip), torch.from_numpy(ix.astype(np.int64)), torch.from_numpy(d), size=(len(ip) - 1, n_cols))
+
+
+# ---- src/ir/utils/sparse.py ---------------------------------------------------------------------------
+def test_elu1p(golden):
+    g = golden("sparse_utils")
+    out = sp.elu1p(torch.from_numpy(g["elu_in"]))
+    np.testing.assert_allclose(out.numpy(), g["elu_out"], rtol=2e-7, atol=1.2e-7)
+    assert sp.elu1p(torch.from_numpy(g["elu_in"]).cuda()).is_cuda
+
+
+@pytest.mark.parametrize("k", [1, 100, 768])
+def test_build_topk_mask(golden, k):
+    g = golden("sparse_utils")
+    x = synth.dense_tiefree(int(g["x_seed"]), (int(g["x_rows"]), V))
+    ref = np.unpackbits(g[f"mask_k{k}"], axis=1)[:, :V].astype(bool)
+    m = sp.build_topk_mask(torch.from_numpy(x), k=k)
+    assert m.dtype == torch.bool and (m.numpy() == ref).all()
+    assert (sp.build_topk_mask(x, k=k).numpy() == ref).all()             # numpy input branch (sparse.py:9-10)
+
+
+def test_topk_mask_ties_and_edges():
+    x = torch.tensor([[1., 3., 3., 2., 3., 3., 0., 3.], [5., 5., 5., 5., 5., 5., 5., 5.]])
+    m = sp.build_topk_mask(x, k=3)
+    assert m.tolist() == [[False, True, True, False, True, False, False, False], [True, True, True] + [False] * 5]
+    assert (m.numpy() == oracle.topk_mask(x.numpy(), 3)).all()
+    assert sp.build_topk_mask(x, k=8).all() and not sp.build_topk_mask(x, k=0).any()
+    with pytest.raises(RuntimeError):
+        sp.build_topk_mask(x, k=9)
+    neg = torch.tensor([[-1., -3., -0.5, -2.]])
+    assert sp.build_topk_mask(neg, k=2).tolist() == [[True, False, True, False]]
+
+
+def test_topk_sparsify(golden):
+    g = golden("sparse_utils")
+    x = synth.dense_tiefree(int(g["x_seed"]), (int(g["x_rows"]), V))
+    out = sp.topk_sparsify(torch.from_numpy(x).cuda(), 768).cpu().numpy()
+    r, c = np.nonzero(out)
+    assert (c.reshape(-1, 768) == g["sparsify_cols"]).all() and (out[r, c].reshape(-1, 768) == g["sparsify_vals"]).all()
+
+
+@pytest.mark.parametrize("batch", [0, 1])
+@pytest.mark.parametrize("norm", [False, True])
+def test_build_bow_mask(golden, batch, norm):
+    g = golden("bow_mask")
+    ids = g[f"b{batch}_ids"]
+    out = sp.build_bow_mask(torch.from_numpy(ids), vocab_size=VOCAB, shift_num=SHIFT, norm=norm).numpy()
+    tag = f"b{batch}_{'norm' if norm else 'raw'}"
+    r, c = np.nonzero(out)
+    assert out.shape == (ids.shape[0], V) and (r == g[f"{tag}_rows"]).all() and (c == g[f"{tag}_cols"]).all()
+    np.testing.assert_allclose(out[r, c], g[f"{tag}_vals"], rtol=1e-6)
+    assert (sp.build_bow_mask(torch.from_numpy(ids), VOCAB, 0).sum(1).numpy() == g[f"b{batch}_noshift_nnz"]).all()
+    with pytest.raises(RuntimeError):
+        sp.build_bow_mask(torch.tensor([[VOCAB]]), VOCAB, SHIFT)
+
+
+@pytest.mark.parametrize("name,kw", [
+    ("top768_lex", dict(topk=768, activate_lexical=True)), ("top768_nolex", dict(topk=768, activate_lexical=False)),
+    ("top0_lex", dict(topk=0, activate_lexical=True)), ("bow", dict(topk=0, activate_lexical=True, bow=True)),
+    ("top16_lex_bs4", dict(topk=16, activate_lexical=True)),
+])
+def test_embed_mask_stage(golden, name, kw):
+    g = golden("embed_mask")                                             # vdr.py:152-169
+    ids = torch.from_numpy(g["ids"])
+    emb = torch.from_numpy(synth.dense_tiefree(int(g["dense_seed"]), (ids.shape[0], V), 0.05, 6.0)).cuda()
+    sp.apply_embed_mask_(emb, ids, VOCAB, SHIFT, **kw)
+    out = emb.cpu().numpy()
+    r, c = np.nonzero(out)
+    assert (r == g[f"{name}_rows"]).all() and (c == g[f"{name}_cols"]).all() and (out[r, c] == g[f"{name}_vals"]).all()
+
+
+def test_head_pool_and_dense_to_csr(golden):
+    g = golden("encoder_head")
+    B, L, H, vocab, shift = g["shape"].tolist()
+    s = g["seeds"].tolist()
+    hidden = torch.from_numpy(synth.dense_uniform(s[0], (B, L, H), -2.0, 2.0)).cuda()
+    W = torch.from_numpy(synth.dense_uniform(s[1], (vocab, H), -0.08, 0.08)).cuda()
+    ln = torch.nn.LayerNorm(H).cuda()
+    with torch.no_grad():
+        ln.weight.copy_(torch.from_numpy(synth.dense_uniform(s[2], (H,), 0.5, 1.5)))
+        ln.bias.copy_(torch.from_numpy(synth.dense_uniform(s[3], (H,), -0.1, 0.1)))
+        logits = ln(hidden) @ W[shift:].t()
+    emb = sp.head_pool(logits)
+    np.testing.assert_allclose(emb.cpu().numpy(), g["emb"], rtol=1e-4, atol=1e-5)
+    assert (emb.cpu().numpy() == oracle.head_pool(logits.cpu().numpy())).all()      # same logits -> bit-equal pooling
+    masked = sp.topk_sparsify(emb, 64)
+    rp, ci, va = sp.dense_to_csr(masked)
+    want = masked.cpu().to_sparse_csr()
+    assert (rp.cpu() == want.crow_indices()).all() and (ci.cpu() == want.col_indices()).all() and (va.cpu() == want.values()).all()
+
+
+# ---- Index / SparseIndex / BoTIndex --------------------------------------------------------------------
+@pytest.mark.parametrize("device", ["cpu", "cuda"])
+def test_sparse_index_search_golden(golden, device):
+    g = golden("search_sparse_n2000")
+    ip, ix, d = oracle.synth_csr(0, 0, 2000)
+    idx = SparseIndex(device=device)
+    idx.vector = csr_tensor(ip, ix, d)
+    idx.move_to_device(device)
+    q = torch.from_numpy(oracle.synth_queries(1, 8))
+    res = idx.search(q, 100)
+    assert isinstance(res, SearchResults) and res.ids.dtype == torch.int64 and res.scores.dtype == torch.float32
+    assert res.ids.device.type == device and tuple(res.ids.shape) == (8, 100)
+    compare.compare_topk(g["ids_k100"], g["scores_k100"], res.ids.cpu().numpy(), res.scores.cpu().numpy(), rtol=RTOL)
+    v = idx.vector                                                        # exported back from the device format
+    assert v.layout == torch.sparse_csr and (v.col_indices().cpu().numpy() == ix).all() and (v.values().cpu().numpy() == d).all()
+    assert "SparseIndex" in str(idx) and "torch.sparse_csr" in str(idx) and "2000, 29523" in str(idx)
+    with pytest.raises(RuntimeError):
+        idx.search(q, 2001)
+
+
+def test_dense_index_search_golden(golden):
+    g = golden("search_dense")
+    ip, ix, d = oracle.synth_csr(0, 0, 2000)
+    idx = Index()
+    idx.vector = csr_tensor(ip, ix, d).to_dense()
+    idx.move_to_device("cuda")
+    res = idx.search(torch.from_numpy(oracle.synth_queries(1, 8)), 100)
+    compare.compare_topk(g["ids_k100"], g["scores_k100"], res.ids.cpu().numpy(), res.scores.cpu().numpy(), rtol=RTOL)
+
+
+def test_retrieve_and_rerank_golden(golden):
+    g = golden("retrieve")                                                # retriever.py:107-148 run unbound on a fake self
+    n, b, k = int(g["n"]), int(g["b"]), int(g["k"])
+    s_bot, s_par, s_q = g["seeds"].tolist()
+    ip, ix, d = oracle.synth_csr(s_bot, 0, n, V, 86, synth.KIND_BOT)
+    bot = BoTIndex()
+    bot.data = [str(i) for i in range(n)]
+    bot.vector = csr_tensor(ip, ix, d.astype(np.float32))
+    bot.move_to_device("cuda")
+    ip2, ix2, d2 = oracle.synth_csr(s_par, 0, n)
+    p_dense = csr_tensor(ip2, ix2, d2).to_dense().cuda()
+
+    def fake_embed(texts, batch_size=32, require_grad=False, **kw):
+        return p_dense[[int(t) for t in texts]]
+
+    fake = types.SimpleNamespace(index=bot, device="cuda", encoder_q=types.SimpleNamespace(config=types.SimpleNamespace(topk=768)),
+                                 encoder_p=types.SimpleNamespace(embed=fake_embed))
+    fake.process_query = types.MethodType(Retriever.process_query, fake)
+    fake._rerank = types.MethodType(Retriever._rerank, fake)
+    q = oracle.synth_queries(s_q, b)
+    r_t = Retriever.retrieve(fake, torch.from_numpy(q), k=k)
+    r_n = Retriever.retrieve(fake, q, k=k)                                # ndarray queries (retriever.py:96-97)
+    assert (r_t.ids == r_n.ids).all()
+    compare.compare_topk(g["ids"], g["scores"], r_t.ids.cpu().numpy(), r_t.scores.cpu().numpy(), rtol=RTOL)
+    r_r = Retriever.retrieve(fake, torch.from_numpy(q), k=k, rerank=True)
+    compare.compare_topk(g["rerank_ids"], g["rerank_scores"], r_r.ids.numpy(), r_r.scores.numpy(), rtol=RTOL)
+    sparse = SparseIndex()
+    sparse.data = bot.data
+    sparse.vector = csr_tensor(ip2, ix2, d2)
+    sparse.move_to_device("cuda")
+    r_s = Retriever.retrieve(fake, torch.from_numpy(q), k=k, rerank=True, index=sparse)   # passed index is honoured; rerank ignored
+    compare.compare_topk(g["sparse_ids"], g["sparse_scores"], r_s.ids.cpu().numpy(), r_s.scores.cpu().numpy(), rtol=RTOL)
+    with pytest.raises(NotImplementedError):
+        Retriever.process_query(fake, 3.14)
+
+
+def test_bot_index_fp16_dtype_and_exact_ids():
+    n = 3000
+    ip, ix, _ = oracle.synth_csr(3, 0, n, V, 86, synth.KIND_BOT)
+    idx = BoTIndex()
+    idx.vector = torch.sparse_csr_tensor(torch.from_numpy(ip), torch.from_numpy(ix.astype(np.int64)),
+                                         torch.ones(len(ix), dtype=torch.float16), size=(n, V))   # what _build_bot_vectors returns
+    idx.move_to_device("cuda")
+    q = oracle.synth_queries(5, 6, val_law=synth.VAL_DYADIC)
+    res = idx.search(torch.from_numpy(q), 100)
+    assert res.scores.dtype == torch.float16                             # scores come back in the index dtype (index.py:89-93)
+    o_ids, o_sc = oracle.csr_search(ip, ix, None, V, q.astype(np.float16).astype(np.float32), 100)
+    assert (res.ids.cpu().numpy() == o_ids).all()
+    assert (res.scores.cpu().numpy() == o_sc.astype(np.float16)).all()
+    bad = BoTIndex()
+    bad.vector = torch.sparse_csr_tensor(torch.tensor([0, 1]), torch.tensor([3]), torch.tensor([2.0]), size=(1, V))
+    with pytest.raises(ValueError, match="binary"):
+        bad.move_to_device("cuda")
+
+
+def test_save_load_roundtrip(golden, tmp_path):
+    g = golden("save_load")                                               # index.py:163-202
+    n = 10
+    ip, ix, d = oracle.synth_csr(int(g["seed"]), 0, 2 * n)
+    for s in range(2):
+        sl = slice(ip[s * n], ip[(s + 1) * n])
+        idx = SparseIndex(device="cuda")
+        idx.vector = csr_tensor(ip[s * n:(s + 1) * n + 1] - ip[s * n], ix[sl], d[sl])
+        idx.move_to_device("cuda")
+        idx.save(str(tmp_path / f"index{s}.npz"))
+    with np.load(tmp_path / "index0.npz") as z:
+        assert sorted(z.files) == g["manifest_keys"].tolist()
+        assert [str(z[k].dtype) for k in sorted(z.files)] == g["manifest_dtypes"].tolist()
+        assert (z["indices"] == g["reload_indices"]).all() and (z["data"] == g["reload_data"]).all() and (z["indptr"] == g["reload_indptr"]).all()
+    for tag, shift in (("shift0", 0), ("shift999", 999)):
+        li = SparseIndex(str(tmp_path / "index*.npz"), None, fp16=False, device="cuda", shift=shift)
+        v = li.vector
+        assert list(v.shape) == g[f"{tag}_shape"].tolist()
+        assert (v.crow_indices().cpu().numpy() == g[f"{tag}_indptr"]).all()
+        assert (v.col_indices().cpu().numpy() == g[f"{tag}_indices"]).all()
+        assert (v.values().cpu().numpy() == g[f"{tag}_data"]).all()
+    # fp16=True (the upstream default) is applied on the device
+    l16 = SparseIndex(str(tmp_path / "index*.npz"), None, device="cuda")
+    assert l16.vector.values().dtype == torch.float16
+    assert (l16.vector.values().cpu().numpy() == d.astype(np.float16)).all()
+    q = torch.from_numpy(oracle.synth_queries(2, 3))
+    r = l16.search(q, 5)
+    assert r.scores.dtype == torch.float16
+    o_ids, o_sc = oracle.csr_search(ip, ix, d.astype(np.float16).astype(np.float32), V, q.numpy().astype(np.float16).astype(np.float32), 5, acc64=True)
+    compare.compare_topk(o_ids, o_sc.astype(np.float16).astype(np.float32), r.ids.cpu().numpy(), r.scores.float().cpu().numpy(), rtol=1e-3)
+    # Retriever.load_index infers the type from the extension and accepts IndexType (upstream: str only)
+    rt = Retriever.__new__(Retriever)
+    torch.nn.Module.__init__(rt)
+    rt._dummy = torch.nn.Parameter(torch.zeros(1, device="cuda"))
+    Retriever.load_index(rt, index_file=str(tmp_path / "index0.npz"))
+    assert isinstance(rt.index, SparseIndex) and rt.index_type == IndexType.SPARSE
+    Retriever.load_index(rt, index_file=str(tmp_path / "index0.npz"), index_type=IndexType.SPARSE)
+    assert isinstance(rt.index, SparseIndex)
+    # dense .pt shards (broken upstream, index.py:36-44)
+    dense = csr_tensor(ip, ix, d).to_dense()
+    torch.save(dense[:n].clone(), tmp_path / "d0.pt")
+    torch.save(dense[n:].clone(), tmp_path / "d1.pt")
+    di = Index(str(tmp_path / "d*.pt"), None, fp16=False, device="cuda")
+    assert (di.vector.cpu() == dense).all()
+    di.save(str(tmp_path / "all.pt"))
+    assert (torch.load(tmp_path / "all.pt") == dense).all()
+
+
+# ---- encoder + build_index on a small random-init BERT -------------------------------------------------
+class FakeTokenizer:
+    """Whitespace 'tokenizer': texts are space-separated token ids (no WordPiece vocab offline)."""
+    vocab = range(VOCAB)
+
+    def _ids(self, texts, max_length, truncation):
+        out = []
+        for t in texts:
+            ids = [int(x) for x in t.split()]
+            if truncation and max_length and len(ids) > max_length:
+                ids = ids[:max_length - 1] + [102]
+            out.append(ids)
+        return out
+
+    def __call__(self, texts, max_length=None, truncation=False):
+        return {"input_ids": self._ids(texts, max_length, truncation)}
+
+    def batch_encode_plus(self, texts, padding=True, truncation=True, max_length=None, return_tensors="pt"):
+        from transformers import BatchEncoding
+        rows = self._ids(texts, max_length, truncation)
+        L = max(len(r) for r in rows)
+        ids = torch.tensor([r + [0] * (L - len(r)) for r in rows])
+        mask = torch.tensor([[1] * len(r) + [0] * (L - len(r)) for r in rows])
+        return BatchEncoding({"input_ids": ids, "token_type_ids": torch.zeros_like(ids), "attention_mask": mask})
+
+    def convert_ids_to_tokens(self, ids):
+        return [f"tok{i}" for i in ids]
+
+
+def make_texts(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        body = rng.integers(1996, 9000, size=int(rng.integers(5, 40)))
+        out.append(" ".join(map(str, [101] + body.tolist() + [102])))
+    return out
+
+
+@pytest.fixture(scope="module")
+def tiny_retriever():
+    from vsearch_amd.ir import RetrieverConfig
+    from vsearch_amd.ir.encoder.vdr import VDREncoder, VDREncoderConfig
+    torch.manual_seed(0)
+    kw = dict(hidden_size=64, num_hidden_layers=2, num_attention_heads=2, intermediate_size=128, vocab_size=VOCAB,
+              max_len=48, topk=32, random_init=True, type="vdr")
+    enc_q = VDREncoder(VDREncoderConfig(**kw), tokenizer=FakeTokenizer())
+    enc_p = VDREncoder(VDREncoderConfig(**kw), tokenizer=FakeTokenizer())
+    r = Retriever(RetrieverConfig(encoder_q=kw, encoder_p=kw), encoder_q=enc_q, encoder_p=enc_p)
+    return r.to("cuda").eval()
+
+
+def reference_embed(enc, texts, topk, activate_lexical=True, bow=False, max_len=None):
+    """vdr.py:97-179 restated with plain torch ops on the same weights (the torch fp32 reference for the HIP head)."""
+    import torch.nn.functional as F
+    encd = enc.encode(texts, max_len=max_len)
+    ids = encd["input_ids"]
+    bow_mask = torch.zeros([ids.shape[0], VOCAB], device=ids.device).scatter_(-1, ids, 1).bool().float()[:, SHIFT:]
+    if bow:
+        return bow_mask
+    with torch.no_grad():
+        h = enc.ln(enc.bert_model(**encd).last_hidden_state)
+        emb = (F.elu(h @ enc.bert_model.embeddings.word_embeddings.weight[SHIFT:].t()) + 1).max(1)[0]
+    if topk == 0:
+        tk = torch.zeros_like(emb)
+    elif topk in (None, -1):
+        tk = torch.ones_like(emb)
+    else:
+        tk = torch.zeros_like(emb, dtype=torch.bool).scatter_(-1, emb.topk(topk).indices, True)
+    mask = torch.logical_or(bow_mask, tk) if activate_lexical else tk
+    return emb * mask
+
+
+@pytest.mark.parametrize("kw", [dict(topk=32), dict(topk=32, activate_lexical=False), dict(topk=0), dict(topk=-1, activate_lexical=False), dict(bow=True)])
+def test_encoder_embed_matches_torch_reference(tiny_retriever, kw):
+    enc = tiny_retriever.encoder_q
+    texts = make_texts(7, 1)
+    got = enc.embed(texts, batch_size=3, **kw)
+    want = torch.cat([reference_embed(enc, texts[s:s + 3], kw.get("topk", 32), kw.get("activate_lexical", True), kw.get("bow", False))
+                      for s in range(0, 7, 3)])
+    assert got.shape == (7, V) and got.is_cuda
+    assert ((got != 0) == (want != 0)).all()
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-6)
+    assert isinstance(enc.embed(texts[0], convert_to_tensor=False, **kw), np.ndarray)
+    with pytest.raises(NotImplementedError):
+        enc.embed(texts, require_grad=True)
+
+
+@pytest.mark.parametrize("index_type", ["sparse", IndexType.DENSE, IndexType.BAG_OF_TOKEN])
+def test_build_index_and_retrieve_text_queries(tiny_retriever, index_type, tmp_path):
+    r = tiny_retriever
+    texts = make_texts(50, 2)
+    r.build_index(texts, batch_size=16, index_type=index_type)
+    assert len(r.index) == 50 and r.index.get_sample(3) == texts[3]
+    p_ref = torch.cat([reference_embed(r.encoder_p, texts[s:s + 16], 32, activate_lexical=False, max_len=128) for s in range(0, 50, 16)])
+    v = r.index.vector
+    if r.index.index_type == IndexType.BAG_OF_TOKEN:
+        toks = [[int(x) for x in t.split()] for t in texts]
+        o_ip, o_ix = oracle.bot_build(toks, VOCAB, SHIFT)
+        assert v.values().dtype == torch.float16 and (v.crow_indices().cpu().numpy() == o_ip).all() and (v.col_indices().cpu().numpy() == o_ix).all()
+        p_ref = (v.to_dense().float() != 0).float().cuda()
+    elif r.index.index_type == IndexType.SPARSE:
+        assert v.layout == torch.sparse_csr and ((v.to_dense() != 0).cuda() == (p_ref != 0)).all()
+        assert (torch.diff(v.crow_indices()) == 32).all()                  # exactly topk nnz per passage (activate_lexical=False)
+    else:
+        torch.testing.assert_close(v.cuda(), p_ref, rtol=1e-5, atol=1e-6)
+    queries = make_texts(5, 3)
+    res = r.retrieve(queries, k=10, a=32)
+    q_ref = reference_embed(r.encoder_q, queries, 32, activate_lexical=True)
+    want = (q_ref.double() @ p_ref.double().t()).float().cpu().numpy()
+    ids, sc = res.ids.cpu().numpy(), res.scores.float().cpu().numpy()
+    compare.check_topk_valid(want, ids, sc, rtol=1e-3 if r.index.index_type == IndexType.BAG_OF_TOKEN else RTOL)
+    one = r.retrieve(queries[0], k=3)                                     # single str query
+    assert tuple(one.ids.shape) == (1, 3)
+    path = str(tmp_path / ("idx.pt" if r.index.index_type == IndexType.DENSE else "idx.npz"))
+    r.save_index(path)
+    assert os.path.getsize(path) > 0

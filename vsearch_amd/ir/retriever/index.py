@@ -1,0 +1,320 @@
+"""Index containers with the reference's interface (/root/reference/src/ir/retriever/index.py:16-218),
+backed by the device-resident formats of libvsearch_hip.so.
+
+Same names, constructor arguments and return conventions as ``src.ir.retriever.index``:
+``Index`` (dense), ``SparseIndex`` (CSR), ``BoTIndex`` (binary bag-of-token CSR), ``SearchResults``,
+``IndexType``.  Differences, all supersets:
+  * ``search`` never materialises the [B, N] score matrix; ties are ordered (score desc, id asc);
+  * compute always runs on an MI355X: an index whose ``device`` is "cpu" keeps its API tensors on
+    the host but is searched on GPU 0 (there is no CPU fallback -- without a GPU it raises);
+  * loading a dense index from ``.pt`` shards and ``low_memory=True`` work (broken upstream);
+  * ``fp16=True`` is applied on the device (scipy >= 1.15 cannot ``astype(float16)`` a sparse array).
+"""
+from __future__ import annotations
+
+import glob
+import json
+import logging
+from enum import Enum
+from typing import List, NamedTuple, Optional
+
+import numpy as np
+import torch
+
+from ... import _native as nat
+from ...device_index import DeviceIndex
+
+logger = logging.getLogger(__name__)
+
+
+class SearchResults(NamedTuple):
+    ids: List[int]
+    scores: List[float]
+
+
+class IndexType(Enum):
+    DENSE = "dense"
+    SPARSE = "sparse"
+    BAG_OF_TOKEN = "bag_of_token"
+
+
+def _gpu_ordinal(device) -> int:
+    d = torch.device(device) if not isinstance(device, torch.device) else device
+    if d.type == "cuda":
+        return d.index if d.index is not None else torch.cuda.current_device()
+    return 0
+
+
+class Index:
+    index_type = IndexType.DENSE
+
+    def __init__(self, index_file: Optional[str] = None, data_file: Optional[str] = None, fp16: bool = True,
+                 device: str = "cpu", low_memory: bool = False):
+        self.data = None
+        self.low_memory = low_memory
+        self.device = device
+        self._vector = None            # torch view of the index (dense tensor / sparse CSR tensor), lazily exported
+        self._dev: Optional[DeviceIndex] = None
+        self._dtype = torch.float32    # dtype the reference would report for `vector` (scores are returned in it)
+        self._shape = None
+        self.init_index(index_file, fp16)
+        self.load_data(data_file)
+
+    # ---- the `vector` attribute of the reference: assignable and readable ----------------------
+    @property
+    def vector(self):
+        if self._vector is None and self._dev is not None:
+            self._vector = self._export_vector()
+        return self._vector
+
+    @vector.setter
+    def vector(self, value):
+        self._drop_device()
+        if value is not None and not isinstance(value, torch.Tensor):      # scipy CSR
+            value = torch.sparse_csr_tensor(torch.from_numpy(value.indptr), torch.from_numpy(value.indices),
+                                            torch.from_numpy(value.data), size=value.shape)
+        self._vector = value
+        if value is not None:
+            self._dtype = value.dtype
+            self._shape = tuple(value.shape)
+
+    def _drop_device(self):
+        if self._dev is not None:
+            self._dev.close()
+        self._dev = None
+
+    def _export_vector(self):
+        mat = self._dev.export_dense(np.float16 if self._dtype == torch.float16 else np.float32)
+        return torch.from_numpy(mat).to(self.device)
+
+    def _build_device_index(self) -> DeviceIndex:
+        v = self._vector
+        if v is None:
+            raise RuntimeError("index is empty: no vector to search")
+        if v.layout != torch.strided:
+            raise TypeError(f"{type(self).__name__} expects a dense tensor, got layout {v.layout}")
+        if v.dtype not in (torch.float32, torch.float16):
+            v = v.float()
+        store = nat.VS_F16 if v.dtype == torch.float16 else nat.VS_F32
+        return DeviceIndex.from_dense(v.contiguous(), store_dtype=store, device=_gpu_ordinal(self.device))
+
+    def _device_index(self) -> DeviceIndex:
+        if self._dev is None:
+            self._dev = self._build_device_index()
+        return self._dev
+
+    # ---- loading -------------------------------------------------------------------------------
+    def init_index(self, index_path: Optional[str], fp16: bool = True):
+        if not index_path:
+            return
+        files = sorted(glob.glob(index_path))
+        if not files:
+            raise FileNotFoundError(f"no index file matches {index_path!r}")
+        logger.info("***** Loading %s Index from %d files *****", self.index_type.value, len(files))
+        shards = [torch.load(f, map_location="cpu") for f in files]
+        vector = torch.cat(shards, dim=0) if len(shards) > 1 else shards[0]
+        self.vector = vector.to(torch.float16) if fp16 else vector
+        self.move_to_device(self.device)
+
+    def load_data(self, data_file: Optional[str]):
+        if not data_file:
+            return
+        if not self.low_memory:
+            with open(data_file, "r") as fh:
+                self.data = [json.loads(line) for line in fh]
+        else:
+            self.data_file = data_file
+            self.offsets = self._calculate_offsets(data_file)
+
+    def move_to_device(self, device: str):
+        logger.info("Moving index to %s.", device)
+        if self._vector is not None:
+            self._vector = self._vector.to(device)
+        same_gpu = self._dev is not None and self._dev.info().device == _gpu_ordinal(device)
+        if not same_gpu:
+            if self._vector is None and self._dev is not None:
+                self._vector = self._export_vector()
+            self._drop_device()
+        self.device = device
+        if self._vector is not None or self._dev is not None:
+            self._device_index()
+            if torch.device(device).type == "cuda" and self._vector is not None and self._keep_only_device_copy():
+                self._vector = None            # re-exported on demand; avoids a second device copy
+
+    def _keep_only_device_copy(self) -> bool:
+        return True
+
+    # ---- text store ----------------------------------------------------------------------------
+    @staticmethod
+    def _calculate_offsets(data_file: str):
+        offsets, pos = [], 0
+        with open(data_file, "rb") as fh:
+            for line in fh:
+                offsets.append(pos)
+                pos += len(line)
+        return offsets
+
+    def _load_line(self, file_path: str, offset: int):
+        with open(file_path, "rb") as fh:
+            fh.seek(offset)
+            return json.loads(fh.readline().decode("utf-8"))
+
+    def get_sample(self, index: int):
+        if not self.low_memory:
+            return self.data[index]
+        return self._load_line(self.data_file, self.offsets[index])
+
+    # ---- search (index.py:88-94) -------------------------------------------------------------------
+    def search(self, q_embs: torch.Tensor, k: int) -> SearchResults:
+        if isinstance(q_embs, np.ndarray):
+            q_embs = torch.from_numpy(q_embs)
+        dev_index = self._device_index()
+        gpu = torch.device("cuda", dev_index.info().device)
+        q = q_embs.detach().to(gpu)
+        q = q.to(self._dtype) if self._dtype in (torch.float16, torch.float32) else q.float()   # `.type(self.vector.dtype)`
+        if q.dim() == 1:
+            q = q.unsqueeze(0)
+        ids, scores = dev_index.search(q.contiguous(), int(k))
+        scores = scores.to(self._dtype)
+        if torch.device(self.device).type != "cuda":
+            ids, scores = ids.cpu(), scores.cpu()
+        return SearchResults(ids, scores)
+
+    # ---- persistence -------------------------------------------------------------------------------
+    def save(self, path):
+        """Dense index -> ``.pt`` (torch.save of the CPU tensor), like index.py:96-109."""
+        try:
+            torch.save(self.vector.cpu(), path)
+            logger.info("Index successfully saved to %s", path)
+        except Exception as exc:
+            logger.error("Failed to save index to %s: %s", path, exc)
+            raise
+
+    def __len__(self):
+        if self.data:
+            return len(self.data)
+        return len(getattr(self, "offsets", [])) if self.low_memory else 0
+
+    def __repr__(self):
+        return repr(self.vector)
+
+    def _vector_meta(self):
+        if self._vector is not None:
+            return self._vector.shape, self._vector.dtype, self._vector.layout
+        if self._dev is not None:
+            info = self._dev.info()
+            layout = torch.strided if info.kind == nat.VS_KIND_DENSE else torch.sparse_csr
+            return torch.Size([info.n_rows, info.n_cols]), self._dtype, layout
+        return None, None, None
+
+    def __str__(self):
+        shape, dtype, layout = self._vector_meta()
+        rows = [("Index Type", type(self).__name__), ("Vector Shape", shape), ("Vector Dtype", dtype),
+                ("Vector Layout", layout), ("Number of Texts", len(self.data) if self.data else 0), ("Device", self.device)]
+        return "".join(f"{name:<18}: {value}\n" for name, value in rows)
+
+
+class SparseIndex(Index):
+    index_type = IndexType.SPARSE
+
+    def __init__(self, index_file: Optional[str] = None, data_file: Optional[str] = None, fp16: bool = True,
+                 device: str = "cpu", low_memory: bool = False, shift: int = 0):
+        self.shift = shift
+        super().__init__(index_file, data_file, fp16, device, low_memory)
+
+    # -- conversions ---------------------------------------------------------------------------------
+    @staticmethod
+    def _csr_parts(v):
+        """torch sparse CSR tensor | scipy CSR -> (indptr, indices, data, (n_rows, n_cols))."""
+        if isinstance(v, torch.Tensor):
+            if v.layout != torch.sparse_csr:
+                v = v.to_sparse_csr()
+            return v.crow_indices(), v.col_indices(), v.values(), tuple(v.shape)
+        return v.indptr, v.indices, v.data, tuple(v.shape)         # scipy.sparse.csr_array / csr_matrix
+
+    def _binary(self) -> bool:
+        return False
+
+    def _build_device_index(self) -> DeviceIndex:
+        v = self._vector
+        if v is None:
+            raise RuntimeError("index is empty: no vector to search")
+        indptr, indices, data, shape = self._csr_parts(v)
+        if isinstance(data, torch.Tensor) and data.dtype not in (torch.float32, torch.float16):
+            data = data.float()
+        if isinstance(data, np.ndarray) and data.dtype not in (np.float32, np.float16):
+            data = data.astype(np.float32)
+        if self._binary():
+            ok = bool((data == 1).all())
+            if not ok:
+                raise ValueError("BoTIndex expects a binary matrix (every stored value == 1)")
+            store, data = nat.VS_NONE, None
+        else:
+            store = nat.VS_F16 if self._dtype == torch.float16 else nat.VS_F32
+        return DeviceIndex.from_csr(indptr, indices, data, shape[1], store_dtype=store, device=_gpu_ordinal(self.device))
+
+    def _export_vector(self):
+        indptr, indices, data = self._dev.export_csr(np.float16 if self._dtype == torch.float16 else np.float32)
+        info = self._dev.info()
+        t = torch.sparse_csr_tensor(torch.from_numpy(indptr), torch.from_numpy(indices), torch.from_numpy(data),
+                                    size=(info.n_rows, info.n_cols))
+        return t.to(self.device)
+
+    def _scipy_csr_to_torch_csr(self, mat) -> torch.Tensor:
+        t = torch.sparse_csr_tensor(torch.from_numpy(mat.indptr), torch.from_numpy(mat.indices), torch.from_numpy(mat.data), size=mat.shape)
+        return t.to(self.device)
+
+    # -- loading (index.py:163-179) ------------------------------------------------------------------
+    def init_index(self, index_file: Optional[str], fp16: bool = True):
+        if not index_file:
+            return
+        from scipy.sparse import load_npz, vstack
+        files = sorted(glob.glob(index_file))
+        if not files:
+            raise FileNotFoundError(f"no index file matches {index_file!r}")
+        logger.info("***** Loading %s Index from %d files *****", self.index_type.value, len(files))
+        shards = [load_npz(f).tocsr()[:, self.shift:] for f in files]
+        mat = vstack(shards).tocsr() if len(shards) > 1 else shards[0]
+        mat.sort_indices()
+        self._drop_device()
+        self._dtype = torch.float16 if fp16 else torch.float32
+        self._shape = tuple(mat.shape)
+        data = mat.data.astype(np.float32, copy=False)
+        if self._binary():
+            if not bool((data == 1).all()):
+                raise ValueError("BoTIndex expects a binary matrix (every stored value == 1)")
+            store, data = nat.VS_NONE, None
+        else:
+            store = nat.VS_F16 if fp16 else nat.VS_F32           # fp32 -> fp16 conversion happens on the device
+        logger.info("***** Converting Sparse index to the device CSR format *****")
+        self._vector = None
+        self._dev = DeviceIndex.from_csr(mat.indptr, mat.indices, data, mat.shape[1], store_dtype=store, device=_gpu_ordinal(self.device))
+
+    # -- persistence (index.py:181-202) --------------------------------------------------------------
+    def save(self, path):
+        """CSR index -> scipy ``.npz`` (keys indices, indptr, data, shape, format; int64 indices)."""
+        from scipy.sparse import csr_array, save_npz
+        try:
+            if self._dev is not None:
+                indptr, indices, data = self._dev.export_csr(np.float16 if self._dtype == torch.float16 else np.float32)
+                info = self._dev.info()
+                shape = (info.n_rows, info.n_cols)
+            else:
+                ip, ix, d, shape = self._csr_parts(self._vector)
+                indptr, indices, data = ip.cpu().numpy(), ix.cpu().numpy(), d.cpu().numpy()
+            save_npz(path, csr_array((data, indices, indptr), shape=shape))
+            logger.info("Index successfully saved to %s", path)
+        except Exception as exc:
+            logger.error("Failed to save index to %s: %s", path, exc)
+            raise
+
+
+class BoTIndex(SparseIndex):
+    index_type = IndexType.BAG_OF_TOKEN
+
+    def __init__(self, index_file: Optional[str] = None, data_file: Optional[str] = None, fp16: bool = True,
+                 device: str = "cpu", low_memory: bool = False, shift: int = 0):
+        super().__init__(index_file, data_file, fp16, device, low_memory, shift)
+
+    def _binary(self) -> bool:
+        return True
