@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py -- queries/sec of the vocabulary-space retrieval hot path on MI355X.
+
+Metric (BASELINE.json): queries/sec over a 21 M-doc sparse CSR index (V = 29 523, 768 nnz/doc, fp32),
+k = 100.  One "step" = one batch of B = 1024 synthetic queries (768 + 8 nnz each) searched against
+the whole index: CSR scoring pass + fused top-k + merge (+ one all-gather and a final merge when the
+index is row-sharded over N GPUs).  Index and queries are resident in HBM when the timed region
+starts.  Strong scaling: the 21 015 324-row index is re-partitioned over the N ranks.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel: the CSR scan, HBM-bound) and
+`cpu_baseline` (the reference's three torch calls, oracle/torch_ref.py, timed on this host).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+N_DOCS = 21_015_324          # Wiki21M (test/svdr_wiki21m/build_binary_token_index.sh:14)
+V = 29_523
+NNZ_DOC = 768
+NNZ_Q = 776
+BATCH = 1024
+K = 100
+INDEX_SEED, QUERY_SEED = 0, 1
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--docs", type=int, default=N_DOCS, help="total index rows (default: the metric's 21 015 324)")
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--k", type=int, default=K)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-docs", type=int, default=100_000)
+    return ap.parse_args()
+
+
+def make_query_batches(n_batches, batch, device):
+    """Distinct synthetic query batches (host generation, then resident in HBM)."""
+    import oracle          # only its synthetic generator twin is used here (inputs, not results)
+    out = []
+    for i in range(n_batches):
+        q = oracle.synth_queries(QUERY_SEED, batch, V, NNZ_Q, 0, q0=i * batch)
+        out.append(torch.from_numpy(q).to(device))
+    return out
+
+
+def parity_check(device):
+    """Small prefix of the same synthetic index (rows are a pure function of (seed, row id)) searched
+    by the HIP path and by the CPU oracle: recall@100 and max relative score error."""
+    import oracle
+    from oracle import compare
+    from vsearch_amd.device_index import DeviceIndex
+    n = 20_000
+    idx = DeviceIndex.synthetic(INDEX_SEED, 0, n, V, NNZ_DOC, 0, 0, 0, device)
+    q = oracle.synth_queries(QUERY_SEED, 8, V, NNZ_Q)
+    ids, sc = idx.search(q, K)
+    ip, ix, d = idx.export_csr()
+    o_ids, o_sc, allsc = oracle.csr_search(ip, ix.astype(np.int32), d, V, q, K, acc64=True, return_all=True)
+    compare.check_topk_valid(allsc, ids, sc, rtol=1e-4)
+    rel = float(np.max(np.abs(sc.astype(np.float64) - o_sc) / np.abs(o_sc)))
+    return {"docs": n, "queries": 8, "recall_at_100_vs_oracle": compare.recall_at_k(o_ids, ids), "max_rel_score_err": rel}
+
+
+def cpu_baseline(sample_docs, device):
+    """The reference's Index.search (index.py:89-92: cast, torch.matmul(q, csr.t()), topk) restated in
+    oracle/torch_ref.py and timed on this box's host cores on a bounded sample of the same index."""
+    from oracle import torch_ref
+    from vsearch_amd.device_index import DeviceIndex
+    n = sample_docs
+    idx = DeviceIndex.synthetic(INDEX_SEED, 0, n, V, NNZ_DOC, 0, 0, 0, device)   # bit-identical rows, generated on the GPU
+    ip, ix, d = idx.export_csr()
+    idx.close()
+    vec = torch_ref.make_csr(ip, ix, d, (n, V))
+    import oracle
+    bq = 32
+    q = torch.from_numpy(oracle.synth_queries(QUERY_SEED, bq, V, NNZ_Q))
+    torch_ref.search(vec, q, K)                                   # warm-up
+    reps, t0 = 0, time.perf_counter()
+    while reps < 3 or (time.perf_counter() - t0 < 10.0 and reps < 50):
+        torch_ref.search(vec, q, K)
+        reps += 1
+    dt = (time.perf_counter() - t0) / reps
+    qps_sample = bq / dt
+    return {"value": qps_sample * n / N_DOCS, "unit": "queries/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"reference Index.search restated (torch {torch.__version__} CPU sparse-CSR matmul + topk, fp32): "
+                      f"{n} of the same synthetic docs x 768 nnz, {bq}-query batches, {reps} timed calls, "
+                      f"{qps_sample:.1f} q/s on the sample, scaled linearly in nnz to {N_DOCS} docs",
+            "sample_qps": qps_sample, "host_cpus": os.cpu_count()}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
+    import torch.distributed as dist
+    from vsearch_amd import _native as nat
+    from vsearch_amd.device_index import DeviceIndex, Profile
+    from vsearch_amd.distributed import ShardedSearcher, shard_rows
+    nat.require_device()
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    row0, n_local = shard_rows(args.docs, world, rank)
+    t0 = time.perf_counter()
+    index = DeviceIndex.synthetic(INDEX_SEED, row0, n_local, V, NNZ_DOC, 0, 0, nat.VS_F32, local_rank)
+    info = index.info()
+    build_s = time.perf_counter() - t0
+    searcher = ShardedSearcher.from_device_index(index, row0, args.docs)
+    batches = make_query_batches(min(4, args.steps + args.warmup), args.batch, device)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step(i):
+        return searcher.search(batches[i % len(batches)], args.k)
+
+    for i in range(args.warmup):
+        step(i)
+    Profile.enable(True)
+    Profile.reset()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ids, scores = step(args.warmup + i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    Profile.enable(False)
+    scan_ms, scan_launches = Profile.read("csr_scan_topk")
+    merge_ms, _ = Profile.read("merge_topk")
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        qps = args.steps * args.batch / elapsed
+        # dominant kernel: csr_scan_topk. One launch scores `queries_per_launch` queries, Qt per pass.
+        qt = max(1, info.queries_per_pass)
+        queries_per_launch = args.steps * args.batch / max(1, scan_launches)
+        passes_per_launch = -(-queries_per_launch // qt)
+        algo_bytes_per_launch = passes_per_launch * info.bytes_per_pass
+        avg_launch_s = scan_ms / 1e3 / max(1, scan_launches)
+        achieved = algo_bytes_per_launch / avg_launch_s / 1e9
+        traffic = None
+        pmc = os.path.join(REPO, "profiles", "pmc_summary.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("csr_scan_topk", {}).get("hbm_bytes_per_launch_at_bench_shape")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "queries/sec over 21M-doc sparse index, k=100; recall@100 vs reference",
+            "value": qps, "unit": "queries/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"wiki21m-shaped sparse CSR index: {args.docs} docs x {NNZ_DOC} nnz, V={V}, fp32 values, "
+                                   f"row-sharded over {world} GPU(s); {args.batch} queries/step ({NNZ_Q} nnz), k={args.k}",
+                       "docs": args.docs, "docs_per_gpu": n_local, "batch": args.batch, "k": args.k, "queries_per_pass": qt,
+                       "lanes_per_row": info.lanes_per_row, "index_bytes_per_gpu": info.device_bytes,
+                       "index_build_s": round(build_s, 2)},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "kernel": "csr_scan_topk", "launches": scan_launches,
+                         "avg_launch_ms": avg_launch_s * 1e3, "algorithmic_bytes_per_launch": algo_bytes_per_launch,
+                         "bytes_per_pass": info.bytes_per_pass, "merge_ms_total": merge_ms},
+        }
+        if world == 1:
+            line["parity"] = parity_check(local_rank)
+            if not args.no_cpu_baseline:
+                line["cpu_baseline"] = cpu_baseline(args.cpu_sample_docs, local_rank)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -305,7 +305,6 @@ static inline float synth_val(uint64_t seed, int64_t row, uint32_t col, int val_
     if (val_law == 1) return (1.0f + (float)(h % 255ull)) / 64.0f;
     return 1.0f;
 }
-static int u32_cmp(const void* a, const void* b) { uint32_t x = *(const uint32_t*)a, y = *(const uint32_t*)b; return (x > y) - (x < y); }
 
 /* indices == NULL -> fill indptr only. kind: 0 = fixed nnz, 1 = BoT lengths (binary). */
 VSO_API int vso_synth_csr(uint64_t seed, int64_t row0, int64_t n_rows, int32_t n_cols, int32_t nnz, int kind,
@@ -314,15 +313,28 @@ VSO_API int vso_synth_csr(uint64_t seed, int64_t row0, int64_t n_rows, int32_t n
     indptr[0] = 0;
     for (int64_t r = 0; r < n_rows; ++r) indptr[r + 1] = indptr[r] + row_len(seed, row0 + r, kind, nnz, n_cols);
     if (!indices) return 0;
-    uint32_t* tmp = (uint32_t*)malloc(sizeof(uint32_t) * 65536);
+    /* columns of a row are distinct: set them in a bitmap, then read the bitmap in ascending order
+       (same result as sorting; far fewer cycles than qsort for 768 entries out of 29 523) */
+    const int words = (n_cols + 63) / 64;
+    uint64_t* tmp = (uint64_t*)calloc((size_t)words, sizeof(uint64_t));
     for (int64_t r = 0; r < n_rows; ++r) {
         int64_t row = row0 + r, len = indptr[r + 1] - indptr[r];
         uint64_t key = hash3(seed, (uint64_t)row, 0x4B4559ull);
-        for (int64_t j = 0; j < len; ++j) tmp[j] = perm_col(key, (uint32_t)j, (uint32_t)n_cols);
-        qsort(tmp, (size_t)len, sizeof(uint32_t), u32_cmp);
         for (int64_t j = 0; j < len; ++j) {
-            indices[indptr[r] + j] = (int32_t)tmp[j];
-            if (data) data[indptr[r] + j] = (kind == 1) ? 1.0f : synth_val(seed, row, tmp[j], val_law);
+            uint32_t c = perm_col(key, (uint32_t)j, (uint32_t)n_cols);
+            tmp[c >> 6] |= 1ull << (c & 63);
+        }
+        int64_t w = indptr[r];
+        for (int i = 0; i < words; ++i) {
+            uint64_t bits = tmp[i];
+            tmp[i] = 0;
+            while (bits) {
+                uint32_t c = (uint32_t)i * 64 + (uint32_t)__builtin_ctzll(bits);
+                bits &= bits - 1;
+                indices[w] = (int32_t)c;
+                if (data) data[w] = (kind == 1) ? 1.0f : synth_val(seed, row, c, val_law);
+                ++w;
+            }
         }
     }
     free(tmp);
