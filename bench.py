@@ -168,7 +168,10 @@ def main():
         pmc = os.path.join(REPO, "profiles", "pmc_summary.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("csr_scan_topk", {}).get("hbm_bytes_per_launch_at_bench_shape")
+                # PMC counters cannot be read in-process: per-query HBM bytes of this kernel come from the committed
+                # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the same 21 M-doc index (profiles/pmc_summary.json)
+                per_pass = json.load(open(pmc)).get("csr_scan_topk", {}).get("hbm_bytes_per_pass_21m")
+                traffic = per_pass * passes_per_launch * (n_local / N_DOCS) if per_pass else None
             except Exception:
                 traffic = None
         line = {

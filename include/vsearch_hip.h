@@ -68,7 +68,7 @@ typedef struct vs_index_info_t {
     int64_t device_bytes;    /* bytes of the device-resident index                                    */
     int64_t bytes_per_pass;  /* algorithmic HBM bytes one scoring pass streams      */
     int32_t lanes_per_row;   /* CSR scan geometry                                                     */
-    int32_t queries_per_pass;/* Qt of the scan kernel that search() would pick                        */
+    int32_t queries_per_pass;/* Qt of the most recent search() (the planned default before any search)   */
 } vs_index_info_t;
 
 /* ---- library ------------------------------------------------------------------------------- */
@@ -113,6 +113,11 @@ VS_API int vs_index_scores(vs_index* index, const void* q, int q_dtype, int64_t 
                            float* out_scores, void* stream);
 
 VS_API int  vs_index_info(const vs_index* index, vs_index_info_t* out);
+
+/* Scan selection (tuning / tests; no reference counterpart): 0 = auto -- score tiles of 8 sparse queries
+ * per pass over the index when the batch qualifies (k <= 1024, every query sparse enough for the LDS
+ * tile tables), else one query per pass with a dense fp32 query image;  1 = always the latter.      */
+VS_API int  vs_index_set_queries_per_pass(vs_index* index, int qt);
 
 /* SparseIndex.save (index.py:181-202) needs crow/col/values back: int64 rowptr [n_rows+1], int64
  * colidx [nnz], values [nnz] as val_dtype (VS_F32 | VS_F16).  Pass NULL colidx/values to get rowptr

@@ -30,12 +30,15 @@ def test_library_reports_gfx950_device():
     assert nat.lib().vs_version() >= 100
 
 
-@pytest.mark.parametrize("k", [1, 100, 128, 129, 2000])
-def test_sparse_fp32_vs_golden_and_oracle(golden, sparse2000, k):
+@pytest.mark.parametrize("qt", [0, 1], ids=["multi-query", "dense-image"])
+@pytest.mark.parametrize("k", [1, 100, 128, 129, 1024, 2000])
+def test_sparse_fp32_vs_golden_and_oracle(golden, sparse2000, k, qt):
     ip, ix, d, idx = sparse2000
     g = golden("search_sparse_n2000")
     q = oracle.synth_queries(1, 8)
+    idx.set_queries_per_pass(qt)
     ids, sc = idx.search(q, k)
+    idx.set_queries_per_pass(0)
     o_ids, o_sc, allsc = oracle.csr_search(ip, ix, d, V, q, k, acc64=True, return_all=True)
     compare.check_topk_valid(allsc, ids, sc, rtol=RTOL)
     compare.compare_topk(o_ids, o_sc, ids, sc, rtol=RTOL)
@@ -52,15 +55,45 @@ def test_sparse_all_scores_match_oracle(sparse2000):
     np.testing.assert_allclose(got, want, rtol=2e-6, atol=1e-6)
 
 
-def test_sparse_n20000_golden(golden):
+@pytest.mark.parametrize("qt", [0, 1], ids=["multi-query", "dense-image"])
+def test_sparse_n20000_golden(golden, qt):
     g = golden("search_sparse_n20000")
     ip, ix, d = oracle.synth_csr(0, 0, 20000)
     idx = DeviceIndex.from_csr(ip, ix, d, V)
+    idx.set_queries_per_pass(qt)
     q = oracle.synth_queries(1, 32)
     ids, sc = idx.search(q, 100)
+    assert idx.info().queries_per_pass == (8 if qt == 0 else 1)
     compare.compare_topk(g["ids_k100"], g["scores_k100"], ids, sc, rtol=RTOL)
-    _, _, allsc = oracle.csr_search(ip, ix, d, V, q, 100, acc64=True, return_all=True)
+    o_ids, o_sc, allsc = oracle.csr_search(ip, ix, d, V, q, 100, acc64=True, return_all=True)
     compare.check_topk_valid(allsc, ids, sc, rtol=RTOL)
+    compare.compare_topk(o_ids, o_sc, ids, sc, rtol=RTOL)
+
+
+def test_multi_query_tiles_ragged_batches_and_dense_fallback():
+    """Tile planning: batch sizes that are not multiples of 8, queries of very different density, and a
+    query too dense for the LDS tile tables (whole batch falls back to the dense-image pass)."""
+    n = 3000
+    ip, ix, d = oracle.synth_csr(21, 0, n, V, 200)
+    idx = DeviceIndex.from_csr(ip, ix, d, V)
+    rng = np.random.default_rng(1)
+    q = np.zeros((13, V), np.float32)
+    for i, nz in enumerate([1, 5, 776, 2000, 40, 776, 3000, 9, 776, 776, 100, 2, 1500]):
+        cols = rng.choice(V, size=nz, replace=False)
+        q[i, cols] = rng.uniform(-1, 2, size=nz).astype(np.float32)
+    o_ids, o_sc, allsc = oracle.csr_search(ip, ix, d, V, q, 64, acc64=True, return_all=True)
+    ids, sc = idx.search(q, 64)
+    assert idx.info().queries_per_pass == 8
+    compare.check_topk_valid(allsc, ids, sc, rtol=RTOL)
+    compare.compare_topk(o_ids, o_sc, ids, sc, rtol=RTOL, tie_rtol=1e-5)
+    q[4] = rng.uniform(0, 1, size=V).astype(np.float32)              # fully dense query
+    o_ids, o_sc, allsc = oracle.csr_search(ip, ix, d, V, q, 64, acc64=True, return_all=True)
+    ids, sc = idx.search(q, 64)
+    assert idx.info().queries_per_pass == 1
+    compare.check_topk_valid(allsc, ids, sc, rtol=RTOL)
+    empty = np.zeros((3, V), np.float32)                               # all-zero queries: every score 0, lowest ids win
+    ids, sc = idx.search(empty, 5)
+    assert (ids == np.arange(5)).all() and (sc == 0).all()
 
 
 def test_k_gt_n_raises_like_topk(sparse2000):
@@ -90,7 +123,8 @@ def test_bot_binary_index(golden, tag, exact):
     assert idx.info().store_dtype == nat.VS_NONE
     seed = int(g["query_seeds"][1 if exact else 0])
     q = oracle.synth_queries(seed, b, val_law=synth.VAL_DYADIC if exact else synth.VAL_GRID)
-    for k in (10, 100):
+    for k, qt in ((10, 0), (100, 0), (100, 1)):
+        idx.set_queries_per_pass(qt)
         ids, sc = idx.search(q, k)
         compare.compare_topk(g[f"{tag}_ids_k{k}"], g[f"{tag}_scores_k{k}"], ids, sc, rtol=RTOL, exact=exact)
         o_ids, o_sc, allsc = oracle.csr_search(ip, ix, None, V, q, k, return_all=True)

@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Turn rocprofv3 rocpd databases (gpurun_out/<dir>/*_results.db) into the small text / JSON
+summaries committed under profiles/.
+
+    python tools/rocprof_summary.py --stats gpurun_out/prof_stats/r01_results.db \
+        --fetch gpurun_out/prof_fetch/r01_results.db --write gpurun_out/prof_write/r01_results.db \
+        --tag r01 --note "bench.py --steps 2 --warmup 1"
+
+HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md §HBM: FETCH_SIZE / WRITE_SIZE are in KiB,
+collected in separate --pmc passes; on gfx950 FETCH_SIZE reports 1/2 of the bytes of a wide
+(16 B/lane) coalesced streaming read, so the read side is doubled.
+"""
+import argparse
+import json
+import os
+import sqlite3
+
+
+def top_kernels(db):
+    con = sqlite3.connect(db)
+    rows = con.execute("select name, total_calls, total_duration, average, percentage from top_kernels").fetchall()
+    per = con.execute("select name, (end - start) from kernels order by start").fetchall()
+    return rows, per
+
+
+def counters(db, counter):
+    con = sqlite3.connect(db)
+    return con.execute("select kernel_name, grid_size, sum(value), count(*) from counters_collection where counter_name = ? "
+                       "group by kernel_name, dispatch_id order by dispatch_id", (counter,)).fetchall()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--stats")
+    ap.add_argument("--fetch")
+    ap.add_argument("--write")
+    ap.add_argument("--tag", required=True)
+    ap.add_argument("--note", default="")
+    ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles"))
+    a = ap.parse_args()
+    os.makedirs(a.out, exist_ok=True)
+    summary = {"tag": a.tag, "note": a.note}
+    if a.stats:
+        rows, per = top_kernels(a.stats)
+        with open(os.path.join(a.out, f"{a.tag}_kernel_stats.txt"), "w") as f:
+            f.write(f"# rocprofv3 --kernel-trace --stats   ({a.note})\n# durations in milliseconds\n")
+            f.write(f"{'kernel':100s} {'calls':>6s} {'total_ms':>14s} {'avg_ms':>14s} {'pct':>7s}\n")
+            for name, calls, tot, avg, pct in rows:            # top_kernels reports microseconds
+                f.write(f"{name[:100]:100s} {calls:6d} {tot / 1e3:14.3f} {avg / 1e3:14.3f} {pct:7.3f}\n")
+            f.write("\n# per dispatch (launch order), ms\n")
+            for name, dur in per:                              # kernels view: end - start in nanoseconds
+                f.write(f"{name[:100]:100s} {dur / 1e6:14.3f}\n")
+        summary["kernel_stats"] = [{"kernel": r[0], "calls": r[1], "total_ms": r[2] / 1e3, "avg_ms": r[3] / 1e3, "pct": r[4]} for r in rows]
+        summary["dispatches"] = [{"kernel": n, "ms": d / 1e6} for n, d in per]
+    for key, db, counter in (("fetch", a.fetch, "FETCH_SIZE"), ("write", a.write, "WRITE_SIZE")):
+        if db:
+            rows = counters(db, counter)
+            summary[counter] = [{"kernel": r[0], "grid": r[1], "KiB": r[2]} for r in rows]
+            with open(os.path.join(a.out, f"{a.tag}_{counter.lower()}.txt"), "w") as f:
+                f.write(f"# rocprofv3 --pmc {counter}   ({a.note})\n# value = sum over XCDs/instances, KiB; per dispatch in launch order\n")
+                for name, grid, val, n in rows:
+                    f.write(f"{name[:100]:100s} grid={grid:<10d} {val:18.1f}\n")
+    with open(os.path.join(a.out, f"{a.tag}_summary.json"), "w") as f:
+        json.dump(summary, f, indent=1)
+    print(json.dumps({k: v for k, v in summary.items() if k in ("tag", "note")}))
+
+
+if __name__ == "__main__":
+    main()

@@ -59,6 +59,13 @@ extern "C" int vs_index_scores(vs_index* idx, const void* q, int q_dtype, int64_
     return VS_OK;
 }
 
+extern "C" int vs_index_set_queries_per_pass(vs_index* idx, int qt) {
+    if (!idx) return fail(VS_EINVAL, "NULL argument");
+    if (qt != 0 && qt != 1) return fail(VS_EINVAL, "queries_per_pass: 0 = auto, 1 = dense-image pass");
+    idx->qt_pref = qt;
+    return VS_OK;
+}
+
 extern "C" int vs_profile_enable(int on) {
     Profiler::get().on = on != 0;
     return VS_OK;

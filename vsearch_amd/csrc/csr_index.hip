@@ -2,6 +2,7 @@
 //   reference: src/ir/retriever/index.py:128-218 (containers), :88-94 (search)
 #include "common.h"
 #include "csr_scan.h"
+#include "csr_scan_mq.h"
 #include "synth_device.h"
 
 #include <algorithm>
@@ -352,6 +353,8 @@ extern "C" int vs_index_create_synthetic(uint64_t seed, int64_t row0, int64_t n_
 // =================================================================================================
 // info / export / destroy
 // =================================================================================================
+constexpr int kQT = 8;   // queries per pass of the multi-query scan (csr_scan_mq.h)
+
 static int64_t csr_bytes_per_pass(const vs_index* idx) {
     const int64_t per_packet = 16 + (idx->store_dtype == VS_F32 ? 32 : idx->store_dtype == VS_F16 ? 16 : 0);
     return idx->n_packets * per_packet + (idx->n_rows + 1) * 4;
@@ -371,7 +374,7 @@ extern "C" int vs_index_info(const vs_index* idx, vs_index_info_t* o) {
         o->bytes_per_pass = csr_bytes_per_pass(idx);
         o->device_bytes = (int64_t)(idx->pk_ptr.bytes + idx->cols.bytes + idx->vals.bytes);
         o->lanes_per_row = idx->lanes_per_row;
-        o->queries_per_pass = 1;
+        o->queries_per_pass = idx->last_qt > 0 ? idx->last_qt : (idx->qt_pref == 1 ? 1 : kQT);
     } else {
         o->bytes_per_pass = idx->n_rows * (int64_t)idx->n_cols * (idx->store_dtype == VS_F16 ? 2 : 4);
         o->device_bytes = (int64_t)idx->mat.bytes;
@@ -541,6 +544,123 @@ int prep_queries(vs_index* idx, const void* q, int q_dtype, int64_t ldq, int B, 
 
 }  // namespace
 
+namespace {
+
+template <int G, int VM>
+int launch_mq_g(const MqArgs& a, int grid, size_t lds, hipStream_t s) {
+    VS_HIP(hipFuncSetAttribute((const void*)csr_scan_topk_mq<G, VM, kQT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((csr_scan_topk_mq<G, VM, kQT>), dim3(grid), dim3(kScanThreads), lds, s, a);
+    VS_HIP(hipGetLastError());
+    return VS_OK;
+}
+template <int VM>
+int launch_mq_vm(int g, const MqArgs& a, int grid, size_t lds, hipStream_t s) {
+    switch (g) {
+        case 8: return launch_mq_g<8, VM>(a, grid, lds, s);
+        case 16: return launch_mq_g<16, VM>(a, grid, lds, s);
+        case 32: return launch_mq_g<32, VM>(a, grid, lds, s);
+        default: return launch_mq_g<64, VM>(a, grid, lds, s);
+    }
+}
+
+// LDS entries left for the tile's weights once the fixed tables are placed
+inline int mq_lanes(const vs_index* idx) { return std::max(idx->lanes_per_row, 8); }
+inline int mq_acc_rows(const vs_index* idx) {          // accumulator rows x copies (see S in csr_scan_topk_mq)
+    const int g = mq_lanes(idx);
+    return kScanWaves * (64 / g) * (g >= 32 ? 4 : (g >= 16 ? 2 : 1));
+}
+int mq_vals_cap(const vs_index* idx) {
+    const size_t fixed = mq_fixed_lds_bytes<kQT>(idx->n_cols, mq_acc_rows(idx));
+    const size_t total = 160 * 1024;
+    if (fixed + 1024 > total) return 0;
+    return (int)((total - fixed) / 4);
+}
+
+// Multi-query pass (Qt = kQT).  Returns VS_OK and sets *done = false when the batch does not qualify
+// (a query denser than the LDS weight capacity): the caller then takes the dense-image path.
+int mq_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64_t id_offset, int64_t* d_ids, float* d_scores,
+              const ScanPlan& plan, hipStream_t s, bool* done) {
+    *done = false;
+    const int vals_cap = mq_vals_cap(idx);
+    if (vals_cap <= 0 || k > kMaxKMq) return VS_OK;
+    const int V = idx->n_cols;
+    // 1. sparsify the batch: counts -> (qptr, tiles, plan) -> (qcols, qvals)
+    const size_t off_counts = 0, off_qptr = off_counts + (size_t)B * 8, off_plan = off_qptr + (size_t)(B + 1) * 8,
+                 off_tiles = off_plan + 64;
+    VS_TRY(idx->ws_mq_meta.reserve(off_tiles + (size_t)B * sizeof(int2)));
+    char* meta = idx->ws_mq_meta.as<char>();
+    int64_t* counts = (int64_t*)(meta + off_counts);
+    int64_t* qptr = (int64_t*)(meta + off_qptr);
+    int64_t* dplan = (int64_t*)(meta + off_plan);
+    int2* tiles = (int2*)(meta + off_tiles);
+    hipLaunchKernelGGL(count_nz_kernel<0>, dim3(std::min(B, 2048)), dim3(kSpThreads), 0, s, dq, (int64_t)V, B, V, counts);
+    hipLaunchKernelGGL(mq_plan_kernel<0>, dim3(1), dim3(64), 0, s, counts, B, kQT, vals_cap, qptr, tiles, dplan);
+    VS_HIP(hipGetLastError());
+    int64_t hplan[3] = {0, 0, 0};
+    VS_HIP(hipMemcpyAsync(hplan, dplan, sizeof(hplan), hipMemcpyDeviceToHost, s));
+    VS_HIP(hipStreamSynchronize(s));
+    if (hplan[1] > vals_cap) return VS_OK;                       // some query is too dense for the tile tables
+    const int n_tiles = (int)hplan[0];
+    const int64_t qnnz = hplan[2];
+    VS_TRY(idx->ws_mq_q.reserve(std::max<size_t>((size_t)qnnz * 8, 16)));
+    int32_t* qcols = idx->ws_mq_q.as<int32_t>();
+    float* qvals = reinterpret_cast<float*>(qcols + qnnz);
+    hipLaunchKernelGGL(fill_csr_kernel<0>, dim3(std::min(B, 2048)), dim3(kSpThreads), 0, s, dq, (int64_t)V, B, V, qptr, qcols, qvals, qnnz);
+    VS_HIP(hipGetLastError());
+    // 2. scan
+    const int64_t items = (int64_t)n_tiles * plan.nchunk;
+    const int grid = (int)std::min<int64_t>(items, idx->cu_count);
+    VS_TRY(idx->ws_mq_cand.reserve((size_t)grid * kQT * kMqCap * 8 + (size_t)grid * kQT * 4));
+    VS_TRY(idx->ws_cand.reserve((size_t)B * plan.nchunk * k * 8));
+    MqArgs a{};
+    a.pk_ptr = idx->pk_ptr.as<uint32_t>();
+    a.cols = idx->cols.as<uint4>();
+    a.vals = idx->vals.p;
+    a.n_rows = idx->n_rows;
+    a.n_cols = V;
+    a.k = k;
+    a.nchunk = plan.nchunk;
+    a.rows_per_chunk = plan.rows_per_chunk;
+    a.qptr = qptr;
+    a.qcols = qcols;
+    a.qvals = qvals;
+    a.tiles = tiles;
+    a.n_tiles = n_tiles;
+    a.vals_cap = vals_cap;
+    a.cand = idx->ws_cand.as<uint64_t>();
+    a.gcand = idx->ws_mq_cand.as<uint64_t>();
+    a.gcnt = reinterpret_cast<uint32_t*>(a.gcand + (size_t)grid * kQT * kMqCap);
+    if (const char* dv = getenv("VS_MQ_VARIANT")) a.debug_variant = atoi(dv);
+    const size_t lds = mq_fixed_lds_bytes<kQT>(V, mq_acc_rows(idx)) + (size_t)vals_cap * 4;
+    {
+        ProfScope prof("csr_scan_topk", s);
+        int rc = idx->store_dtype == VS_F32 ? launch_mq_vm<VM_F32>(mq_lanes(idx), a, grid, lds, s)
+               : idx->store_dtype == VS_F16 ? launch_mq_vm<VM_F16>(mq_lanes(idx), a, grid, lds, s)
+                                            : launch_mq_vm<VM_BIN>(mq_lanes(idx), a, grid, lds, s);
+        VS_TRY(rc);
+    }
+    // 3. merge chunks
+    MergeArgs m{};
+    m.cand = a.cand;
+    m.n_cand = (int64_t)plan.nchunk * k;
+    m.B = B;
+    m.k = k;
+    m.id_offset = id_offset;
+    m.out_ids = d_ids;
+    m.out_scores = d_scores;
+    m.out_ld = k;
+    m.col0 = 0;
+    {
+        ProfScope prof("merge_topk", s);
+        hipLaunchKernelGGL(merge_topk_kernel<0>, dim3(std::min(B, idx->cu_count * 2)), dim3(kScanThreads), 0, s, m);
+    }
+    VS_HIP(hipGetLastError());
+    *done = true;
+    return VS_OK;
+}
+
+}  // namespace
+
 int vs_csr_search(vs_index* idx, const void* q, int q_dtype, int64_t ldq, int32_t B, int32_t k, int64_t id_offset,
                   int64_t* out_ids, float* out_scores, hipStream_t s) {
     const float* dq = nullptr;
@@ -555,6 +675,28 @@ int vs_csr_search(vs_index* idx, const void* q, int q_dtype, int64_t ldq, int32_
         VS_TRY(idx->ws_out_scores.reserve((size_t)B * k * 4));
         d_ids = idx->ws_out_ids.as<int64_t>();
         d_scores = idx->ws_out_scores.as<float>();
+    }
+    idx->last_qt = 1;
+    if (idx->qt_pref != 1 && k <= kMaxKMq) {
+        bool done = false;
+        // large batches are cut so that the candidate scratch stays bounded
+        const size_t per_q_mq = (size_t)plan.nchunk * k * 8;
+        const int bs_mq = (int)std::max<size_t>(1, std::min<size_t>((size_t)B, ((size_t)1 << 30) / per_q_mq));
+        bool all = true;
+        for (int b0 = 0; b0 < B && all; b0 += bs_mq) {
+            const int bs = std::min(bs_mq, B - b0);
+            VS_TRY(mq_search(idx, dq + (size_t)b0 * idx->n_cols, bs, k, id_offset, d_ids + (size_t)b0 * k, d_scores + (size_t)b0 * k, plan, s, &done));
+            all = all && done;
+        }
+        if (all) {
+            idx->last_qt = kQT;
+            if (!out_dev) {
+                VS_HIP(hipMemcpyAsync(out_ids, d_ids, (size_t)B * k * 8, hipMemcpyDeviceToHost, s));
+                VS_HIP(hipMemcpyAsync(out_scores, d_scores, (size_t)B * k * 4, hipMemcpyDeviceToHost, s));
+                VS_HIP(hipStreamSynchronize(s));
+            }
+            return VS_OK;
+        }
     }
     const int passes = ceil_div(k, kMaxKShared);
     DevBuf upper;                                              // [B] exclusive upper-bound keys (multi-pass only)

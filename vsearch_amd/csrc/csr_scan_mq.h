@@ -1,0 +1,284 @@
+// csr_scan_mq.h -- CSR scoring pass for a TILE of QT sparse queries per index pass (Qt > 1).
+//
+// The HBM stream (column packets + values) is the same as in csr_scan.h; what changes is the query
+// side.  A dense fp32 image of one query fills 118 KB of LDS, so Qt = 1.  Queries on this path are
+// sparse (768 + lexical dims out of V = 29 523), so the tile is kept as
+//     tab[c]  (uint32, c in [0, V]):  low QT bits = which queries of the tile have weight at column c,
+//                                     high bits   = offset of column c's weights in `vals`
+//     vals[]  (fp32): the tile's non-zero weights, grouped by column, ordered by query slot
+// One LDS gather per index non-zero answers "does any of the QT queries touch this column?".  The hit
+// bits of a lane's 8-nnz packet are packed into one 64-bit word; only lanes with hits (~2.6 % x QT per
+// nnz) walk that word -- one hit per iteration: pick the packet position (select tree), fetch the
+// weight and add the product into the row's accumulator.  Accumulators are doubles in LDS
+// (ds_add_f64, a few copies per row to keep lanes off the same address): fp32 x fp32 products are
+// exact in fp64, so a score is the correctly rounded sum whatever the order of the adds --
+// reproducible, and bit-identical to the oracle's fp64-accumulated scores.
+//
+// Top-k: per (workgroup, query slot) candidate keys go to an L2-resident global buffer (appends
+// become rare once the k-th-best threshold tightens); every kMqSuperRows rows the workgroup meets
+// at a barrier and prunes over-full buffers with the LDS bitonic sort.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+#include "csr_scan.h"
+#include "dense_csr.h"
+
+namespace vs {
+
+constexpr int kMqCap = 1024;          // candidate slots per (workgroup, query slot)
+constexpr int kMqSuperRows = 512;     // rows between prune checks; prune when count > kMqCap - kMqSuperRows
+constexpr int kMaxKMq = kMqCap - kMqSuperRows;
+
+// x_i for a lane-varying i in [0, 8): select tree on registers.  Scalars are passed by value on purpose:
+// indexing an array with a lane-varying index makes the compiler place the array in scratch memory.
+template <class T>
+__device__ __forceinline__ T sel8(T x0, T x1, T x2, T x3, T x4, T x5, T x6, T x7, int i) {
+    const bool b0 = i & 1, b1 = i & 2, b2 = i & 4;
+    const T a0 = b0 ? x1 : x0, a1 = b0 ? x3 : x2, a2 = b0 ? x5 : x4, a3 = b0 ? x7 : x6;
+    const T c0 = b1 ? a1 : a0, c1 = b1 ? a3 : a2;
+    return b2 ? c1 : c0;
+}
+
+struct MqArgs {
+    const uint32_t* pk_ptr;
+    const uint4* cols;
+    const void* vals;
+    int64_t n_rows;
+    int32_t n_cols;
+    int32_t k;
+    int32_t nchunk;
+    int64_t rows_per_chunk;
+    // sparse queries (CSR over the batch) and the tile plan
+    const int64_t* qptr;      // [B + 1]
+    const int32_t* qcols;     // [qnnz]
+    const float* qvals;       // [qnnz]
+    const int2* tiles;        // [n_tiles] (first query, count <= QT)
+    int32_t n_tiles;
+    int32_t vals_cap;         // LDS capacity for tile weights (entries)
+    uint64_t* cand;           // [B, nchunk, k] output keys, sorted descending
+    uint64_t* gcand;          // [grid, QT, kMqCap] scratch
+    uint32_t* gcnt;           // [grid, QT] scratch counters
+    int32_t debug_variant;    // perf experiments only (VS_MQ_VARIANT): 1 = skip hit loop, 2 = skip atomics, 3 = skip lookups too
+};
+
+template <int QT>
+__host__ __device__ inline size_t mq_fixed_lds_bytes(int32_t n_cols, int rows_in_flight) {
+    const size_t tab = (((size_t)n_cols + 1) * 4 + 15) & ~(size_t)15;
+    return tab + (size_t)kMqCap * 8 + (size_t)rows_in_flight * QT * 8 + (size_t)QT * 8 + 64 * 4;
+}
+
+template <int G, int VM, int QT>
+__global__ __launch_bounds__(kScanThreads) void csr_scan_topk_mq(MqArgs a) {
+    static_assert(QT == 8 && G >= 8, "the packed hit word assumes 8 query slots per tile; lanes 0..7 of a row group finish them");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int RPW = 64 / G;
+    constexpr int RPI = kScanWaves * RPW;
+    constexpr int SB = kMqSuperRows / RPI;
+    const size_t tab_bytes = (((size_t)a.n_cols + 1) * 4 + 15) & ~(size_t)15;
+    uint32_t* tab = reinterpret_cast<uint32_t*>(smem);
+    uint64_t* sortbuf = reinterpret_cast<uint64_t*>(smem + tab_bytes);          // [kMqCap]
+    constexpr int S = G >= 32 ? 4 : (G >= 16 ? 2 : 1);                          // accumulator copies per row
+    double* acc = reinterpret_cast<double*>(sortbuf + kMqCap);                  // [RPI][S][QT]
+    unsigned long long* tau = reinterpret_cast<unsigned long long*>(acc + RPI * S * QT);   // [QT]
+    int* scratch = reinterpret_cast<int*>(tau + QT);                            // [64]
+    float* qv = reinterpret_cast<float*>(scratch + 64);                         // [vals_cap]
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int g = lane / G, lg = lane % G;
+    const int slot = w * RPW + g;
+    const int K = a.k;
+    uint64_t* my_gcand = a.gcand + (size_t)blockIdx.x * QT * kMqCap;
+    uint32_t* my_gcnt = a.gcnt + (size_t)blockIdx.x * QT;
+    const int seg = (a.n_cols + 1 + kScanThreads - 1) / kScanThreads;
+    const int64_t items = (int64_t)a.n_tiles * a.nchunk;
+
+    for (int64_t item = blockIdx.x; item < items; item += gridDim.x) {
+        const int tile = (int)(item / a.nchunk), c = (int)(item % a.nchunk);
+        const int q0 = a.tiles[tile].x, nq = a.tiles[tile].y;
+        const int64_t r0 = (int64_t)c * a.rows_per_chunk;
+        const int64_t r1 = min(a.n_rows, r0 + a.rows_per_chunk);
+        __syncthreads();
+        // ---- build the tile tables ----
+        for (int i = tid; i <= a.n_cols; i += kScanThreads) tab[i] = 0;
+        for (int i = tid; i < RPI * S * QT; i += kScanThreads) acc[i] = 0.0;
+        if (tid < QT) { tau[tid] = 0ull; my_gcnt[tid] = 0u; }
+        __syncthreads();
+        const int64_t e0 = a.qptr[q0], e1 = a.qptr[q0 + nq];
+        for (int64_t e = e0 + tid; e < e1; e += kScanThreads) {
+            int qs = 0;
+            while (e >= a.qptr[q0 + qs + 1]) ++qs;
+            atomicOr(&tab[a.qcols[e]], 1u << qs);
+        }
+        __syncthreads();
+        {   // offsets: exclusive scan of popc(mask) in column order (contiguous segment per thread)
+            const int i0 = tid * seg, i1 = min(a.n_cols + 1, i0 + seg);
+            int mine = 0;
+            for (int i = i0; i < i1; ++i) mine += __popc(tab[i]);
+            int off = block_excl_scan(mine, scratch, tid, nullptr);
+            for (int i = i0; i < i1; ++i) {
+                const uint32_t m = tab[i];
+                tab[i] = m | ((uint32_t)(off * 4) << QT);        // byte offset into qv
+                off += __popc(m);
+            }
+        }
+        __syncthreads();
+        for (int64_t e = e0 + tid; e < e1; e += kScanThreads) {
+            int qs = 0;
+            while (e >= a.qptr[q0 + qs + 1]) ++qs;
+            const uint32_t t = tab[a.qcols[e]];
+            qv[(t >> (QT + 2)) + __popc(t & ((1u << qs) - 1u))] = a.qvals[e];
+        }
+        __syncthreads();
+
+        // ---- scan ----
+        const int64_t iters = (r1 - r0 + RPI - 1) / RPI;
+        for (int64_t it0 = 0; it0 < iters || it0 == 0; it0 += SB) {
+            const int64_t it1 = min(iters, it0 + SB);
+            for (int64_t it = it0; it < it1; ++it) {
+                const int64_t row = r0 + it * RPI + slot;
+                double* myacc = acc + ((size_t)slot * S + (lg & (S - 1))) * QT;
+                if (row < r1) {
+                    const uint32_t p0 = a.pk_ptr[row], p1 = a.pk_ptr[row + 1];
+                    constexpr int U = 3;                       // packets per lane per trip: all loads first, then the hit walks
+                    const uint32_t padw = (uint32_t)a.n_cols | ((uint32_t)a.n_cols << 16);
+                    for (uint32_t pb = p0 + lg; pb < p1; pb += U * G) {
+                        uint4 cwu[U];
+                        float vu[U][8];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            const uint32_t p = pb + u * G;
+                            const bool ok = p < p1;
+                            const uint32_t pc = ok ? p : pb;
+                            cwu[u] = a.cols[pc];
+                            if (!ok) cwu[u] = make_uint4(padw, padw, padw, padw);
+                            if constexpr (VM == VM_F32) {
+                                const float4* vp = reinterpret_cast<const float4*>(a.vals);
+                                const float4 v0 = vp[2 * (size_t)pc], v1 = vp[2 * (size_t)pc + 1];
+                                vu[u][0] = v0.x; vu[u][1] = v0.y; vu[u][2] = v0.z; vu[u][3] = v0.w;
+                                vu[u][4] = v1.x; vu[u][5] = v1.y; vu[u][6] = v1.z; vu[u][7] = v1.w;
+                            } else if constexpr (VM == VM_F16) {
+                                const uint4 hv = reinterpret_cast<const uint4*>(a.vals)[pc];
+                                const __half2* h = reinterpret_cast<const __half2*>(&hv);
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) { const float2 f = __half22float2(h[i]); vu[u][2 * i] = f.x; vu[u][2 * i + 1] = f.y; }
+                            } else {
+#pragma unroll
+                                for (int i = 0; i < 8; ++i) vu[u][i] = 1.0f;
+                            }
+                        }
+                        // Hits are sparse (a position hits with p ~ 0.026 x QT) and almost always single: per position
+                        // a straight-line, exec-masked "first hit" and "second hit" (static registers, no select
+                        // trees, independent chains); >= 3 queries sharing one column fall into a rare generic loop.
+                        const char* qvb = reinterpret_cast<const char*>(qv);
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            const uint32_t cwv[4] = {cwu[u].x, cwu[u].y, cwu[u].z, cwu[u].w};
+                            uint32_t t[8];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) { t[2 * i] = tab[cwv[i] & 0xFFFF]; t[2 * i + 1] = tab[cwv[i] >> 16]; }
+                            if (a.debug_variant == 1) continue;
+                            uint32_t more = 0;
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) {
+                                const uint32_t m1 = t[i] & 0xFFu;
+                                const uint32_t boff = t[i] >> QT;                      // byte offset of the column's weights
+                                if (m1) {
+                                    const float w = *reinterpret_cast<const float*>(qvb + boff);
+                                    atomicAdd(&myacc[__ffs(m1) - 1], (double)(vu[u][i] * w));          // ds_add_f64
+                                }
+                                const uint32_t m2 = m1 & (m1 - 1);
+                                if (m2) {
+                                    const float w = *reinterpret_cast<const float*>(qvb + boff + 4);
+                                    atomicAdd(&myacc[__ffs(m2) - 1], (double)(vu[u][i] * w));
+                                }
+                                more |= m2 & (m2 - 1);
+                            }
+                            if (__any(more != 0)) {
+#pragma unroll
+                                for (int i = 0; i < 8; ++i) {
+                                    uint32_t m = t[i] & 0xFFu;
+                                    m &= m - 1;
+                                    m &= m - 1;
+                                    uint32_t boff = (t[i] >> QT) + 8;
+                                    while (m) {
+                                        const float w = *reinterpret_cast<const float*>(qvb + boff);
+                                        atomicAdd(&myacc[__ffs(m) - 1], (double)(vu[u][i] * w));
+                                        m &= m - 1;
+                                        boff += 4;
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();     // this wave's adds precede its reads (LDS executes a wave's ops in order)
+                if (row < r1 && lg < nq) {
+                    double sum = 0.0;
+#pragma unroll
+                    for (int c2 = 0; c2 < S; ++c2) {
+                        double* pa = acc + ((size_t)slot * S + c2) * QT + lg;
+                        sum += *pa;
+                        *pa = 0.0;
+                    }
+                    const uint64_t key = make_key((float)sum, (uint32_t)row);
+                    if (key > tau[lg]) {
+                        const uint32_t pos = atomicAdd(&my_gcnt[lg], 1u);
+                        my_gcand[(size_t)lg * kMqCap + pos] = key;
+                    }
+                }
+            }
+            __syncthreads();
+            const bool last = it1 >= iters;
+            for (int qs = 0; qs < nq; ++qs) {
+                const uint32_t cnt = __hip_atomic_load(&my_gcnt[qs], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (last || cnt > (uint32_t)(kMqCap - kMqSuperRows)) {
+                    for (int i = tid; i < kMqCap; i += kScanThreads) sortbuf[i] = (uint32_t)i < cnt ? my_gcand[(size_t)qs * kMqCap + i] : 0ull;
+                    wg_sort_desc<kScanThreads>(sortbuf, kMqCap, tid);
+                    if (last) {
+                        uint64_t* out = a.cand + ((size_t)(q0 + qs) * a.nchunk + c) * (size_t)K;
+                        for (int i = tid; i < K; i += kScanThreads) out[i] = sortbuf[i];
+                    } else if (cnt > (uint32_t)K) {
+                        for (int i = tid; i < K; i += kScanThreads) my_gcand[(size_t)qs * kMqCap + i] = sortbuf[i];
+                        if (tid == 0) {
+                            tau[qs] = sortbuf[K - 1];
+                            __hip_atomic_store(&my_gcnt[qs], (uint32_t)K, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+            __syncthreads();
+            if (last) break;
+        }
+    }
+}
+
+// Single-thread planner: row pointers of the sparse query batch + greedy tiling (<= QT queries and
+// <= vals_cap non-zeros per tile).  plan[0] = n_tiles, plan[1] = max nnz of one query, plan[2] = total nnz.
+template <int UNUSED>
+__global__ void mq_plan_kernel(const int64_t* counts, int32_t B, int32_t qt, int32_t vals_cap, int64_t* qptr, int2* tiles, int64_t* plan) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    int64_t acc = 0, mx = 0;
+    qptr[0] = 0;
+    for (int b = 0; b < B; ++b) {
+        acc += counts[b];
+        qptr[b + 1] = acc;
+        mx = counts[b] > mx ? counts[b] : mx;
+    }
+    int nt = 0, start = 0;
+    while (start < B) {
+        int cnt = 0;
+        int64_t nz = 0;
+        while (cnt < qt && start + cnt < B && nz + counts[start + cnt] <= vals_cap) { nz += counts[start + cnt]; ++cnt; }
+        if (cnt == 0) cnt = 1;            // a query that does not fit: the host sees plan[1] > vals_cap and takes the dense path
+        tiles[nt++] = make_int2(start, cnt);
+        start += cnt;
+    }
+    plan[0] = nt;
+    plan[1] = mx;
+    plan[2] = acc;
+}
+
+}  // namespace vs

@@ -7,6 +7,7 @@
 // go to the lowest column ids (torch.topk leaves them unspecified).
 #include "common.h"
 #include "topk_keys.h"
+#include "dense_csr.h"
 
 #include <algorithm>
 
@@ -14,7 +15,6 @@ using namespace vs;
 
 namespace {
 
-constexpr int kSpThreads = 1024;
 
 __device__ __forceinline__ float elu1p_dev(float x) { return x > 0.f ? x + 1.0f : expm1f(x) + 1.0f; }
 
@@ -32,27 +32,6 @@ __global__ void head_pool_kernel(const float* logits, int32_t B, int32_t L, int3
         for (int l = 0; l < L; ++l) m = fmaxf(m, p[(size_t)l * V]);
         out[i] = elu1p_dev(m);
     }
-}
-
-// block-wide exclusive scan of one int per thread (kSpThreads threads); scratch: 16 ints in LDS
-__device__ __forceinline__ int block_excl_scan(int v, int* scratch, int tid, int* total) {
-    const int lane = tid & 63, w = tid >> 6;
-    int incl = v;
-    for (int o = 1; o < 64; o <<= 1) {
-        const int t = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += t;
-    }
-    __syncthreads();
-    if (lane == 63) scratch[w] = incl;
-    __syncthreads();
-    int base = 0, tot = 0;
-    for (int i = 0; i < kSpThreads / 64; ++i) {
-        const int s = scratch[i];
-        if (i < w) base += s;
-        tot += s;
-    }
-    if (total) *total = tot;
-    return base + incl - v;
 }
 
 struct MaskArgs {
@@ -167,49 +146,6 @@ __global__ __launch_bounds__(kSpThreads) void mask_rows_kernel(MaskArgs a) {
                 else if (!sel) *e = *e * 0.f;                  // `emb *= mask` (vdr.py:169)
             }
         }
-    }
-}
-
-// ---- Tensor.to_sparse_csr() (retriever.py:304): non-zeros of a dense [B, V] matrix ----------------
-__global__ __launch_bounds__(kSpThreads) void count_nz_kernel(const float* x, int64_t ld, int32_t B, int32_t V, int64_t* counts) {
-    __shared__ int scratch[32];
-    const int tid = threadIdx.x;
-    for (int b = blockIdx.x; b < B; b += gridDim.x) {
-        int c = 0;
-        for (int i = tid; i < V; i += kSpThreads) c += x[(size_t)b * ld + i] != 0.f;
-        int total = 0;
-        block_excl_scan(c, scratch, tid, &total);
-        if (tid == 0) counts[b] = total;
-        __syncthreads();
-    }
-}
-
-__global__ void scan_counts_kernel(const int64_t* counts, int32_t B, int64_t* rowptr) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        int64_t acc = 0;
-        rowptr[0] = 0;
-        for (int b = 0; b < B; ++b) { acc += counts[b]; rowptr[b + 1] = acc; }
-    }
-}
-
-__global__ __launch_bounds__(kSpThreads) void fill_csr_kernel(const float* x, int64_t ld, int32_t B, int32_t V, const int64_t* rowptr,
-                                                              int32_t* cols, float* vals, int64_t cap) {
-    __shared__ int scratch[32];
-    const int tid = threadIdx.x;
-    const int seg = (V + kSpThreads - 1) / kSpThreads;
-    for (int b = blockIdx.x; b < B; b += gridDim.x) {
-        const int i0 = tid * seg, i1 = min(V, i0 + seg);
-        int c = 0;
-        for (int i = i0; i < i1; ++i) c += x[(size_t)b * ld + i] != 0.f;
-        int64_t pos = rowptr[b] + block_excl_scan(c, scratch, tid, nullptr);
-        for (int i = i0; i < i1; ++i) {
-            const float v = x[(size_t)b * ld + i];
-            if (v != 0.f) {
-                if (pos < cap) { cols[pos] = i; vals[pos] = v; }
-                ++pos;
-            }
-        }
-        __syncthreads();
     }
 }
 
@@ -343,8 +279,8 @@ extern "C" int vs_dense_to_csr(const float* x, int32_t B, int32_t V, int64_t ld,
     VS_TRY(to_device(x, ((size_t)(B - 1) * ld + V) * 4, st_x, s, &dx));
     VS_TRY(counts.alloc((size_t)B * 8));
     VS_TRY(d_rp.alloc((size_t)(B + 1) * 8));
-    hipLaunchKernelGGL(count_nz_kernel, dim3(std::min(B, 2048)), dim3(kSpThreads), 0, s, (const float*)dx, ld, B, V, counts.as<int64_t>());
-    hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(64), 0, s, counts.as<int64_t>(), B, d_rp.as<int64_t>());
+    hipLaunchKernelGGL(count_nz_kernel<0>, dim3(std::min(B, 2048)), dim3(kSpThreads), 0, s, (const float*)dx, ld, B, V, counts.as<int64_t>());
+    hipLaunchKernelGGL(scan_counts_kernel<0>, dim3(1), dim3(64), 0, s, counts.as<int64_t>(), B, d_rp.as<int64_t>());
     VS_HIP(hipGetLastError());
     std::vector<int64_t> rp((size_t)B + 1);
     VS_HIP(hipMemcpyAsync(rp.data(), d_rp.p, rp.size() * 8, hipMemcpyDeviceToHost, s));
@@ -363,7 +299,7 @@ extern "C" int vs_dense_to_csr(const float* x, int32_t B, int32_t V, int64_t ld,
             dc = st_c.as<int32_t>();
             dv = st_v.as<float>();
         }
-        hipLaunchKernelGGL(fill_csr_kernel, dim3(std::min(B, 2048)), dim3(kSpThreads), 0, s, (const float*)dx, ld, B, V, d_rp.as<int64_t>(), dc, dv, nnz);
+        hipLaunchKernelGGL(fill_csr_kernel<0>, dim3(std::min(B, 2048)), dim3(kSpThreads), 0, s, (const float*)dx, ld, B, V, d_rp.as<int64_t>(), dc, dv, nnz);
         VS_HIP(hipGetLastError());
         if (o_host && nnz > 0) {
             VS_HIP(hipMemcpyAsync(cols, dc, (size_t)nnz * 4, hipMemcpyDeviceToHost, s));

@@ -118,6 +118,10 @@ class DeviceIndex:
         nat.check(nat.lib().vs_index_info(self._h, C.byref(out)))
         return out
 
+    def set_queries_per_pass(self, qt: int):
+        """0 = auto (tiles of 8 sparse queries per index pass when the batch qualifies), 1 = one query per pass."""
+        nat.check(nat.lib().vs_index_set_queries_per_pass(self._h, int(qt)))
+
     def _q_args(self, q):
         if q.ndim != 2:
             raise ValueError("queries must be [B, V]")
