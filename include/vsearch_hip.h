@@ -115,7 +115,7 @@ VS_API int vs_index_scores(vs_index* index, const void* q, int q_dtype, int64_t 
 VS_API int  vs_index_info(const vs_index* index, vs_index_info_t* out);
 
 /* Scan selection (tuning / tests; no reference counterpart): 0 = auto -- score tiles of 8 sparse queries
- * per pass over the index when the batch qualifies (k <= 1024, every query sparse enough for the LDS
+ * per pass over the index when the batch qualifies (k <= 512, every query sparse enough for the LDS
  * tile tables), else one query per pass with a dense fp32 query image;  1 = always the latter.      */
 VS_API int  vs_index_set_queries_per_pass(vs_index* index, int qt);
 

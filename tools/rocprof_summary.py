@@ -47,6 +47,14 @@ def main():
             f.write(f"{'kernel':100s} {'calls':>6s} {'total_ms':>14s} {'avg_ms':>14s} {'pct':>7s}\n")
             for name, calls, tot, avg, pct in rows:            # top_kernels reports microseconds
                 f.write(f"{name[:100]:100s} {calls:6d} {tot / 1e3:14.3f} {avg / 1e3:14.3f} {pct:7.3f}\n")
+            big = {}
+            for name, dur in per:
+                if dur >= 50e6:                                # bench-sized launches only (>= 50 ms)
+                    big.setdefault(name, []).append(dur / 1e6)
+            f.write("\n# bench-sized launches only (>= 50 ms; excludes the 20 k-doc parity check that reuses the kernel)\n")
+            for name, ds in big.items():
+                f.write(f"{name[:100]:100s} {len(ds):6d} launches, avg {sum(ds) / len(ds):12.3f} ms\n")
+            summary["bench_sized_launches"] = {n: {"launches": len(d), "avg_ms": sum(d) / len(d)} for n, d in big.items()}
             f.write("\n# per dispatch (launch order), ms\n")
             for name, dur in per:                              # kernels view: end - start in nanoseconds
                 f.write(f"{name[:100]:100s} {dur / 1e6:14.3f}\n")
