@@ -237,3 +237,57 @@ def test_torch_device_tensors_roundtrip(sparse2000):
     ids2, sc2 = idx.search(qh, 10)
     o_ids, o_sc = oracle.csr_search(ip, ix, d, V, qh.float().cpu().numpy(), 10, acc64=True)
     compare.compare_topk(o_ids, o_sc, ids2.cpu().numpy(), sc2.cpu().numpy(), rtol=RTOL)
+
+
+# ---- BASELINE-scale properties (sizes the oracle cannot score in seconds) ------------------------------
+def test_large_index_topk_is_valid_and_shards_merge_exactly():
+    """2 M synthetic docs (9.2 GB): (1) the fused top-k equals a top-k of the independently computed dense
+    score matrix (csr_scan_scores kernel), (2) searching two row shards and merging == searching the whole."""
+    n, b, k = 2_000_000, 4, 100
+    whole = DeviceIndex.synthetic(0, 0, n)
+    q = oracle.synth_queries(1, b)
+    ids, sc = whole.search(q, k)
+    allsc = whole.scores(q)                                   # Qt = 1 scores-only kernel: independent code path
+    compare.check_topk_valid(allsc, ids, sc, rtol=RTOL)
+    assert (np.diff(sc.astype(np.float64), axis=1) <= 0).all()
+    half = n // 2
+    lo, hi = DeviceIndex.synthetic(0, 0, half), DeviceIndex.synthetic(0, half, n - half)
+    i0, s0 = lo.search(q, k, id_offset=0)
+    i1, s1 = hi.search(q, k, id_offset=half)
+    m_ids, m_sc = merge_topk(np.concatenate([i0, i1], 1), np.concatenate([s0, s1], 1), k)
+    assert (m_ids == ids).all() and (m_sc == sc).all()
+    # idempotence: same call, same bits (reproducible accumulation order)
+    ids2, sc2 = whole.search(q, k)
+    assert (ids2 == ids).all() and (sc2 == sc).all()
+
+
+def test_large_bot_index_exact_against_scores_kernel():
+    n, b, k = 3_000_000, 8, 100
+    idx = DeviceIndex.synthetic(3, 0, n, V, 86, synth.KIND_BOT, 0, nat.VS_NONE)
+    q = oracle.synth_queries(5, b, val_law=synth.VAL_DYADIC)
+    ids, sc = idx.search(q, k)
+    allsc = idx.scores(q)
+    compare.check_topk_valid(allsc, ids, sc, exact=True, canonical=True)   # bit-exact scores, canonical ids
+
+
+def test_nccl_single_rank_exchange_path():
+    """The all-gather + device merge of the row-sharded search, exercised over RCCL with a 1-rank group."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from vsearch_amd.distributed import ShardedSearcher
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        n = 5000
+        ip, ix, d = oracle.synth_csr(0, 0, n)
+        idx = DeviceIndex.from_csr(ip, ix, d, V)
+        s = ShardedSearcher.from_device_index(idx, 0, n)
+        s.force_exchange = True
+        q = torch.from_numpy(oracle.synth_queries(1, 6)).cuda()
+        ids, sc = s.search(q, 100)
+        ref_ids, ref_sc = idx.search(q, 100)
+        assert ids.is_cuda and (ids == ref_ids).all() and (sc == ref_sc).all()
+    finally:
+        dist.destroy_process_group()
