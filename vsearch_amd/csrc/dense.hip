@@ -44,62 +44,105 @@ __global__ void unpad_rows_kernel(const float* src, int32_t ldp, int64_t n_rows,
     }
 }
 
-// One wave = one 32 (queries) x 32 (docs) tile; a workgroup of 4 waves = 64 x 64.
-// Lane l feeds A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31] of each 32x32x2 MFMA; the K order is
-// permuted so that half-wave h owns columns c0 + 16h .. c0 + 16h + 15 of the chunk: every lane
-// streams 64 contiguous bytes of its row per chunk straight from global memory (L1/L2 serve the
-// 2x reuse inside the workgroup).  Rows are padded to ldp (multiple of kDenseKC) with zeros.
-__global__ __launch_bounds__(256) void dense_scores_kernel(const float* __restrict__ Q, const float* __restrict__ P, int32_t B,
+// scores[B, N] = Q[B, V] . P[N, V]^T on the fp32 matrix cores.
+// Workgroup = 4 waves = 128 queries x 128 docs; wave = 64 x 64 = 2 x 2 MFMA tiles (v_mfma_f32_32x32x2_f32).
+// K is walked in chunks of 32 columns: both operand tiles (128 x 32 fp32 each) are fetched with coalesced
+// 16-byte loads into registers while the previous chunk is multiplied (register-staged prefetch), then
+// written to LDS with a 36-float row pitch -- with that pitch a 16-lane ds_read_b128 group touches all 64
+// banks exactly once.  The MFMA K order is permuted (half-wave h owns columns 16h..16h+15 of the chunk) so
+// a lane's operands for 4 consecutive MFMA steps are one ds_read_b128.  Rows are padded to ldp (multiple
+// of 32) with zeros.  Two-level summation: chains inside 512-column blocks, block sums added to `tot`.
+constexpr int kDM = 128, kDN = 128, kDPitch = kDenseKC + 4;
+
+__global__ __launch_bounds__(256, 1) void dense_scores_kernel(const float* __restrict__ Q, const float* __restrict__ P, int32_t B,
                                                            int64_t N, int32_t ldp, uint64_t* keys, float* scores) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int64_t n0 = (int64_t)blockIdx.x * 64 + (w & 1) * 32;
-    const int b0 = blockIdx.y * 64 + (w >> 1) * 32;
+    __shared__ __attribute__((aligned(16))) float As[kDM * kDPitch];
+    __shared__ __attribute__((aligned(16))) float Bs[kDN * kDPitch];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w >> 1, wn = w & 1;
     const int h = lane >> 5, l31 = lane & 31;
-    const int qi = min(b0 + l31, B - 1);
-    const int64_t ni = min(n0 + l31, N - 1);
-    const float4* qa = reinterpret_cast<const float4*>(Q + (size_t)qi * ldp + h * 16);
-    const float4* pb = reinterpret_cast<const float4*>(P + (size_t)ni * ldp + h * 16);
-    // Two-level summation: products are chained inside 512-column blocks (two independent MFMA
-    // accumulators), block sums are added to `tot` -- keeps the fp32 error of a 29 523-term dot
-    // product near 1e-6 relative instead of ~1e-5 for one long chain.
-    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    f32x16 tot = zero, acc0 = zero, acc1 = zero;
-    const int chunks = ldp / kDenseKC;
-    for (int c = 0; c < chunks; ++c) {
-        float4 a[4], b[4];
+    const int64_t n_blk = (int64_t)blockIdx.x * kDN;
+    const int b_blk = blockIdx.y * kDM;
+    // global -> register staging: thread t covers rows (t/8) + 32 j, 16-byte column group t%8
+    const int lr = tid >> 3, lc = (tid & 7) * 4;
+    const float* qsrc[4];
+    const float* psrc[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            a[i] = qa[c * (kDenseKC / 4) + i];
-            b[i] = pb[c * (kDenseKC / 4) + i];
+    for (int j = 0; j < 4; ++j) {
+        qsrc[j] = Q + (size_t)min(b_blk + lr + 32 * j, B - 1) * ldp + lc;
+        psrc[j] = P + (size_t)min(n_blk + lr + 32 * j, N - 1) * ldp + lc;
+    }
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    f32x16 tot[2][2], acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { tot[i][j] = zero; acc[i][j] = zero; }
+    // named registers on purpose: as arrays these staging values end up in scratch memory
+    const float4* q4[4] = {reinterpret_cast<const float4*>(qsrc[0]), reinterpret_cast<const float4*>(qsrc[1]),
+                           reinterpret_cast<const float4*>(qsrc[2]), reinterpret_cast<const float4*>(qsrc[3])};
+    const float4* p4[4] = {reinterpret_cast<const float4*>(psrc[0]), reinterpret_cast<const float4*>(psrc[1]),
+                           reinterpret_cast<const float4*>(psrc[2]), reinterpret_cast<const float4*>(psrc[3])};
+    float4 ra0 = q4[0][0], ra1 = q4[1][0], ra2 = q4[2][0], ra3 = q4[3][0];
+    float4 rb0 = p4[0][0], rb1 = p4[1][0], rb2 = p4[2][0], rb3 = p4[3][0];
+    const int chunks = ldp / kDenseKC;
+    const float* a_rd = As + (wm * 64 + l31) * kDPitch + h * 16;
+    const float* b_rd = Bs + (wn * 64 + l31) * kDPitch + h * 16;
+    for (int c = 0; c < chunks; ++c) {
+        __syncthreads();                                   // previous chunk's fragment reads are done
+        *reinterpret_cast<float4*>(As + (lr + 0) * kDPitch + lc) = ra0;
+        *reinterpret_cast<float4*>(As + (lr + 32) * kDPitch + lc) = ra1;
+        *reinterpret_cast<float4*>(As + (lr + 64) * kDPitch + lc) = ra2;
+        *reinterpret_cast<float4*>(As + (lr + 96) * kDPitch + lc) = ra3;
+        *reinterpret_cast<float4*>(Bs + (lr + 0) * kDPitch + lc) = rb0;
+        *reinterpret_cast<float4*>(Bs + (lr + 32) * kDPitch + lc) = rb1;
+        *reinterpret_cast<float4*>(Bs + (lr + 64) * kDPitch + lc) = rb2;
+        *reinterpret_cast<float4*>(Bs + (lr + 96) * kDPitch + lc) = rb3;
+        __syncthreads();
+        {                                                  // prefetch the next chunk; lands while the MFMAs run
+            const int cn = min(c + 1, chunks - 1) * (kDenseKC / 4);      // (last trip re-reads its own chunk: harmless)
+            ra0 = q4[0][cn]; ra1 = q4[1][cn]; ra2 = q4[2][cn]; ra3 = q4[3][cn];
+            rb0 = p4[0][cn]; rb1 = p4[1][cn]; rb2 = p4[2][cn]; rb3 = p4[3][cn];
         }
 #pragma unroll
-        for (int i = 0; i < 4; i += 2) {
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[i].x, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i + 1].x, b[i + 1].x, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[i].y, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i + 1].y, b[i + 1].y, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[i].z, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i + 1].z, b[i + 1].z, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[i].w, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i + 1].w, b[i + 1].w, acc1, 0, 0, 0);
+        for (int s4 = 0; s4 < 4; ++s4) {
+            float4 fa[2], fb[2];
+            fa[0] = *reinterpret_cast<const float4*>(a_rd + s4 * 4);
+            fa[1] = *reinterpret_cast<const float4*>(a_rd + 32 * kDPitch + s4 * 4);
+            fb[0] = *reinterpret_cast<const float4*>(b_rd + s4 * 4);
+            fb[1] = *reinterpret_cast<const float4*>(b_rd + 32 * kDPitch + s4 * 4);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+                }
         }
         if ((c & 15) == 15 || c == chunks - 1) {
-            tot += acc0 + acc1;
-            acc0 = zero;
-            acc1 = zero;
-        }
-    }
-    const f32x16 acc = tot;
-    // C/D layout: col j = lane & 31 (doc), row i = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (query)
-    const int64_t n = n0 + l31;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int b = b0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (b < B && n < N) {
-            if (keys) keys[(size_t)b * N + n] = make_key(acc[r], (uint32_t)n);
-            if (scores) scores[(size_t)b * N + n] = acc[r];
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) { tot[i][j] += acc[i][j]; acc[i][j] = zero; }
         }
     }
+    // C/D layout of a 32x32 tile: col = lane & 31 (doc), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (query)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int64_t n = n_blk + wn * 64 + j * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int b = b_blk + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (b < B && n < N) {
+                    if (keys) keys[(size_t)b * N + n] = make_key(tot[i][j][r], (uint32_t)n);
+                    if (scores) scores[(size_t)b * N + n] = tot[i][j][r];
+                }
+            }
+        }
 }
 
 int prep_dense_queries(vs_index* idx, const void* q, int q_dtype, int64_t ldq, int B, int ldp, hipStream_t s, const float** out) {
@@ -240,7 +283,7 @@ int vs_dense_search(vs_index* idx, const void* q, int q_dtype, int64_t ldq, int3
         const int bs = std::min(bs_max, B - b0);
         {
             ProfScope prof("dense_scores", s);
-            hipLaunchKernelGGL(dense_scores_kernel, dim3((unsigned)ceil_div64(N, 64), (unsigned)ceil_div(bs, 64)), dim3(256), 0, s,
+            hipLaunchKernelGGL(dense_scores_kernel, dim3((unsigned)ceil_div64(N, kDN), (unsigned)ceil_div(bs, kDM)), dim3(256), 0, s,
                                dq + (size_t)b0 * ldp, idx->mat.as<float>(), bs, N, ldp, idx->ws_cand.as<uint64_t>(), (float*)nullptr);
         }
         VS_HIP(hipGetLastError());
@@ -279,7 +322,7 @@ int vs_dense_scores(vs_index* idx, const void* q, int q_dtype, int64_t ldq, int3
         VS_TRY(idx->ws_out_scores.reserve((size_t)B * N * 4));
         d_scores = idx->ws_out_scores.as<float>();
     }
-    hipLaunchKernelGGL(dense_scores_kernel, dim3((unsigned)ceil_div64(N, 64), (unsigned)ceil_div(B, 64)), dim3(256), 0, s, dq,
+    hipLaunchKernelGGL(dense_scores_kernel, dim3((unsigned)ceil_div64(N, kDN), (unsigned)ceil_div(B, kDM)), dim3(256), 0, s, dq,
                        idx->mat.as<float>(), B, N, ldp, (uint64_t*)nullptr, d_scores);
     VS_HIP(hipGetLastError());
     if (!out_dev) {
