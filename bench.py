@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--k", type=int, default=K)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-docs", type=int, default=100_000)
+    ap.add_argument("--store", choices=["fp32", "fp16"], default="fp32",
+                    help="value dtype streamed by the scan (fp16 = the reference's fp16=True load default, index.py:135)")
     return ap.parse_args()
 
 
@@ -123,7 +125,8 @@ def main():
 
     row0, n_local = shard_rows(args.docs, world, rank)
     t0 = time.perf_counter()
-    index = DeviceIndex.synthetic(INDEX_SEED, row0, n_local, V, NNZ_DOC, 0, 0, nat.VS_F32, local_rank)
+    store = nat.VS_F16 if args.store == "fp16" else nat.VS_F32
+    index = DeviceIndex.synthetic(INDEX_SEED, row0, n_local, V, NNZ_DOC, 0, 0, store, local_rank)
     info = index.info()
     build_s = time.perf_counter() - t0
     searcher = ShardedSearcher.from_device_index(index, row0, args.docs)
@@ -178,8 +181,8 @@ def main():
             "metric": "queries/sec over 21M-doc sparse index, k=100; recall@100 vs reference",
             "value": qps, "unit": "queries/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"wiki21m-shaped sparse CSR index: {args.docs} docs x {NNZ_DOC} nnz, V={V}, fp32 values, "
+            "dtype": "f32" if args.store == "fp32" else "f16 values, f32/f64 accumulate", "data": "synthetic",
+            "config": {"workload": f"wiki21m-shaped sparse CSR index: {args.docs} docs x {NNZ_DOC} nnz, V={V}, {args.store} values, "
                                    f"row-sharded over {world} GPU(s); {args.batch} queries/step ({NNZ_Q} nnz), k={args.k}",
                        "docs": args.docs, "docs_per_gpu": n_local, "batch": args.batch, "k": args.k, "queries_per_pass": qt,
                        "lanes_per_row": info.lanes_per_row, "index_bytes_per_gpu": info.device_bytes,

@@ -15,6 +15,7 @@
 #include <stdint.h>
 
 #include "topk_keys.h"
+#include "dense_csr.h"
 
 namespace vs {
 
@@ -329,6 +330,79 @@ __global__ __launch_bounds__(kScanThreads) void merge_topk_kernel(MergeArgs a) {
             a.out_scores[(size_t)b * a.out_ld + a.col0 + i] = key_score(key);
             if (a.upper_out && i == K - 1) a.upper_out[b] = key;
         }
+    }
+}
+
+// ---- select: per query, n_cand keys (n_cand large, e.g. every row of a dense index) -> top-k ------------
+// MSD radix refinement on LDS histograms (12-bit digits): each pass over the (L2-resident) keys fixes
+// 12 more bits of the k-th largest key; as soon as the keys at or above the current bin fit the 4096-slot
+// LDS buffer they are collected and sorted.  Keys are distinct (the low word is the row id), so the
+// refinement always terminates.  Same MergeArgs / output convention as merge_topk_kernel.
+template <int UNUSED>
+__global__ __launch_bounds__(kScanThreads) void select_topk_kernel(MergeArgs a) {
+    __shared__ uint64_t buf[kWgCap];
+    __shared__ int hist[4096];
+    __shared__ int scratch[32];
+    __shared__ int s_bin, s_above, s_pop, s_cnt;
+    const int tid = threadIdx.x;
+    const int K = a.k;
+    for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+        const uint64_t* src = a.cand + (size_t)b * a.n_cand;
+        uint64_t prefix = 0;
+        int pbits = 0, need = K, total_above = 0;
+        for (;;) {
+            const int width = min(12, 64 - pbits);
+            const int bins = 1 << width;
+            for (int i = tid; i < bins; i += kScanThreads) hist[i] = 0;
+            __syncthreads();
+            for (int64_t i = tid; i < a.n_cand; i += kScanThreads) {
+                const uint64_t key = src[i];
+                if (pbits == 0 || (key >> (64 - pbits)) == prefix) atomicAdd(&hist[(int)((key >> (64 - pbits - width)) & (uint64_t)(bins - 1))], 1);
+            }
+            __syncthreads();
+            // thread t owns 4 bins in DESCENDING order: bins-1-4t .. bins-4-4t
+            int mine = 0, hb[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int bin = bins - 1 - (4 * tid + j);
+                hb[j] = bin >= 0 ? hist[bin] : 0;
+                mine += hb[j];
+            }
+            int above = block_excl_scan(mine, scratch, tid, nullptr);       // keys in strictly higher bins
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int bin = bins - 1 - (4 * tid + j);
+                if (bin >= 0 && above < need && need <= above + hb[j]) { s_bin = bin; s_above = above; s_pop = hb[j]; }
+                above += hb[j];
+            }
+            __syncthreads();
+            total_above += s_above;
+            need -= s_above;
+            prefix = (prefix << width) | (uint64_t)s_bin;
+            pbits += width;
+            const int pop = s_pop;
+            __syncthreads();
+            if (total_above + pop <= kWgCap || pbits >= 64) break;
+        }
+        // collect keys whose top pbits are >= prefix
+        if (tid == 0) s_cnt = 0;
+        for (int i = tid; i < kWgCap; i += kScanThreads) buf[i] = 0ull;
+        __syncthreads();
+        for (int64_t i = tid; i < a.n_cand; i += kScanThreads) {
+            const uint64_t key = src[i];
+            if ((pbits >= 64 ? key : (key >> (64 - pbits))) >= prefix) {
+                const int pos = atomicAdd(&s_cnt, 1);
+                if (pos < kWgCap) buf[pos] = key;
+            }
+        }
+        wg_sort_desc<kScanThreads>(buf, kWgCap, tid);
+        for (int i = tid; i < K; i += kScanThreads) {
+            const uint64_t key = buf[i];
+            a.out_ids[(size_t)b * a.out_ld + a.col0 + i] = (int64_t)key_row(key) + a.id_offset;
+            a.out_scores[(size_t)b * a.out_ld + a.col0 + i] = key_score(key);
+            if (a.upper_out && i == K - 1) a.upper_out[b] = key;
+        }
+        __syncthreads();
     }
 }
 

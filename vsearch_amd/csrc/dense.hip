@@ -299,7 +299,8 @@ int vs_dense_search(vs_index* idx, const void* q, int q_dtype, int64_t ldq, int3
         m.col0 = 0;
         {
             ProfScope prof("merge_topk", s);
-            hipLaunchKernelGGL(merge_topk_kernel<0>, dim3(std::min(bs, idx->cu_count * 2)), dim3(kScanThreads), 0, s, m);
+            if (N > 2 * kWgCap) hipLaunchKernelGGL(select_topk_kernel<0>, dim3(std::min(bs, idx->cu_count * 2)), dim3(kScanThreads), 0, s, m);
+            else hipLaunchKernelGGL(merge_topk_kernel<0>, dim3(std::min(bs, idx->cu_count * 2)), dim3(kScanThreads), 0, s, m);
         }
         VS_HIP(hipGetLastError());
     }
