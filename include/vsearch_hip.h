@@ -89,6 +89,14 @@ VS_API int vs_index_create_csr(const void* rowptr, int rowptr_dtype, const void*
                                const void* values, int val_dtype, int store_dtype,
                                int64_t n_rows, int32_t n_cols, int device, vs_index** out);
 
+/* Shard-by-shard construction: what SparseIndex.init_index does with `vstack(shards)` (index.py:172-175),
+ * without ever holding the concatenation on the host.  Reserve capacity (rows, 8-nnz packets: a row of
+ * `len` entries takes ceil(len / 8)), then append CSR row blocks in order; rows become searchable as they
+ * are appended.                                                                                       */
+VS_API int vs_index_create_reserved(int64_t rows_cap, int64_t packets_cap, int32_t n_cols, int store_dtype, int device, vs_index** out);
+VS_API int vs_index_append_csr(vs_index* index, const void* rowptr, int rowptr_dtype, const void* colidx, int col_dtype,
+                               const void* values, int val_dtype, int64_t n_rows);
+
 /* Dense index (Index.vector = [n_rows, n_cols], index.py:25-44, retriever.py:292-297). */
 VS_API int vs_index_create_dense(const void* mat, int dtype, int store_dtype, int64_t n_rows, int32_t n_cols,
                                  int64_t ld, int device, vs_index** out);

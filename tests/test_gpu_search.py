@@ -291,3 +291,23 @@ def test_nccl_single_rank_exchange_path():
         assert ids.is_cuda and (ids == ref_ids).all() and (sc == ref_sc).all()
     finally:
         dist.destroy_process_group()
+
+
+def test_reserve_and_append_equals_single_shot():
+    """Shard-by-shard construction (vs_index_create_reserved + vs_index_append_csr) == one-shot creation."""
+    n = 1500
+    ip, ix, d = oracle.synth_csr(31, 0, n, V, 300)
+    whole = DeviceIndex.from_csr(ip, ix, d, V)
+    cuts = [0, 1, 400, 401, 1100, n]
+    packets = int(((np.diff(ip) + 7) // 8).sum())
+    inc = DeviceIndex.reserved(n + 10, packets + 5, V, nat.VS_F32)
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        inc.append_csr(ip[a:b + 1] - ip[a], ix[ip[a]:ip[b]], d[ip[a]:ip[b]])
+    assert inc.info().n_rows == n and inc.info().nnz == ip[-1]
+    for x, y in zip(inc.export_csr(), whole.export_csr()):
+        assert (x == y).all()
+    q = oracle.synth_queries(2, 5)
+    for x, y in zip(inc.search(q, 50), whole.search(q, 50)):
+        assert (x == y).all()
+    with pytest.raises(ValueError, match="reserved"):
+        inc.append_csr(ip[:12] - ip[0], ix[:ip[11]], d[:ip[11]])          # 11 more rows than reserved

@@ -176,6 +176,7 @@ struct vs_index {
     int64_t nnz = 0;
     // CSR device format ("packets": 8 nnz, rows padded with column id n_cols whose query weight is 0)
     int64_t n_packets = 0;
+    int64_t rows_cap = 0, packets_cap = 0;   // reserved capacity (vs_index_create_reserved / append)
     int lanes_per_row = 32;
     vs::DevBuf pk_ptr;   // uint32 [n_rows + 1]
     vs::DevBuf cols;     // uint16 [n_packets * 8]

@@ -203,63 +203,58 @@ int dispatch_rp_ci(int rp_dt, int ci_dt, F&& f) {
 // =================================================================================================
 // creation
 // =================================================================================================
-extern "C" int vs_index_create_csr(const void* rowptr, int rowptr_dtype, const void* colidx, int col_dtype,
-                                   const void* values, int val_dtype, int store_dtype, int64_t n_rows, int32_t n_cols,
-                                   int device, vs_index** out) {
-    if (!out) return fail(VS_EINVAL, "out is NULL");
-    *out = nullptr;
-    if (!rowptr || n_rows < 0 || n_cols <= 0) return fail(VS_EINVAL, "bad rowptr / shape");
-    if (n_cols > 65535) return fail(VS_EUNSUPPORTED, "n_cols = %d > 65535: column ids are stored as uint16", n_cols);
-    if (n_rows >= (1ll << 32) - 1) return fail(VS_EUNSUPPORTED, "n_rows must fit in 32 bits");
-    if (store_dtype != VS_F32 && store_dtype != VS_F16 && store_dtype != VS_NONE) return fail(VS_EINVAL, "bad store_dtype");
+namespace {
+
+int validate_csr_args(const void* rowptr, int rowptr_dtype, const void* /*colidx*/, int col_dtype, const void* values, int val_dtype) {
+    if (!rowptr) return fail(VS_EINVAL, "rowptr is NULL");
     if (values && val_dtype != VS_F32 && val_dtype != VS_F16) return fail(VS_EINVAL, "val_dtype must be VS_F32 or VS_F16");
     if ((rowptr_dtype != VS_I32 && rowptr_dtype != VS_I64) || (col_dtype != VS_I32 && col_dtype != VS_I64))
         return fail(VS_EINVAL, "rowptr/colidx dtype must be VS_I32 or VS_I64");
-    vs_index* idx = nullptr;
-    VS_TRY(new_index(device, &idx));
-    struct Guard { vs_index* p; ~Guard() { if (p) vs_index_destroy(p); } } guard{idx};
-    idx->kind = VS_KIND_CSR;
-    idx->store_dtype = store_dtype;
-    idx->n_rows = n_rows;
-    idx->n_cols = n_cols;
+    return VS_OK;
+}
 
+// Appends n_chunk CSR rows behind the rows already in `idx` (capacity reserved beforehand).
+int append_csr_rows(vs_index* idx, const void* rowptr, int rowptr_dtype, const void* colidx, int col_dtype,
+                    const void* values, int val_dtype, int64_t n_chunk) {
+    const int32_t n_cols = idx->n_cols;
+    const int store_dtype = idx->store_dtype;
     // row pointers on the host (they size everything)
     const size_t rps = dtype_size(rowptr_dtype);
-    std::vector<char> rp_host((size_t)(n_rows + 1) * rps);
+    std::vector<char> rp_host((size_t)(n_chunk + 1) * rps);
     if (is_device_ptr(rowptr)) VS_HIP(hipMemcpy(rp_host.data(), rowptr, rp_host.size(), hipMemcpyDeviceToHost));
     else memcpy(rp_host.data(), rowptr, rp_host.size());
     auto rp_at = [&](int64_t i) -> int64_t {
         return rowptr_dtype == VS_I64 ? reinterpret_cast<const int64_t*>(rp_host.data())[i]
                                       : (int64_t) reinterpret_cast<const int32_t*>(rp_host.data())[i];
     };
-    std::vector<uint32_t> pk((size_t)n_rows + 1);
-    int64_t acc = 0;
-    pk[0] = 0;
-    for (int64_t r = 0; r < n_rows; ++r) {
+    const int64_t row_base = idx->n_rows;                      // global index of the chunk's first row
+    if (row_base + n_chunk > idx->rows_cap) return fail(VS_EINVAL, "append exceeds the reserved %lld rows", (long long)idx->rows_cap);
+    std::vector<uint32_t> pk((size_t)n_chunk + 1);
+    int64_t acc = idx->n_packets;
+    pk[0] = (uint32_t)acc;
+    for (int64_t r = 0; r < n_chunk; ++r) {
         const int64_t len = rp_at(r + 1) - rp_at(r);
-        if (len < 0 || len > n_cols) return fail(VS_EINVAL, "row %lld has %lld entries (n_cols = %d)", (long long)r, (long long)len, n_cols);
+        if (len < 0 || len > n_cols) return fail(VS_EINVAL, "row %lld has %lld entries (n_cols = %d)", (long long)(row_base + r), (long long)len, n_cols);
         acc += (len + 7) / 8;
         if (acc >= (1ll << 32)) return fail(VS_EUNSUPPORTED, "index exceeds 2^32 packets on one device");
         pk[r + 1] = (uint32_t)acc;
     }
-    idx->nnz = rp_at(n_rows) - rp_at(0);
-    idx->n_packets = acc;
-    if (idx->nnz > 0 && !colidx) return fail(VS_EINVAL, "colidx is NULL");
-    VS_TRY(alloc_csr_storage(idx));
-    VS_HIP(hipMemcpy(idx->pk_ptr.p, pk.data(), pk.size() * 4, hipMemcpyHostToDevice));
+    if (acc > idx->packets_cap) return fail(VS_EINVAL, "append exceeds the reserved %lld packets", (long long)idx->packets_cap);
+    const int64_t nnz_chunk = rp_at(n_chunk) - rp_at(0);
+    if (nnz_chunk > 0 && !colidx) return fail(VS_EINVAL, "colidx is NULL");
+    VS_HIP(hipMemcpy(idx->pk_ptr.as<uint32_t>() + row_base, pk.data(), pk.size() * 4, hipMemcpyHostToDevice));
 
     DevBuf flags;
     VS_TRY(flags.alloc(4));
     VS_HIP(hipMemset(flags.p, 0, 4));
-
     const bool src_dev = is_device_ptr(colidx);
     const size_t cis = dtype_size(col_dtype), vsz = values ? dtype_size(val_dtype) : 0;
     const int64_t kMaxChunkNnz = 32ll << 20;
     DevBuf st_rp, st_ci, st_v;
     int64_t r = 0;
-    while (r < n_rows) {
+    while (r < n_chunk) {
         int64_t r_end = r + 1;
-        while (r_end < n_rows && rp_at(r_end + 1) - rp_at(r) <= kMaxChunkNnz && r_end - r < (1 << 22)) ++r_end;
+        while (r_end < n_chunk && rp_at(r_end + 1) - rp_at(r) <= kMaxChunkNnz && r_end - r < (1 << 22)) ++r_end;
         const int64_t base = rp_at(r), cnt = rp_at(r_end) - base;
         const void *d_rp = nullptr, *d_ci = nullptr, *d_v = nullptr;
         // rowptr slice always re-uploaded from the host copy (cheap) so the kernel can index it from 0
@@ -283,29 +278,111 @@ extern "C" int vs_index_create_csr(const void* rowptr, int rowptr_dtype, const v
         }
         const int wpb = 4;
         const unsigned grid = (unsigned)ceil_div64(r_end - r, wpb);
+        const int64_t g0 = row_base + r, g1 = row_base + r_end;       // global row range of this slice
         int rc = dispatch_rp_ci(rowptr_dtype, col_dtype, [&](auto* rp_t, auto* ci_t) -> int {
             using RP = std::remove_cv_t<std::remove_pointer_t<decltype(rp_t)>>;
             using CI = std::remove_cv_t<std::remove_pointer_t<decltype(ci_t)>>;
             if (values && val_dtype == VS_F16)
                 hipLaunchKernelGGL((fill_packets_kernel<RP, CI, __half>), dim3(grid), dim3(wpb * 64), 0, 0, (const RP*)d_rp, (const CI*)d_ci,
-                                   (const __half*)d_v, r, r_end, src_base, idx->pk_ptr.as<uint32_t>(), idx->cols.as<uint16_t>(),
+                                   (const __half*)d_v, g0, g1, src_base, idx->pk_ptr.as<uint32_t>(), idx->cols.as<uint16_t>(),
                                    idx->vals.p, store_dtype, n_cols, flags.as<int>());
             else
                 hipLaunchKernelGGL((fill_packets_kernel<RP, CI, float>), dim3(grid), dim3(wpb * 64), 0, 0, (const RP*)d_rp, (const CI*)d_ci,
-                                   (const float*)d_v, r, r_end, src_base, idx->pk_ptr.as<uint32_t>(), idx->cols.as<uint16_t>(),
+                                   (const float*)d_v, g0, g1, src_base, idx->pk_ptr.as<uint32_t>(), idx->cols.as<uint16_t>(),
                                    idx->vals.p, store_dtype, n_cols, flags.as<int>());
             return VS_OK;
         });
         VS_TRY(rc);
         VS_HIP(hipGetLastError());
-        VS_HIP(hipDeviceSynchronize());       // staging buffers are reused by the next chunk
+        VS_HIP(hipDeviceSynchronize());       // staging buffers are reused by the next slice
         r = r_end;
     }
     int hflags = 0;
     VS_HIP(hipMemcpy(&hflags, flags.p, 4, hipMemcpyDeviceToHost));
     if (hflags & 1) return fail(VS_EINVAL, "column index out of range [0, %d)", n_cols);
     if (hflags & 2) return fail(VS_EINVAL, "store_dtype VS_NONE (binary index) requires every value == 1");
+    idx->n_rows = row_base + n_chunk;
+    idx->n_packets = acc;
+    idx->nnz += nnz_chunk;
+    idx->lanes_per_row = pick_lanes_per_row(idx->n_packets, idx->n_rows);
+    return VS_OK;
+}
+
+int reserve_csr(vs_index* idx, int64_t rows_cap, int64_t packets_cap) {
+    idx->rows_cap = rows_cap;
+    idx->packets_cap = packets_cap;
+    VS_TRY(idx->pk_ptr.alloc((size_t)(rows_cap + 1) * 4));
+    VS_HIP(hipMemset(idx->pk_ptr.p, 0, 4));
+    VS_TRY(idx->cols.alloc(std::max<size_t>((size_t)packets_cap * 16, 16)));
+    if (idx->store_dtype == VS_F32) VS_TRY(idx->vals.alloc(std::max<size_t>((size_t)packets_cap * 32, 32)));
+    if (idx->store_dtype == VS_F16) VS_TRY(idx->vals.alloc(std::max<size_t>((size_t)packets_cap * 16, 16)));
+    return VS_OK;
+}
+
+int check_csr_shape(int64_t n_rows, int32_t n_cols, int store_dtype) {
+    if (n_rows < 0 || n_cols <= 0) return fail(VS_EINVAL, "bad shape");
+    if (n_cols > 65535) return fail(VS_EUNSUPPORTED, "n_cols = %d > 65535: column ids are stored as uint16", n_cols);
+    if (n_rows >= (1ll << 32) - 1) return fail(VS_EUNSUPPORTED, "n_rows must fit in 32 bits");
+    if (store_dtype != VS_F32 && store_dtype != VS_F16 && store_dtype != VS_NONE) return fail(VS_EINVAL, "bad store_dtype");
+    return VS_OK;
+}
+
+}  // namespace
+
+extern "C" int vs_index_create_reserved(int64_t rows_cap, int64_t packets_cap, int32_t n_cols, int store_dtype, int device, vs_index** out) {
+    if (!out) return fail(VS_EINVAL, "out is NULL");
+    *out = nullptr;
+    VS_TRY(check_csr_shape(rows_cap, n_cols, store_dtype));
+    if (packets_cap < 0 || packets_cap >= (1ll << 32)) return fail(VS_EUNSUPPORTED, "packets_cap must be in [0, 2^32)");
+    vs_index* idx = nullptr;
+    VS_TRY(new_index(device, &idx));
+    struct Guard { vs_index* p; ~Guard() { if (p) vs_index_destroy(p); } } guard{idx};
+    idx->kind = VS_KIND_CSR;
+    idx->store_dtype = store_dtype;
+    idx->n_rows = 0;
+    idx->n_cols = n_cols;
+    VS_TRY(reserve_csr(idx, rows_cap, packets_cap));
     guard.p = nullptr;
+    *out = idx;
+    return VS_OK;
+}
+
+extern "C" int vs_index_append_csr(vs_index* idx, const void* rowptr, int rowptr_dtype, const void* colidx, int col_dtype,
+                                   const void* values, int val_dtype, int64_t n_rows) {
+    if (!idx || idx->kind != VS_KIND_CSR) return fail(VS_EINVAL, "not a CSR index");
+    if (n_rows < 0) return fail(VS_EINVAL, "bad n_rows");
+    VS_TRY(validate_csr_args(rowptr, rowptr_dtype, colidx, col_dtype, values, val_dtype));
+    VS_HIP(hipSetDevice(idx->device));
+    return append_csr_rows(idx, rowptr, rowptr_dtype, colidx, col_dtype, values, val_dtype, n_rows);
+}
+
+extern "C" int vs_index_create_csr(const void* rowptr, int rowptr_dtype, const void* colidx, int col_dtype,
+                                   const void* values, int val_dtype, int store_dtype, int64_t n_rows, int32_t n_cols,
+                                   int device, vs_index** out) {
+    if (!out) return fail(VS_EINVAL, "out is NULL");
+    *out = nullptr;
+    VS_TRY(check_csr_shape(n_rows, n_cols, store_dtype));
+    VS_TRY(validate_csr_args(rowptr, rowptr_dtype, colidx, col_dtype, values, val_dtype));
+    // exact packet count from the row pointers
+    const size_t rps = dtype_size(rowptr_dtype);
+    std::vector<char> rp_host((size_t)(n_rows + 1) * rps);
+    if (is_device_ptr(rowptr)) VS_HIP(hipMemcpy(rp_host.data(), rowptr, rp_host.size(), hipMemcpyDeviceToHost));
+    else memcpy(rp_host.data(), rowptr, rp_host.size());
+    int64_t packets = 0;
+    for (int64_t r = 0; r < n_rows; ++r) {
+        const int64_t len = rowptr_dtype == VS_I64 ? reinterpret_cast<const int64_t*>(rp_host.data())[r + 1] - reinterpret_cast<const int64_t*>(rp_host.data())[r]
+                                                   : (int64_t) reinterpret_cast<const int32_t*>(rp_host.data())[r + 1] - reinterpret_cast<const int32_t*>(rp_host.data())[r];
+        if (len < 0 || len > n_cols) return fail(VS_EINVAL, "row %lld has %lld entries (n_cols = %d)", (long long)r, (long long)len, n_cols);
+        packets += (len + 7) / 8;
+    }
+    if (packets >= (1ll << 32)) return fail(VS_EUNSUPPORTED, "index exceeds 2^32 packets on one device");
+    vs_index* idx = nullptr;
+    VS_TRY(vs_index_create_reserved(n_rows, packets, n_cols, store_dtype, device, &idx));
+    int rc = append_csr_rows(idx, rowptr, rowptr_dtype, colidx, col_dtype, values, val_dtype, n_rows);
+    if (rc != VS_OK) {
+        vs_index_destroy(idx);
+        return rc;
+    }
     *out = idx;
     return VS_OK;
 }
@@ -336,6 +413,8 @@ extern "C" int vs_index_create_synthetic(uint64_t seed, int64_t row0, int64_t n_
     }
     idx->nnz = nz;
     idx->n_packets = acc;
+    idx->rows_cap = n_rows;
+    idx->packets_cap = acc;
     VS_TRY(alloc_csr_storage(idx));
     VS_HIP(hipMemcpy(idx->pk_ptr.p, pk.data(), pk.size() * 4, hipMemcpyHostToDevice));
     const int words = (n_cols + 31) / 32;
@@ -546,20 +625,26 @@ int prep_queries(vs_index* idx, const void* q, int q_dtype, int64_t ldq, int B, 
 
 namespace {
 
-template <int G, int VM>
-int launch_mq_g(const MqArgs& a, int grid, size_t lds, hipStream_t s) {
-    VS_HIP(hipFuncSetAttribute((const void*)csr_scan_topk_mq<G, VM, kQT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((csr_scan_topk_mq<G, VM, kQT>), dim3(grid), dim3(kScanThreads), lds, s, a);
+template <int G, int VM, int U>
+int launch_mq_gu(const MqArgs& a, int grid, size_t lds, hipStream_t s) {
+    VS_HIP(hipFuncSetAttribute((const void*)csr_scan_topk_mq<G, VM, kQT, U>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((csr_scan_topk_mq<G, VM, kQT, U>), dim3(grid), dim3(kScanThreads), lds, s, a);
     VS_HIP(hipGetLastError());
     return VS_OK;
 }
+template <int G, int VM>
+int launch_mq_g(int u, const MqArgs& a, int grid, size_t lds, hipStream_t s) {
+    if (u <= 1) return launch_mq_gu<G, VM, 1>(a, grid, lds, s);
+    if (u == 2) return launch_mq_gu<G, VM, 2>(a, grid, lds, s);
+    return launch_mq_gu<G, VM, 3>(a, grid, lds, s);
+}
 template <int VM>
-int launch_mq_vm(int g, const MqArgs& a, int grid, size_t lds, hipStream_t s) {
+int launch_mq_vm(int g, int u, const MqArgs& a, int grid, size_t lds, hipStream_t s) {
     switch (g) {
-        case 8: return launch_mq_g<8, VM>(a, grid, lds, s);
-        case 16: return launch_mq_g<16, VM>(a, grid, lds, s);
-        case 32: return launch_mq_g<32, VM>(a, grid, lds, s);
-        default: return launch_mq_g<64, VM>(a, grid, lds, s);
+        case 8: return launch_mq_g<8, VM>(u, a, grid, lds, s);
+        case 16: return launch_mq_g<16, VM>(u, a, grid, lds, s);
+        case 32: return launch_mq_g<32, VM>(u, a, grid, lds, s);
+        default: return launch_mq_g<64, VM>(u, a, grid, lds, s);
     }
 }
 
@@ -634,9 +719,12 @@ int mq_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64_t id_o
     const size_t lds = mq_fixed_lds_bytes<kQT>(V, mq_acc_rows(idx)) + (size_t)vals_cap * 4;
     {
         ProfScope prof("csr_scan_topk", s);
-        int rc = idx->store_dtype == VS_F32 ? launch_mq_vm<VM_F32>(mq_lanes(idx), a, grid, lds, s)
-               : idx->store_dtype == VS_F16 ? launch_mq_vm<VM_F16>(mq_lanes(idx), a, grid, lds, s)
-                                            : launch_mq_vm<VM_BIN>(mq_lanes(idx), a, grid, lds, s);
+        // packets per lane per trip: enough to cover an average row in one trip, at most 3
+        const double ppr = idx->n_rows > 0 ? (double)idx->n_packets / (double)idx->n_rows : 1.0;
+        const int u = std::max(1, std::min(3, (int)((ppr + mq_lanes(idx) - 1) / mq_lanes(idx))));
+        int rc = idx->store_dtype == VS_F32 ? launch_mq_vm<VM_F32>(mq_lanes(idx), u, a, grid, lds, s)
+               : idx->store_dtype == VS_F16 ? launch_mq_vm<VM_F16>(mq_lanes(idx), u, a, grid, lds, s)
+                                            : launch_mq_vm<VM_BIN>(mq_lanes(idx), u, a, grid, lds, s);
         VS_TRY(rc);
     }
     // 3. merge chunks

@@ -69,7 +69,7 @@ __host__ __device__ inline size_t mq_fixed_lds_bytes(int32_t n_cols, int rows_in
     return tab + (size_t)kMqCap * 8 + (size_t)rows_in_flight * QT * 8 + (size_t)QT * 8 + 64 * 4;
 }
 
-template <int G, int VM, int QT>
+template <int G, int VM, int QT, int U>
 __global__ __launch_bounds__(kScanThreads) void csr_scan_topk_mq(MqArgs a) {
     static_assert(QT == 8 && G >= 8, "the packed hit word assumes 8 query slots per tile; lanes 0..7 of a row group finish them");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -134,14 +134,22 @@ __global__ __launch_bounds__(kScanThreads) void csr_scan_topk_mq(MqArgs a) {
 
         // ---- scan ----
         const int64_t iters = (r1 - r0 + RPI - 1) / RPI;
+        // row pointers of the NEXT row are fetched while the current row is processed (short rows -- BoT --
+        // are otherwise a chain of dependent loads: pointer -> packets -> table)
+        uint32_t np0 = 0, np1 = 0;
+        if (r0 + slot < r1) { np0 = a.pk_ptr[r0 + slot]; np1 = a.pk_ptr[r0 + slot + 1]; }
         for (int64_t it0 = 0; it0 < iters || it0 == 0; it0 += SB) {
             const int64_t it1 = min(iters, it0 + SB);
             for (int64_t it = it0; it < it1; ++it) {
                 const int64_t row = r0 + it * RPI + slot;
                 double* myacc = acc + ((size_t)slot * S + (lg & (S - 1))) * QT;
+                const uint32_t p0 = np0, p1 = np1;
+                {
+                    const int64_t nrow = row + RPI;
+                    if (nrow < r1) { np0 = a.pk_ptr[nrow]; np1 = a.pk_ptr[nrow + 1]; }
+                }
                 if (row < r1) {
-                    const uint32_t p0 = a.pk_ptr[row], p1 = a.pk_ptr[row + 1];
-                    constexpr int U = 3;                       // packets per lane per trip: all loads first, then the hit walks
+                    // U packets per lane per trip: all loads first, then the hit walks
                     const uint32_t padw = (uint32_t)a.n_cols | ((uint32_t)a.n_cols << 16);
                     for (uint32_t pb = p0 + lg; pb < p1; pb += U * G) {
                         uint4 cwu[U];

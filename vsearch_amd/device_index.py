@@ -82,6 +82,22 @@ class DeviceIndex:
         return cls(h)
 
     @classmethod
+    def reserved(cls, rows_cap, packets_cap, n_cols, store_dtype, device=0):
+        """Empty CSR index with room for rows_cap rows / packets_cap 8-nnz packets; fill with append_csr()."""
+        nat.require_device()
+        h = C.c_void_p()
+        nat.check(nat.lib().vs_index_create_reserved(int(rows_cap), int(packets_cap), int(n_cols), int(store_dtype), int(device), C.byref(h)))
+        return cls(h)
+
+    def append_csr(self, indptr, indices, data):
+        """Append a block of CSR rows (a shard) behind the rows already in the index."""
+        p_rp, dt_rp, k1 = as_arg(indptr, (nat.VS_I32, nat.VS_I64))
+        p_ci, dt_ci, k2 = as_arg(indices, (nat.VS_I32, nat.VS_I64))
+        p_v, dt_v, k3 = as_arg(data, (nat.VS_F32, nat.VS_F16))
+        nat.check(nat.lib().vs_index_append_csr(self._h, p_rp, dt_rp, p_ci, dt_ci, p_v, dt_v if data is not None else nat.VS_F32,
+                                                int(indptr.shape[0]) - 1))
+
+    @classmethod
     def from_dense(cls, mat, store_dtype=None, device=0):
         nat.require_device()
         p, dt, keep = as_arg(mat, (nat.VS_F32, nat.VS_F16))

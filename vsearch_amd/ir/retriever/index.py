@@ -268,27 +268,47 @@ class SparseIndex(Index):
     def init_index(self, index_file: Optional[str], fp16: bool = True):
         if not index_file:
             return
-        from scipy.sparse import load_npz, vstack
+        from scipy.sparse import load_npz
         files = sorted(glob.glob(index_file))
         if not files:
             raise FileNotFoundError(f"no index file matches {index_file!r}")
         logger.info("***** Loading %s Index from %d files *****", self.index_type.value, len(files))
-        shards = [load_npz(f).tocsr()[:, self.shift:] for f in files]
-        mat = vstack(shards).tocsr() if len(shards) > 1 else shards[0]
-        mat.sort_indices()
+        # pass 1: sizes only (row pointers are read lazily from the .npz; the column shift can only shorten rows,
+        # so the packet count before the shift is an upper bound for the reservation)
+        rows_total, packets_cap, n_cols = 0, 0, None
+        for f in files:
+            with np.load(f) as z:
+                fmt = z["format"].item() if "format" in z.files else b"csr"
+                fmt = fmt.decode() if isinstance(fmt, bytes) else str(fmt)
+                shape = tuple(int(x) for x in z["shape"])
+                if fmt == "csr":
+                    lens = np.diff(z["indptr"])
+                    packets_cap += int(((lens + 7) // 8).sum())
+                else:                                           # other scipy formats: bound by nnz
+                    packets_cap += int(z["data"].shape[0]) if "data" in z.files else shape[0] * shape[1]
+            rows_total += shape[0]
+            if n_cols is None:
+                n_cols = shape[1]
+            elif n_cols != shape[1]:
+                raise ValueError(f"shard {f} has {shape[1]} columns, expected {n_cols}")
         self._drop_device()
-        self._dtype = torch.float16 if fp16 else torch.float32
-        self._shape = tuple(mat.shape)
-        data = mat.data.astype(np.float32, copy=False)
-        if self._binary():
-            if not bool((data == 1).all()):
-                raise ValueError("BoTIndex expects a binary matrix (every stored value == 1)")
-            store, data = nat.VS_NONE, None
-        else:
-            store = nat.VS_F16 if fp16 else nat.VS_F32           # fp32 -> fp16 conversion happens on the device
-        logger.info("***** Converting Sparse index to the device CSR format *****")
         self._vector = None
-        self._dev = DeviceIndex.from_csr(mat.indptr, mat.indices, data, mat.shape[1], store_dtype=store, device=_gpu_ordinal(self.device))
+        self._dtype = torch.float16 if fp16 else torch.float32
+        self._shape = (rows_total, n_cols - self.shift)
+        store = nat.VS_NONE if self._binary() else (nat.VS_F16 if fp16 else nat.VS_F32)   # fp32 -> fp16 happens on the device
+        logger.info("***** Converting Sparse index to the device CSR format *****")
+        # pass 2: one shard at a time -- the reference's vstack(shards) (index.py:175) never exists on the host
+        dev = DeviceIndex.reserved(rows_total, packets_cap, n_cols - self.shift, store, device=_gpu_ordinal(self.device))
+        for f in files:
+            mat = load_npz(f).tocsr()[:, self.shift:]
+            mat.sort_indices()
+            data = mat.data.astype(np.float32, copy=False)
+            if self._binary():
+                if not bool((data == 1).all()):
+                    raise ValueError("BoTIndex expects a binary matrix (every stored value == 1)")
+                data = None
+            dev.append_csr(mat.indptr, mat.indices, data)
+        self._dev = dev
 
     # -- persistence (index.py:181-202) --------------------------------------------------------------
     def save(self, path):
