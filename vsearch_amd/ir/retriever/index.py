@@ -315,13 +315,14 @@ class SparseIndex(Index):
         """CSR index -> scipy ``.npz`` (keys indices, indptr, data, shape, format; int64 indices)."""
         from scipy.sparse import csr_array, save_npz
         try:
+            # values go to disk as float32: scipy.sparse has no float16, and the loader re-applies fp16 (fp16=True)
             if self._dev is not None:
-                indptr, indices, data = self._dev.export_csr(np.float16 if self._dtype == torch.float16 else np.float32)
+                indptr, indices, data = self._dev.export_csr(np.float32)
                 info = self._dev.info()
                 shape = (info.n_rows, info.n_cols)
             else:
                 ip, ix, d, shape = self._csr_parts(self._vector)
-                indptr, indices, data = ip.cpu().numpy(), ix.cpu().numpy(), d.cpu().numpy()
+                indptr, indices, data = ip.cpu().numpy(), ix.cpu().numpy(), d.float().cpu().numpy()
             save_npz(path, csr_array((data, indices, indptr), shape=shape))
             logger.info("Index successfully saved to %s", path)
         except Exception as exc:
