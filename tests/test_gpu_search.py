@@ -311,3 +311,29 @@ def test_reserve_and_append_equals_single_shot():
         assert (x == y).all()
     with pytest.raises(ValueError, match="reserved"):
         inc.append_csr(ip[:12] - ip[0], ix[:ip[11]], d[:ip[11]])          # 11 more rows than reserved
+
+
+def test_sparsity_aware_dense_index(golden):
+    """A dense index that is > 95 % zeros (VDR embeddings kept dense, retriever.py:292-297) is stored as CSR packets
+    and searched by the CSR scan: same results as the MFMA path and the golden; a really dense matrix stays dense."""
+    g = golden("search_dense")
+    n, b = int(g["n"]), int(g["b"])
+    ip, ix, d = oracle.synth_csr(0, 0, n)
+    dense = np.zeros((n, V), np.float32)
+    dense[np.repeat(np.arange(n), 768), ix] = d
+    auto = DeviceIndex.from_dense(dense, max_density=0.05)
+    info = auto.info()
+    assert info.kind == nat.VS_KIND_DENSE and info.n_packets == n * 96 and info.nnz == n * 768
+    q = oracle.synth_queries(1, b)
+    for k in (1, 100):
+        ids, sc = auto.search(q, k)
+        compare.compare_topk(g[f"ids_k{k}"], g[f"scores_k{k}"], ids, sc, rtol=RTOL)
+    mfma = DeviceIndex.from_dense(dense)                                   # max_density = 0: dense kernel
+    assert mfma.info().n_packets == 0
+    i2, s2 = mfma.search(q, 100)
+    compare.compare_topk(i2, s2, *auto.search(q, 100), rtol=RTOL)
+    assert (auto.export_dense() == dense).all()
+    h16 = DeviceIndex.from_dense(dense.astype(np.float16), max_density=0.05)
+    assert (h16.export_dense(np.float16) == dense.astype(np.float16)).all()
+    full = synth.dense_uniform(41, (64, V), 0.0, 1.0)
+    assert DeviceIndex.from_dense(full, max_density=0.05).info().n_packets == 0

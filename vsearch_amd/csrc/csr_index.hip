@@ -329,6 +329,12 @@ int check_csr_shape(int64_t n_rows, int32_t n_cols, int store_dtype) {
 
 }  // namespace
 
+// internal (dense.hip): append rows to a reserved CSR index from device / host arrays
+int vs_csr_append_rows(vs_index* idx, const void* rowptr, int rowptr_dtype, const void* colidx, int col_dtype,
+                       const void* values, int val_dtype, int64_t n_rows) {
+    return append_csr_rows(idx, rowptr, rowptr_dtype, colidx, col_dtype, values, val_dtype, n_rows);
+}
+
 extern "C" int vs_index_create_reserved(int64_t rows_cap, int64_t packets_cap, int32_t n_cols, int store_dtype, int device, vs_index** out) {
     if (!out) return fail(VS_EINVAL, "out is NULL");
     *out = nullptr;
@@ -442,7 +448,7 @@ static int64_t csr_bytes_per_pass(const vs_index* idx) {
 extern "C" int vs_index_info(const vs_index* idx, vs_index_info_t* o) {
     if (!idx || !o) return fail(VS_EINVAL, "NULL argument");
     memset(o, 0, sizeof(*o));
-    o->kind = idx->kind;
+    o->kind = idx->logical_dense ? VS_KIND_DENSE : idx->kind;
     o->store_dtype = idx->store_dtype;
     o->n_rows = idx->n_rows;
     o->n_cols = idx->n_cols;

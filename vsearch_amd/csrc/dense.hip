@@ -4,6 +4,7 @@
 //   shared top-k merge selects per query.
 #include "common.h"
 #include "csr_scan.h"
+#include "dense_csr.h"
 
 #include <algorithm>
 
@@ -171,6 +172,90 @@ inline int dense_ldp(int32_t n_cols) { return (n_cols + kDenseKC - 1) / kDenseKC
 
 }  // namespace
 
+
+int vs_csr_append_rows(vs_index* idx, const void* rowptr, int rowptr_dtype, const void* colidx, int col_dtype,
+                       const void* values, int val_dtype, int64_t n_rows);
+
+namespace {
+
+// rows of a CSR-backed dense index -> dense rows (zeros elsewhere)
+template <class T>
+__global__ void csr_rows_to_dense_kernel(const uint32_t* pk_ptr, const uint16_t* cols, const void* vals, int store_dtype, int32_t n_cols,
+                                         int64_t row_begin, int64_t row_end, int64_t ld, T* dst) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = row_begin + (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= row_end) return;
+    T* out = dst + (size_t)(row - row_begin) * ld;
+    for (int c = lane; c < n_cols; c += 64) {
+        if constexpr (sizeof(T) == 4) out[c] = 0.f;
+        else out[c] = __float2half_rn(0.f);
+    }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    const int64_t d0 = (int64_t)pk_ptr[row] * 8, d1 = (int64_t)pk_ptr[row + 1] * 8;
+    for (int64_t j = d0 + lane; j < d1; j += 64) {
+        const uint16_t c = cols[j];
+        if (c == (uint16_t)n_cols) continue;
+        float v = 1.0f;
+        if (store_dtype == VS_F32) v = reinterpret_cast<const float*>(vals)[j];
+        else if (store_dtype == VS_F16) v = __half2float(reinterpret_cast<const __half*>(vals)[j]);
+        if constexpr (sizeof(T) == 4) out[c] = v;
+        else out[c] = __float2half_rn(v);
+    }
+}
+
+int export_dense_from_csr(const vs_index* idx, void* mat, int dtype, int64_t ld) {
+    const size_t esz = dtype_size(dtype);
+    const bool dst_dev = is_device_ptr(mat);
+    const int64_t rows_per_chunk = std::max<int64_t>(1, ((int64_t)256 << 20) / ((int64_t)ld * (int64_t)esz));
+    DevBuf stage;
+    for (int64_t r = 0; r < idx->n_rows; r += rows_per_chunk) {
+        const int64_t nr = std::min(rows_per_chunk, idx->n_rows - r);
+        void* ddst = (char*)mat + (size_t)r * ld * esz;
+        if (!dst_dev) {
+            VS_TRY(stage.reserve((size_t)nr * ld * esz));
+            ddst = stage.p;
+        }
+        const unsigned grid = (unsigned)ceil_div64(nr, 4);
+        if (dtype == VS_F32)
+            hipLaunchKernelGGL((csr_rows_to_dense_kernel<float>), dim3(grid), dim3(256), 0, 0, idx->pk_ptr.as<uint32_t>(), idx->cols.as<uint16_t>(),
+                               idx->vals.p, idx->store_dtype, idx->n_cols, r, r + nr, ld, (float*)ddst);
+        else
+            hipLaunchKernelGGL((csr_rows_to_dense_kernel<__half>), dim3(grid), dim3(256), 0, 0, idx->pk_ptr.as<uint32_t>(), idx->cols.as<uint16_t>(),
+                               idx->vals.p, idx->store_dtype, idx->n_cols, r, r + nr, ld, (__half*)ddst);
+        VS_HIP(hipGetLastError());
+        VS_HIP(hipDeviceSynchronize());
+        if (!dst_dev) {
+            const size_t bytes = ((size_t)(nr - 1) * ld + idx->n_cols) * esz;
+            VS_HIP(hipMemcpy((char*)mat + (size_t)r * ld * esz, stage.p, bytes, hipMemcpyDeviceToHost));
+        }
+    }
+    return VS_OK;
+}
+
+// stage rows [r, r + nr) of the caller's matrix as contiguous fp32 [nr, n_cols] on the device
+int stage_rows_f32(const void* mat, int dtype, int64_t ld, int32_t n_cols, int64_t r, int64_t nr, int round_f16, DevBuf& raw, DevBuf& f32) {
+    const size_t esz = dtype_size(dtype);
+    const char* src = (const char*)mat + (size_t)r * ld * esz;
+    const void* dsrc = src;
+    if (!is_device_ptr(mat)) {
+        const size_t bytes = ((size_t)(nr - 1) * ld + n_cols) * esz;
+        VS_TRY(raw.reserve(bytes));
+        VS_HIP(hipMemcpy(raw.p, src, bytes, hipMemcpyHostToDevice));
+        dsrc = raw.p;
+    }
+    VS_TRY(f32.reserve((size_t)nr * n_cols * 4));
+    const unsigned grid = (unsigned)std::min<int64_t>(ceil_div64(nr * n_cols, 256), 16384);
+    if (dtype == VS_F32)
+        hipLaunchKernelGGL((pad_rows_kernel<float>), dim3(grid), dim3(256), 0, 0, (const float*)dsrc, ld, nr, n_cols, n_cols, round_f16, f32.as<float>());
+    else
+        hipLaunchKernelGGL((pad_rows_kernel<__half>), dim3(grid), dim3(256), 0, 0, (const __half*)dsrc, ld, nr, n_cols, n_cols, round_f16, f32.as<float>());
+    VS_HIP(hipGetLastError());
+    return VS_OK;
+}
+
+}  // namespace
+
 extern "C" int vs_index_create_dense(const void* mat, int dtype, int store_dtype, int64_t n_rows, int32_t n_cols, int64_t ld,
                                      int device, vs_index** out) {
     if (!out) return fail(VS_EINVAL, "out is NULL");
@@ -227,12 +312,79 @@ extern "C" int vs_index_create_dense(const void* mat, int dtype, int store_dtype
     return VS_OK;
 }
 
+// Sparsity-aware dense index: a "dense" index of VDR embeddings holds <= 768 non-zeros per 29 523-wide row
+// (retriever.py:292-297 keeps them dense).  When the matrix density is <= max_density the rows are stored
+// as CSR packets and searched by the CSR scan (identical sums: zeros contribute nothing) -- ~2.6 % of the
+// bytes and none of the 2*B*V*N flops; otherwise this is vs_index_create_dense.
+extern "C" int vs_index_create_dense_auto(const void* mat, int dtype, int store_dtype, int64_t n_rows, int32_t n_cols, int64_t ld,
+                                          double max_density, int device, vs_index** out) {
+    if (!out) return fail(VS_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (!mat || n_rows <= 0 || n_cols <= 0 || ld < n_cols) return fail(VS_EINVAL, "bad matrix / shape");
+    if (dtype != VS_F32 && dtype != VS_F16) return fail(VS_EINVAL, "dtype must be VS_F32 or VS_F16");
+    if (store_dtype != VS_F32 && store_dtype != VS_F16) return fail(VS_EINVAL, "store_dtype must be VS_F32 or VS_F16");
+    if (max_density <= 0.0 || n_cols > 65535) return vs_index_create_dense(mat, dtype, store_dtype, n_rows, n_cols, ld, device, out);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        (void)hipGetLastError();
+        return fail(VS_ENODEVICE, "no HIP device visible: libvsearch_hip has no CPU fallback");
+    }
+    if (device < 0 || device >= ndev) return fail(VS_EINVAL, "device %d out of range", device);
+    VS_HIP(hipSetDevice(device));
+    const size_t esz = dtype_size(dtype);
+    const int64_t rows_per_chunk = std::max<int64_t>(1, std::min<int64_t>(((int64_t)256 << 20) / ((int64_t)ld * (int64_t)esz), 1 << 20));
+    DevBuf raw, f32, counts;
+    VS_TRY(counts.alloc((size_t)n_rows * 8));
+    // pass 1: non-zeros per row (of the values as stored, i.e. after fp16 rounding if requested)
+    for (int64_t r = 0; r < n_rows; r += rows_per_chunk) {
+        const int64_t nr = std::min(rows_per_chunk, n_rows - r);
+        VS_TRY(stage_rows_f32(mat, dtype, ld, n_cols, r, nr, store_dtype == VS_F16, raw, f32));
+        hipLaunchKernelGGL(count_nz_kernel<0>, dim3((unsigned)std::min<int64_t>(nr, 2048)), dim3(kSpThreads), 0, 0, f32.as<float>(), (int64_t)n_cols,
+                           (int32_t)nr, n_cols, counts.as<int64_t>() + r);
+        VS_HIP(hipGetLastError());
+        VS_HIP(hipDeviceSynchronize());
+    }
+    std::vector<int64_t> hc((size_t)n_rows);
+    VS_HIP(hipMemcpy(hc.data(), counts.p, (size_t)n_rows * 8, hipMemcpyDeviceToHost));
+    int64_t nnz = 0, packets = 0;
+    for (int64_t r = 0; r < n_rows; ++r) { nnz += hc[r]; packets += (hc[r] + 7) / 8; }
+    if ((double)nnz > max_density * (double)n_rows * (double)n_cols || packets >= (1ll << 32))
+        return vs_index_create_dense(mat, dtype, store_dtype, n_rows, n_cols, ld, device, out);
+    vs_index* idx = nullptr;
+    VS_TRY(vs_index_create_reserved(n_rows, packets, n_cols, store_dtype, device, &idx));
+    struct Guard { vs_index* p; ~Guard() { if (p) vs_index_destroy(p); } } guard{idx};
+    idx->logical_dense = true;
+    // pass 2: dense rows -> CSR (ordered compaction on the device) -> packets
+    DevBuf d_rp, d_cols, d_vals;
+    for (int64_t r = 0; r < n_rows; r += rows_per_chunk) {
+        const int64_t nr = std::min(rows_per_chunk, n_rows - r);
+        std::vector<int64_t> rp((size_t)nr + 1);
+        rp[0] = 0;
+        for (int64_t i = 0; i < nr; ++i) rp[i + 1] = rp[i] + hc[r + i];
+        const int64_t cn = rp[nr];
+        VS_TRY(d_rp.reserve(rp.size() * 8));
+        VS_HIP(hipMemcpy(d_rp.p, rp.data(), rp.size() * 8, hipMemcpyHostToDevice));
+        VS_TRY(d_cols.reserve(std::max<size_t>((size_t)cn * 4, 16)));
+        VS_TRY(d_vals.reserve(std::max<size_t>((size_t)cn * 4, 16)));
+        VS_TRY(stage_rows_f32(mat, dtype, ld, n_cols, r, nr, store_dtype == VS_F16, raw, f32));
+        hipLaunchKernelGGL(fill_csr_kernel<0>, dim3((unsigned)std::min<int64_t>(nr, 2048)), dim3(kSpThreads), 0, 0, f32.as<float>(), (int64_t)n_cols,
+                           (int32_t)nr, n_cols, d_rp.as<int64_t>(), d_cols.as<int32_t>(), d_vals.as<float>(), cn);
+        VS_HIP(hipGetLastError());
+        VS_HIP(hipDeviceSynchronize());
+        VS_TRY(vs_csr_append_rows(idx, d_rp.p, VS_I64, d_cols.p, VS_I32, d_vals.p, VS_F32, nr));
+    }
+    guard.p = nullptr;
+    *out = idx;
+    return VS_OK;
+}
+
 extern "C" int vs_index_export_dense(const vs_index* idx, void* mat, int dtype, int64_t ld) {
     if (!idx || !mat) return fail(VS_EINVAL, "NULL argument");
-    if (idx->kind != VS_KIND_DENSE) return fail(VS_EINVAL, "not a dense index");
+    if (idx->kind != VS_KIND_DENSE && !idx->logical_dense) return fail(VS_EINVAL, "not a dense index");
     if (dtype != VS_F32 && dtype != VS_F16) return fail(VS_EINVAL, "dtype must be VS_F32 or VS_F16");
     if (ld < idx->n_cols) return fail(VS_EINVAL, "ld < n_cols");
     VS_HIP(hipSetDevice(idx->device));
+    if (idx->logical_dense) return export_dense_from_csr(idx, mat, dtype, ld);
     const int ldp = dense_ldp(idx->n_cols);
     const size_t esz = dtype_size(dtype);
     const bool dst_dev = is_device_ptr(mat);

@@ -98,13 +98,15 @@ class DeviceIndex:
                                                 int(indptr.shape[0]) - 1))
 
     @classmethod
-    def from_dense(cls, mat, store_dtype=None, device=0):
+    def from_dense(cls, mat, store_dtype=None, device=0, max_density=0.0):
+        """Dense [N, V] index. max_density > 0: store as CSR packets when the matrix is that sparse
+        (sparsity-aware dense index: same results, searched by the CSR scan)."""
         nat.require_device()
         p, dt, keep = as_arg(mat, (nat.VS_F32, nat.VS_F16))
         n_rows, n_cols = int(mat.shape[0]), int(mat.shape[1])
         h = C.c_void_p()
-        nat.check(nat.lib().vs_index_create_dense(p, dt, dt if store_dtype is None else store_dtype, n_rows, n_cols, n_cols,
-                                                  int(device), C.byref(h)))
+        nat.check(nat.lib().vs_index_create_dense_auto(p, dt, dt if store_dtype is None else store_dtype, n_rows, n_cols, n_cols,
+                                                       float(max_density), int(device), C.byref(h)))
         del keep
         return cls(h)
 

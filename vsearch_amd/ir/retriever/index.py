@@ -47,6 +47,7 @@ def _gpu_ordinal(device) -> int:
 
 class Index:
     index_type = IndexType.DENSE
+    DENSE_AS_CSR_DENSITY = 0.05        # set to 0 to always use the dense (MFMA) search kernel
 
     def __init__(self, index_file: Optional[str] = None, data_file: Optional[str] = None, fp16: bool = True,
                  device: str = "cpu", low_memory: bool = False):
@@ -96,7 +97,9 @@ class Index:
         if v.dtype not in (torch.float32, torch.float16):
             v = v.float()
         store = nat.VS_F16 if v.dtype == torch.float16 else nat.VS_F32
-        return DeviceIndex.from_dense(v.contiguous(), store_dtype=store, device=_gpu_ordinal(self.device))
+        # a dense index of VDR embeddings is > 97 % zeros: below DENSE_AS_CSR_DENSITY it is stored as CSR packets
+        return DeviceIndex.from_dense(v.contiguous(), store_dtype=store, device=_gpu_ordinal(self.device),
+                                      max_density=self.DENSE_AS_CSR_DENSITY)
 
     def _device_index(self) -> DeviceIndex:
         if self._dev is None:
