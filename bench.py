@@ -51,12 +51,18 @@ def parse():
 
 
 def make_query_batches(n_batches, batch, device):
-    """Distinct synthetic query batches (host generation, then resident in HBM)."""
-    import oracle          # only its synthetic generator twin is used here (inputs, not results)
+    """Distinct synthetic query batches, generated on the GPU by the library's own generator (rows of the
+    seed-1 synthetic matrix with 776 non-zeros) and left resident in HBM as dense [B, V] fp32."""
+    from vsearch_amd.device_index import DeviceIndex
     out = []
     for i in range(n_batches):
-        q = oracle.synth_queries(QUERY_SEED, batch, V, NNZ_Q, 0, q0=i * batch)
-        out.append(torch.from_numpy(q).to(device))
+        gen = DeviceIndex.synthetic(QUERY_SEED, i * batch, batch, V, NNZ_Q, 0, 0, 0, device.index or 0)
+        ip, ix, d = gen.export_csr()
+        gen.close()
+        q = torch.zeros((batch, V), dtype=torch.float32, device=device)
+        rows = torch.from_numpy(np.repeat(np.arange(batch), np.diff(ip))).to(device)
+        q[rows, torch.from_numpy(ix).to(device)] = torch.from_numpy(d).to(device)
+        out.append(q)
     return out
 
 

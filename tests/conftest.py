@@ -16,6 +16,9 @@ SHIFT = 999
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box via gpurun)")
+    # keep the checker in step with its source (single process here; bench ranks never rebuild it)
+    import subprocess
+    subprocess.call(["make", "-s", "-C", os.path.join(REPO, "oracle")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
 
 
 @pytest.fixture(scope="session")

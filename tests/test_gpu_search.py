@@ -337,3 +337,32 @@ def test_sparsity_aware_dense_index(golden):
     assert (h16.export_dense(np.float16) == dense.astype(np.float16)).all()
     full = synth.dense_uniform(41, (64, V), 0.0, 1.0)
     assert DeviceIndex.from_dense(full, max_density=0.05).info().n_packets == 0
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_shapes_against_oracle(seed):
+    """Randomised small problems: odd vocabulary sizes, ragged/empty rows, B and k not multiples of anything,
+    all three value modes, both scan families -- each checked against the full oracle score matrix."""
+    rng = np.random.default_rng(100 + seed)
+    n_cols = int(rng.choice([7, 40, 257, 1000, 4099, 65535]))
+    n = int(rng.integers(1, 700))
+    max_len = min(n_cols, int(rng.choice([1, 5, 60, 300])))
+    lens = rng.integers(0, max_len + 1, size=n)
+    ip = np.zeros(n + 1, np.int64)
+    np.cumsum(lens, out=ip[1:])
+    ix = np.concatenate([np.sort(rng.choice(n_cols, size=l, replace=False)) for l in lens] + [np.zeros(0, np.int64)]).astype(np.int32)
+    mode = seed % 3
+    d = None if mode == 2 else rng.integers(1, 200, size=ix.size).astype(np.float32) / 16          # exactly representable in fp16 too
+    B = int(rng.integers(1, 20))
+    q = np.zeros((B, n_cols), np.float32)
+    for i in range(B):
+        nz = int(rng.integers(0, min(n_cols, 50) + 1))
+        q[i, rng.choice(n_cols, size=nz, replace=False)] = rng.integers(-64, 128, size=nz).astype(np.float32) / 32
+    idx = DeviceIndex.from_csr(ip, ix, d, n_cols, store_dtype={0: nat.VS_F32, 1: nat.VS_F16, 2: nat.VS_NONE}[mode])
+    _, _, allsc = oracle.csr_search(ip, ix, d, n_cols, q, 1, acc64=True, return_all=True)
+    assert (idx.scores(q) == allsc).all()                      # small dyadic values: every sum is exact
+    for k in sorted({1, min(n, 7), min(n, 130), n}):
+        for qt in (0, 1):
+            idx.set_queries_per_pass(qt)
+            ids, sc = idx.search(q, k)
+            compare.check_topk_valid(allsc, ids, sc, exact=True, canonical=True)

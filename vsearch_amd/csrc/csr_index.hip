@@ -698,11 +698,28 @@ int mq_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64_t id_o
     float* qvals = reinterpret_cast<float*>(qcols + qnnz);
     hipLaunchKernelGGL(fill_csr_kernel<0>, dim3(std::min(B, 2048)), dim3(kSpThreads), 0, s, dq, (int64_t)V, B, V, qptr, qcols, qvals, qnnz);
     VS_HIP(hipGetLastError());
-    // 2. scan
-    const int64_t items = (int64_t)n_tiles * plan.nchunk;
+    // 2. scan.  Work items = (tile, row chunk).  Every item pays a table build and top-k sorts, so chunks are as
+    // long as the machine allows: with many tiles the rows are cut into few chunks (each workgroup streams a long
+    // row range for its own tile), with few tiles into up to one chunk per CU.
+    int nchunk = plan.nchunk;
+    {
+        const int cus = idx->cu_count;
+        const int max_chunks = (int)std::max<int64_t>(1, std::min<int64_t>(plan.nchunk, idx->n_rows / 512));
+        int best = std::min(max_chunks, std::max(1, (cus + n_tiles - 1) / n_tiles));
+        double best_eff = 0.0;
+        for (int c = best; c <= max_chunks; ++c) {
+            const int64_t it = (int64_t)n_tiles * c;
+            const double eff = (double)it / (double)(((it + cus - 1) / cus) * cus);      // fill of the last round
+            if (eff > best_eff + 1e-9) { best_eff = eff; best = c; }
+            if (eff >= 0.92) break;
+        }
+        nchunk = best;
+    }
+    const int64_t rows_per_chunk = ceil_div64(idx->n_rows, nchunk);
+    const int64_t items = (int64_t)n_tiles * nchunk;
     const int grid = (int)std::min<int64_t>(items, idx->cu_count);
     VS_TRY(idx->ws_mq_cand.reserve((size_t)grid * kQT * kMqCap * 8 + (size_t)grid * kQT * 4));
-    VS_TRY(idx->ws_cand.reserve((size_t)B * plan.nchunk * k * 8));
+    VS_TRY(idx->ws_cand.reserve((size_t)B * nchunk * k * 8));
     MqArgs a{};
     a.pk_ptr = idx->pk_ptr.as<uint32_t>();
     a.cols = idx->cols.as<uint4>();
@@ -710,8 +727,8 @@ int mq_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64_t id_o
     a.n_rows = idx->n_rows;
     a.n_cols = V;
     a.k = k;
-    a.nchunk = plan.nchunk;
-    a.rows_per_chunk = plan.rows_per_chunk;
+    a.nchunk = nchunk;
+    a.rows_per_chunk = rows_per_chunk;
     a.qptr = qptr;
     a.qcols = qcols;
     a.qvals = qvals;
@@ -736,7 +753,7 @@ int mq_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64_t id_o
     // 3. merge chunks
     MergeArgs m{};
     m.cand = a.cand;
-    m.n_cand = (int64_t)plan.nchunk * k;
+    m.n_cand = (int64_t)nchunk * k;
     m.B = B;
     m.k = k;
     m.id_offset = id_offset;
