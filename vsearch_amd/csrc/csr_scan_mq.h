@@ -187,16 +187,24 @@ __global__ __launch_bounds__(kScanThreads) void csr_scan_topk_mq(MqArgs a) {
 #pragma unroll
                             for (int i = 0; i < 4; ++i) { t[2 * i] = tab[cwv[i] & 0xFFFF]; t[2 * i + 1] = tab[cwv[i] >> 16]; }
                             if (a.debug_variant == 1) continue;
-                            // first hit of every position: straight-line, static registers
+                            // first hits, two packet positions (i, i+4) per LDS round trip: a position hits with
+                            // p ~ 0.2, so "exactly one of the pair" is the common case and is served by ONE weight
+                            // fetch + ONE ds_add_f64 instead of two mostly-empty ones; a pair whose both positions
+                            // hit leaves position i+4 to the remainder loop.
                             uint32_t r[8];                                             // remaining hit bits per position
 #pragma unroll
-                            for (int i = 0; i < 8; ++i) {
-                                const uint32_t m1 = t[i] & 0xFFu;
+                            for (int i = 0; i < 4; ++i) {
+                                const uint32_t ma = t[i] & 0xFFu, mb = t[i + 4] & 0xFFu;
+                                const bool use_a = ma != 0;
+                                const uint32_t m1 = use_a ? ma : mb;
+                                const uint32_t ts = use_a ? t[i] : t[i + 4];
+                                const float vs_ = use_a ? vu[u][i] : vu[u][i + 4];
                                 if (m1) {
-                                    const float w = *reinterpret_cast<const float*>(qvb + (t[i] >> QT));
-                                    atomicAdd(&myacc[__ffs(m1) - 1], (double)(vu[u][i] * w));          // ds_add_f64
+                                    const float w = *reinterpret_cast<const float*>(qvb + (ts >> QT));
+                                    atomicAdd(&myacc[__ffs(m1) - 1], (double)(vs_ * w));                // ds_add_f64
                                 }
-                                r[i] = m1 & (m1 - 1);
+                                r[i] = ma & (ma - 1);
+                                r[i + 4] = use_a ? mb : (mb & (mb - 1));
                             }
                             // columns shared by >= 2 queries of the tile (~10 % of hits): one loop over the packed
                             // remainder word -- few iterations, and far fewer LDS instructions than a second
