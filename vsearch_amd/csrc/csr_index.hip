@@ -738,7 +738,6 @@ int mq_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64_t id_o
     a.cand = idx->ws_cand.as<uint64_t>();
     a.gcand = idx->ws_mq_cand.as<uint64_t>();
     a.gcnt = reinterpret_cast<uint32_t*>(a.gcand + (size_t)grid * kQT * kMqCap);
-    if (const char* dv = getenv("VS_MQ_VARIANT")) a.debug_variant = atoi(dv);
     const size_t lds = mq_fixed_lds_bytes<kQT>(V, mq_acc_rows(idx)) + (size_t)vals_cap * 4;
     {
         ProfScope prof("csr_scan_topk", s);

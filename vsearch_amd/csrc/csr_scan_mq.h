@@ -60,7 +60,6 @@ struct MqArgs {
     uint64_t* cand;           // [B, nchunk, k] output keys, sorted descending
     uint64_t* gcand;          // [grid, QT, kMqCap] scratch
     uint32_t* gcnt;           // [grid, QT] scratch counters
-    int32_t debug_variant;    // perf experiments only (VS_MQ_VARIANT): 1 = skip hit loop, 2 = skip atomics, 3 = skip lookups too
 };
 
 template <int QT>
@@ -186,7 +185,6 @@ __global__ __launch_bounds__(kScanThreads) void csr_scan_topk_mq(MqArgs a) {
                             uint32_t t[8];
 #pragma unroll
                             for (int i = 0; i < 4; ++i) { t[2 * i] = tab[cwv[i] & 0xFFFF]; t[2 * i + 1] = tab[cwv[i] >> 16]; }
-                            if (a.debug_variant == 1) continue;
                             // first hits, two packet positions (i, i+4) per LDS round trip: a position hits with
                             // p ~ 0.2, so "exactly one of the pair" is the common case and is served by ONE weight
                             // fetch + ONE ds_add_f64 instead of two mostly-empty ones; a pair whose both positions
