@@ -190,20 +190,23 @@ __global__ __launch_bounds__(kScanThreads) void csr_scan_topk_mq(MqArgs a) {
                             // fetch + ONE ds_add_f64 instead of two mostly-empty ones; a pair whose both positions
                             // hit leaves position i+4 to the remainder loop.
                             uint32_t r[8];                                             // remaining hit bits per position
+                            uint32_t m1[4];
+                            float wv[4];
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) {
+                            for (int i = 0; i < 4; ++i) {                              // all four weight fetches first (independent)
                                 const uint32_t ma = t[i] & 0xFFu, mb = t[i + 4] & 0xFFu;
                                 const bool use_a = ma != 0;
-                                const uint32_t m1 = use_a ? ma : mb;
+                                m1[i] = use_a ? ma : mb;
                                 const uint32_t ts = use_a ? t[i] : t[i + 4];
                                 const float vs_ = use_a ? vu[u][i] : vu[u][i + 4];
-                                if (m1) {
-                                    const float w = *reinterpret_cast<const float*>(qvb + (ts >> QT));
-                                    atomicAdd(&myacc[__ffs(m1) - 1], (double)(vs_ * w));                // ds_add_f64
-                                }
+                                // lanes without a hit read entry 0 (one broadcast address: no bank conflict, result unused)
+                                wv[i] = vs_ * *reinterpret_cast<const float*>(qvb + (m1[i] ? (ts >> QT) : 0u));
                                 r[i] = ma & (ma - 1);
                                 r[i + 4] = use_a ? mb : (mb & (mb - 1));
                             }
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                if (m1[i]) atomicAdd(&myacc[__ffs(m1[i]) - 1], (double)wv[i]);         // ds_add_f64
                             // columns shared by >= 2 queries of the tile (~10 % of hits): one loop over the packed
                             // remainder word -- few iterations, and far fewer LDS instructions than a second
                             // exec-masked pass over all 8 positions
