@@ -46,104 +46,150 @@ __global__ void unpad_rows_kernel(const float* src, int32_t ldp, int64_t n_rows,
 }
 
 // scores[B, N] = Q[B, V] . P[N, V]^T on the fp32 matrix cores.
-// Workgroup = 4 waves = 128 queries x 128 docs; wave = 64 x 64 = 2 x 2 MFMA tiles (v_mfma_f32_32x32x2_f32).
-// K is walked in chunks of 32 columns: both operand tiles (128 x 32 fp32 each) are fetched with coalesced
-// 16-byte loads into registers while the previous chunk is multiplied (register-staged prefetch), then
-// written to LDS with a 36-float row pitch -- with that pitch a 16-lane ds_read_b128 group touches all 64
-// banks exactly once.  The MFMA K order is permuted (half-wave h owns columns 16h..16h+15 of the chunk) so
-// a lane's operands for 4 consecutive MFMA steps are one ds_read_b128.  Rows are padded to ldp (multiple
-// of 32) with zeros.  Two-level summation: chains inside 512-column blocks, block sums added to `tot`.
-constexpr int kDM = 128, kDN = 128, kDPitch = kDenseKC + 4;
+// Workgroup = 4 waves arranged WM x WN; a wave owns TM x TN MFMA tiles of 32 x 32 (v_mfma_f32_32x32x2_f32), so the
+// block tile is BM x BN = (WM*TM*32) queries x (WN*TN*32) docs.  <2,2,2,2> = 128 x 128 is the main shape; <1,4,1,1> =
+// 32 x 128 blocks (a quarter of the work each) fill the last, partial round of the grid so the tail does not
+// cost a whole extra round.  K is walked in chunks of 32 columns: both operand tiles are fetched with coalesced
+// 16-byte loads into registers while the previous chunk is multiplied (register-staged prefetch), then written
+// to a double-buffered LDS image with a 36-float row pitch -- with that pitch a 16-lane ds_read_b128 group
+// touches all 64 banks exactly once.  The MFMA K order is permuted (half-wave h owns columns 16h..16h+15 of the
+// chunk) so a lane's operands for 4 consecutive MFMA steps are one ds_read_b128.  Rows are padded to ldp
+// (multiple of 32) with zeros.  Two-level summation: chains inside 512-column blocks, block sums added to `tot`.
+constexpr int kDPitch = kDenseKC + 4;
 
-__global__ __launch_bounds__(256, 1) void dense_scores_kernel(const float* __restrict__ Q, const float* __restrict__ P, int32_t B,
-                                                           int64_t N, int32_t ldp, uint64_t* keys, float* scores) {
-    __shared__ __attribute__((aligned(16))) float As[kDM * kDPitch];
-    __shared__ __attribute__((aligned(16))) float Bs[kDN * kDPitch];
+template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(256) void dense_scores_kernel(const float* __restrict__ Q, const float* __restrict__ P, int32_t B,
+                                                           int64_t N, int64_t n_begin, int32_t ldp, uint64_t* keys, float* scores) {
+    static_assert(WM * WN == 4 && WM * TM <= 4 && WN * TN <= 4, "4 waves per workgroup, tiles up to 128 x 128");
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int JA = BM / 32, JB = BN / 32;               // float4 staged per thread for each operand
+    __shared__ __attribute__((aligned(16))) float As[2][BM * kDPitch];      // double-buffered: one barrier per K chunk
+    __shared__ __attribute__((aligned(16))) float Bs[2][BN * kDPitch];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int wm = w >> 1, wn = w & 1;
+    const int wm = w / WN, wn = w % WN;
     const int h = lane >> 5, l31 = lane & 31;
-    const int64_t n_blk = (int64_t)blockIdx.x * kDN;
-    const int b_blk = blockIdx.y * kDM;
+    const int64_t n_blk = n_begin + (int64_t)blockIdx.x * BN;
+    const int b_blk = blockIdx.y * BM;
     // global -> register staging: thread t covers rows (t/8) + 32 j, 16-byte column group t%8
     const int lr = tid >> 3, lc = (tid & 7) * 4;
-    const float* qsrc[4];
-    const float* psrc[4];
+    const float4* q4[JA];
+    const float4* p4[JB];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        qsrc[j] = Q + (size_t)min(b_blk + lr + 32 * j, B - 1) * ldp + lc;
-        psrc[j] = P + (size_t)min(n_blk + lr + 32 * j, N - 1) * ldp + lc;
-    }
+    for (int j = 0; j < JA; ++j) q4[j] = reinterpret_cast<const float4*>(Q + (size_t)min(b_blk + lr + 32 * j, B - 1) * ldp + lc);
+#pragma unroll
+    for (int j = 0; j < JB; ++j) p4[j] = reinterpret_cast<const float4*>(P + (size_t)min(n_blk + lr + 32 * j, N - 1) * ldp + lc);
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    f32x16 tot[2][2], acc[2][2];
+    f32x16 tot[TM][TN], acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) { tot[i][j] = zero; acc[i][j] = zero; }
-    // named registers on purpose: as arrays these staging values end up in scratch memory
-    const float4* q4[4] = {reinterpret_cast<const float4*>(qsrc[0]), reinterpret_cast<const float4*>(qsrc[1]),
-                           reinterpret_cast<const float4*>(qsrc[2]), reinterpret_cast<const float4*>(qsrc[3])};
-    const float4* p4[4] = {reinterpret_cast<const float4*>(psrc[0]), reinterpret_cast<const float4*>(psrc[1]),
-                           reinterpret_cast<const float4*>(psrc[2]), reinterpret_cast<const float4*>(psrc[3])};
-    float4 ra0 = q4[0][0], ra1 = q4[1][0], ra2 = q4[2][0], ra3 = q4[3][0];
-    float4 rb0 = p4[0][0], rb1 = p4[1][0], rb2 = p4[2][0], rb3 = p4[3][0];
+        for (int j = 0; j < TN; ++j) { tot[i][j] = zero; acc[i][j] = zero; }
+    // staging registers: named scalars + `if constexpr` (as arrays -- even with unrolled constant indices -- the
+    // compiler keeps them in scratch memory, which halves the kernel's speed)
+    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+    ra0 = ra1 = ra2 = ra3 = rb0 = rb1 = rb2 = rb3 = make_float4(0.f, 0.f, 0.f, 0.f);
     const int chunks = ldp / kDenseKC;
-    const float* a_rd = As + (wm * 64 + l31) * kDPitch + h * 16;
-    const float* b_rd = Bs + (wn * 64 + l31) * kDPitch + h * 16;
+    const int a_off = (wm * TM * 32 + l31) * kDPitch + h * 16, b_off = (wn * TN * 32 + l31) * kDPitch + h * 16;
+    const int wa = lr * kDPitch + lc;
+#define VS_DENSE_FETCH(c)                                     \
+    {                                                         \
+        const int cn_ = min((c), chunks - 1) * (kDenseKC / 4);\
+        ra0 = q4[0][cn_];                                     \
+        if constexpr (JA > 1) ra1 = q4[JA > 1 ? 1 : 0][cn_];  \
+        if constexpr (JA > 2) ra2 = q4[JA > 2 ? 2 : 0][cn_];  \
+        if constexpr (JA > 3) ra3 = q4[JA > 3 ? 3 : 0][cn_];  \
+        rb0 = p4[0][cn_];                                     \
+        if constexpr (JB > 1) rb1 = p4[JB > 1 ? 1 : 0][cn_];  \
+        if constexpr (JB > 2) rb2 = p4[JB > 2 ? 2 : 0][cn_];  \
+        if constexpr (JB > 3) rb3 = p4[JB > 3 ? 3 : 0][cn_];  \
+    }
+#define VS_DENSE_STAGE(buf)                                                                            \
+    {                                                                                                  \
+        *reinterpret_cast<float4*>(As[buf] + wa) = ra0;                                                \
+        if constexpr (JA > 1) *reinterpret_cast<float4*>(As[buf] + wa + 32 * kDPitch) = ra1;           \
+        if constexpr (JA > 2) *reinterpret_cast<float4*>(As[buf] + wa + 64 * kDPitch) = ra2;           \
+        if constexpr (JA > 3) *reinterpret_cast<float4*>(As[buf] + wa + 96 * kDPitch) = ra3;           \
+        *reinterpret_cast<float4*>(Bs[buf] + wa) = rb0;                                                \
+        if constexpr (JB > 1) *reinterpret_cast<float4*>(Bs[buf] + wa + 32 * kDPitch) = rb1;           \
+        if constexpr (JB > 2) *reinterpret_cast<float4*>(Bs[buf] + wa + 64 * kDPitch) = rb2;           \
+        if constexpr (JB > 3) *reinterpret_cast<float4*>(Bs[buf] + wa + 96 * kDPitch) = rb3;           \
+    }
+    VS_DENSE_FETCH(0)
+    VS_DENSE_STAGE(0)
+    VS_DENSE_FETCH(1)
+    __syncthreads();
     for (int c = 0; c < chunks; ++c) {
-        __syncthreads();                                   // previous chunk's fragment reads are done
-        *reinterpret_cast<float4*>(As + (lr + 0) * kDPitch + lc) = ra0;
-        *reinterpret_cast<float4*>(As + (lr + 32) * kDPitch + lc) = ra1;
-        *reinterpret_cast<float4*>(As + (lr + 64) * kDPitch + lc) = ra2;
-        *reinterpret_cast<float4*>(As + (lr + 96) * kDPitch + lc) = ra3;
-        *reinterpret_cast<float4*>(Bs + (lr + 0) * kDPitch + lc) = rb0;
-        *reinterpret_cast<float4*>(Bs + (lr + 32) * kDPitch + lc) = rb1;
-        *reinterpret_cast<float4*>(Bs + (lr + 64) * kDPitch + lc) = rb2;
-        *reinterpret_cast<float4*>(Bs + (lr + 96) * kDPitch + lc) = rb3;
-        __syncthreads();
-        {                                                  // prefetch the next chunk; lands while the MFMAs run
-            const int cn = min(c + 1, chunks - 1) * (kDenseKC / 4);      // (last trip re-reads its own chunk: harmless)
-            ra0 = q4[0][cn]; ra1 = q4[1][cn]; ra2 = q4[2][cn]; ra3 = q4[3][cn];
-            rb0 = p4[0][cn]; rb1 = p4[1][cn]; rb2 = p4[2][cn]; rb3 = p4[3][cn];
-        }
+        const float* a_rd = As[c & 1] + a_off;
+        const float* b_rd = Bs[c & 1] + b_off;
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
-            float4 fa[2], fb[2];
-            fa[0] = *reinterpret_cast<const float4*>(a_rd + s4 * 4);
-            fa[1] = *reinterpret_cast<const float4*>(a_rd + 32 * kDPitch + s4 * 4);
-            fb[0] = *reinterpret_cast<const float4*>(b_rd + s4 * 4);
-            fb[1] = *reinterpret_cast<const float4*>(b_rd + 32 * kDPitch + s4 * 4);
+            float4 fa[TM], fb[TN];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const float4*>(a_rd + i * 32 * kDPitch + s4 * 4);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const float4*>(b_rd + j * 32 * kDPitch + s4 * 4);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
                 }
         }
+        // the other buffer was last read in iteration c-1 (every wave has passed that iteration's barrier)
+        if (c + 1 < chunks) {
+            if (c & 1) VS_DENSE_STAGE(0) else VS_DENSE_STAGE(1)
+        }
+        __syncthreads();
+        VS_DENSE_FETCH(c + 2)
         if ((c & 15) == 15 || c == chunks - 1) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) { tot[i][j] += acc[i][j]; acc[i][j] = zero; }
+                for (int j = 0; j < TN; ++j) { tot[i][j] += acc[i][j]; acc[i][j] = zero; }
         }
     }
+#undef VS_DENSE_FETCH
+#undef VS_DENSE_STAGE
     // C/D layout of a 32x32 tile: col = lane & 31 (doc), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (query)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int64_t n = n_blk + wn * 64 + j * 32 + l31;
+        for (int j = 0; j < TN; ++j) {
+            const int64_t n = n_blk + (wn * TN + j) * 32 + l31;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int b = b_blk + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int b = b_blk + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (b < B && n < N) {
                     if (keys) keys[(size_t)b * N + n] = make_key(tot[i][j][r], (uint32_t)n);
                     if (scores) scores[(size_t)b * N + n] = tot[i][j][r];
                 }
             }
         }
+}
+
+// Launch plan: full rounds of 128 x 128 blocks (2 co-resident per CU), then the remaining doc range with 32 x 128 blocks.
+int launch_dense_scores(const vs_index* idx, const float* dq, int B, int ldp, uint64_t* keys, float* scores, hipStream_t s) {
+    const int64_t N = idx->n_rows;
+    const int64_t doc_tiles = ceil_div64(N, 128), q_tiles = ceil_div64(B, 128);
+    const int64_t slots = (int64_t)idx->cu_count * 2;
+    const int64_t full_rounds = (doc_tiles * q_tiles) / slots;
+    int64_t main_doc_tiles = std::min(doc_tiles, (full_rounds * slots) / q_tiles);
+    if (main_doc_tiles * 128 > N) main_doc_tiles = N / 128;
+    if (main_doc_tiles > 0) {
+        hipLaunchKernelGGL((dense_scores_kernel<2, 2, 2, 2>), dim3((unsigned)main_doc_tiles, (unsigned)q_tiles), dim3(256), 0, s, dq,
+                           idx->mat.as<float>(), B, N, (int64_t)0, ldp, keys, scores);
+        VS_HIP(hipGetLastError());
+    }
+    const int64_t n_begin = main_doc_tiles * 128;
+    if (n_begin < N) {
+        hipLaunchKernelGGL((dense_scores_kernel<1, 4, 1, 1>), dim3((unsigned)ceil_div64(N - n_begin, 128), (unsigned)ceil_div(B, 32)), dim3(256), 0, s,
+                           dq, idx->mat.as<float>(), B, N, n_begin, ldp, keys, scores);
+        VS_HIP(hipGetLastError());
+    }
+    return VS_OK;
 }
 
 int prep_dense_queries(vs_index* idx, const void* q, int q_dtype, int64_t ldq, int B, int ldp, hipStream_t s, const float** out) {
@@ -435,8 +481,7 @@ int vs_dense_search(vs_index* idx, const void* q, int q_dtype, int64_t ldq, int3
         const int bs = std::min(bs_max, B - b0);
         {
             ProfScope prof("dense_scores", s);
-            hipLaunchKernelGGL(dense_scores_kernel, dim3((unsigned)ceil_div64(N, kDN), (unsigned)ceil_div(bs, kDM)), dim3(256), 0, s,
-                               dq + (size_t)b0 * ldp, idx->mat.as<float>(), bs, N, ldp, idx->ws_cand.as<uint64_t>(), (float*)nullptr);
+            VS_TRY(launch_dense_scores(idx, dq + (size_t)b0 * ldp, bs, ldp, idx->ws_cand.as<uint64_t>(), nullptr, s));
         }
         VS_HIP(hipGetLastError());
         MergeArgs m{};
@@ -475,9 +520,7 @@ int vs_dense_scores(vs_index* idx, const void* q, int q_dtype, int64_t ldq, int3
         VS_TRY(idx->ws_out_scores.reserve((size_t)B * N * 4));
         d_scores = idx->ws_out_scores.as<float>();
     }
-    hipLaunchKernelGGL(dense_scores_kernel, dim3((unsigned)ceil_div64(N, kDN), (unsigned)ceil_div(B, kDM)), dim3(256), 0, s, dq,
-                       idx->mat.as<float>(), B, N, ldp, (uint64_t*)nullptr, d_scores);
-    VS_HIP(hipGetLastError());
+    VS_TRY(launch_dense_scores(idx, dq, B, ldp, nullptr, d_scores, s));
     if (!out_dev) {
         VS_HIP(hipMemcpyAsync(out_scores, d_scores, (size_t)B * N * 4, hipMemcpyDeviceToHost, s));
         VS_HIP(hipStreamSynchronize(s));
