@@ -175,6 +175,12 @@ VS_API int vs_dense_to_csr(const float* x, int32_t B, int32_t V, int64_t ld, int
  * (computed as elu1p(max) -- elu1p is monotone; pad positions are pooled like the reference).    */
 VS_API int vs_head_pool(const float* logits, int32_t B, int32_t L, int32_t V, float* out, int device, void* stream);
 
+/* Encoder head, fused (vdr.py:72-75): out[b, v] = elu1p(max_l hidden[b, l, :] . W[v, :]) on the fp32 matrix cores;
+ * hidden [B, L, H] (LayerNorm'ed), W [V, H] (= word_embeddings[shift:]), out [B, V]: device pointers, H % 32 == 0.
+ * The reference's [B, L, V] logits tensor is never materialised.                                          */
+VS_API int vs_head_project_pool(const float* hidden, const float* W, int32_t B, int32_t L, int32_t H, int32_t V, float* out,
+                                int device, void* stream);
+
 /* elu1p (sparse.py:6) elementwise. */
 VS_API int vs_elu1p(const float* x, int64_t n, float* out, int device, void* stream);
 

@@ -361,3 +361,30 @@ def test_build_index_and_retrieve_text_queries(tiny_retriever, index_type, tmp_p
     path = str(tmp_path / ("idx.pt" if r.index.index_type == IndexType.DENSE else "idx.npz"))
     r.save_index(path)
     assert os.path.getsize(path) > 0
+
+
+@pytest.mark.parametrize("B,L,H,vocab", [(4, 16, 768, 3000), (3, 200, 64, 2500), (2, 129, 96, 1200), (5, 7, 32, 999 + 130)])
+def test_fused_head_project_pool(golden, B, L, H, vocab):
+    """vs_head_project_pool == elu1p(max_l LN(h) @ W[shift:].T) (vdr.py:71-75), incl. the golden encoder-head fixture."""
+    shift = 999
+    if (B, L, H, vocab) == (4, 16, 768, 3000):
+        g = golden("encoder_head")
+        s = g["seeds"].tolist()
+        hidden = torch.from_numpy(synth.dense_uniform(s[0], (B, L, H), -2.0, 2.0)).cuda()
+        W = torch.from_numpy(synth.dense_uniform(s[1], (vocab, H), -0.08, 0.08)).cuda()
+        ln = torch.nn.LayerNorm(H).cuda()
+        with torch.no_grad():
+            ln.weight.copy_(torch.from_numpy(synth.dense_uniform(s[2], (H,), 0.5, 1.5)))
+            ln.bias.copy_(torch.from_numpy(synth.dense_uniform(s[3], (H,), -0.1, 0.1)))
+            h_ln = ln(hidden)
+        want_golden = g["emb"]
+    else:
+        gen = torch.Generator(device="cuda").manual_seed(B * 1000 + L)
+        h_ln = torch.randn((B, L, H), device="cuda", generator=gen)
+        W = torch.randn((vocab, H), device="cuda", generator=gen) * 0.1
+        want_golden = None
+    got = sp.head_project_pool(h_ln, W[shift:])
+    want = torch.nn.functional.elu(h_ln.double() @ W[shift:].double().t()).add(1).max(1)[0].float()
+    torch.testing.assert_close(got, want, rtol=2e-5, atol=2e-6)
+    if want_golden is not None:
+        np.testing.assert_allclose(got.cpu().numpy(), want_golden, rtol=1e-4, atol=1e-5)

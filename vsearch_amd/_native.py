@@ -53,6 +53,7 @@ _SIGNATURES = {
     "vs_embed_mask": ([_vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _int, _int, _int, _vp], _int),
     "vs_dense_to_csr": ([_vp, _i32, _i32, _i64, _vp, _vp, _vp, _i64, _int, _vp], _int),
     "vs_head_pool": ([_vp, _i32, _i32, _i32, _vp, _int, _vp], _int),
+    "vs_head_project_pool": ([_vp, _vp, _i32, _i32, _i32, _i32, _vp, _int, _vp], _int),
     "vs_elu1p": ([_vp, _i64, _vp, _int, _vp], _int),
     "vs_bot_build": ([_vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp], _int),
     "vs_profile_enable": ([_int], _int),

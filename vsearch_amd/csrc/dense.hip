@@ -59,7 +59,11 @@ constexpr int kDPitch = kDenseKC + 4;
 
 template <int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(256) void dense_scores_kernel(const float* __restrict__ Q, const float* __restrict__ P, int32_t B,
-                                                           int64_t N, int64_t n_begin, int32_t ldp, uint64_t* keys, float* scores) {
+                                                           int64_t N, int64_t n_begin, int32_t ldp, uint64_t* keys, float* scores,
+                                                           int32_t pool_L, uint32_t* pool_out) {
+    // pool_L > 0: encoder-head mode (vdr.py:72-75).  Q = LayerNorm'ed hidden states [B * pool_L, ldp]; the block covers rows
+    // of ONE sequence (blockIdx.y = sequence * l_tiles + l_tile); instead of scores it emits the column-wise max over the
+    // sequence positions, as order keys merged with atomicMax (rows past the sequence end repeat its last row).
     static_assert(WM * WN == 4 && WM * TM <= 4 && WN * TN <= 4, "4 waves per workgroup, tiles up to 128 x 128");
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int JA = BM / 32, JB = BN / 32;               // float4 staged per thread for each operand
@@ -69,13 +73,20 @@ __global__ __launch_bounds__(256) void dense_scores_kernel(const float* __restri
     const int wm = w / WN, wn = w % WN;
     const int h = lane >> 5, l31 = lane & 31;
     const int64_t n_blk = n_begin + (int64_t)blockIdx.x * BN;
-    const int b_blk = blockIdx.y * BM;
+    int b_blk = blockIdx.y * BM;
+    int row_hi = B - 1, seq = 0;
+    if (pool_L > 0) {
+        const int l_tiles = (pool_L + BM - 1) / BM;
+        seq = blockIdx.y / l_tiles;
+        row_hi = seq * pool_L + pool_L - 1;
+        b_blk = seq * pool_L + (blockIdx.y % l_tiles) * BM;
+    }
     // global -> register staging: thread t covers rows (t/8) + 32 j, 16-byte column group t%8
     const int lr = tid >> 3, lc = (tid & 7) * 4;
     const float4* q4[JA];
     const float4* p4[JB];
 #pragma unroll
-    for (int j = 0; j < JA; ++j) q4[j] = reinterpret_cast<const float4*>(Q + (size_t)min(b_blk + lr + 32 * j, B - 1) * ldp + lc);
+    for (int j = 0; j < JA; ++j) q4[j] = reinterpret_cast<const float4*>(Q + (size_t)min(b_blk + lr + 32 * j, row_hi) * ldp + lc);
 #pragma unroll
     for (int j = 0; j < JB; ++j) p4[j] = reinterpret_cast<const float4*>(P + (size_t)min(n_blk + lr + 32 * j, N - 1) * ldp + lc);
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -153,6 +164,22 @@ __global__ __launch_bounds__(256) void dense_scores_kernel(const float* __restri
     }
 #undef VS_DENSE_FETCH
 #undef VS_DENSE_STAGE
+    if (pool_L > 0) {
+        // column max over this wave's rows (all valid: clamped rows duplicate the last position), both half-waves, then
+        // one atomicMax per column into the [sequences, N] key buffer
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float m = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) m = fmaxf(m, tot[i][j][r]);
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            const int64_t n = n_blk + (wn * TN + j) * 32 + l31;
+            if (h == 0 && n < N) atomicMax(pool_out + (size_t)seq * N + n, flip_f32(m));
+        }
+        return;
+    }
     // C/D layout of a 32x32 tile: col = lane & 31 (doc), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (query)
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -180,13 +207,13 @@ int launch_dense_scores(const vs_index* idx, const float* dq, int B, int ldp, ui
     if (main_doc_tiles * 128 > N) main_doc_tiles = N / 128;
     if (main_doc_tiles > 0) {
         hipLaunchKernelGGL((dense_scores_kernel<2, 2, 2, 2>), dim3((unsigned)main_doc_tiles, (unsigned)q_tiles), dim3(256), 0, s, dq,
-                           idx->mat.as<float>(), B, N, (int64_t)0, ldp, keys, scores);
+                           idx->mat.as<float>(), B, N, (int64_t)0, ldp, keys, scores, 0, (uint32_t*)nullptr);
         VS_HIP(hipGetLastError());
     }
     const int64_t n_begin = main_doc_tiles * 128;
     if (n_begin < N) {
         hipLaunchKernelGGL((dense_scores_kernel<1, 4, 1, 1>), dim3((unsigned)ceil_div64(N - n_begin, 128), (unsigned)ceil_div(B, 32)), dim3(256), 0, s,
-                           dq, idx->mat.as<float>(), B, N, n_begin, ldp, keys, scores);
+                           dq, idx->mat.as<float>(), B, N, n_begin, ldp, keys, scores, 0, (uint32_t*)nullptr);
         VS_HIP(hipGetLastError());
     }
     return VS_OK;
@@ -455,6 +482,51 @@ extern "C" int vs_index_export_dense(const vs_index* idx, void* mat, int dtype, 
             VS_HIP(hipMemcpy((char*)mat + (size_t)r * ld * esz, stage.p, bytes, hipMemcpyDeviceToHost));
         }
     }
+    return VS_OK;
+}
+
+
+namespace {
+__global__ void pool_finish_kernel(const uint32_t* keys, int64_t n, float* out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float x = unflip_f32(keys[i]);
+        out[i] = x > 0.f ? x + 1.0f : expm1f(x) + 1.0f;           // elu1p after the max (monotone), vdr.py:73-75
+    }
+}
+}  // namespace
+
+// Encoder head, fused (vdr.py:72-75):  out[b, v] = elu1p( max_l  hidden[b, l, :] . W[v, :] ).
+// hidden: [B, L, H] fp32 device (already LayerNorm'ed), W: [V, H] fp32 device (caller passes word_emb[shift:]).
+// The [B, L, V] logits tensor of the reference (1.9 GB at B = 64, L = 256) is never materialised.
+extern "C" int vs_head_project_pool(const float* hidden, const float* W, int32_t B, int32_t L, int32_t H, int32_t V, float* out,
+                                    int device, void* stream) {
+    if (!hidden || !W || !out || B <= 0 || L <= 0 || H <= 0 || V <= 0) return fail(VS_EINVAL, "bad argument");
+    if (H % kDenseKC != 0) return fail(VS_EUNSUPPORTED, "hidden size %d is not a multiple of %d", H, kDenseKC);
+    if (!is_device_ptr(hidden) || !is_device_ptr(W) || !is_device_ptr(out)) return fail(VS_EINVAL, "vs_head_project_pool takes device pointers");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { (void)hipGetLastError(); return fail(VS_ENODEVICE, "no HIP device visible"); }
+    VS_HIP(hipSetDevice(device));
+    hipStream_t s = (hipStream_t)stream;
+    DevBuf keys;
+    VS_TRY(keys.alloc((size_t)B * V * 4));
+    VS_HIP(hipMemsetAsync(keys.p, 0, (size_t)B * V * 4, s));            // key 0 < key of any real number
+    {
+        ProfScope prof("head_project_pool", s);
+        if (L > 64) {
+            const int l_tiles = (L + 127) / 128;
+            hipLaunchKernelGGL((dense_scores_kernel<2, 2, 2, 2>), dim3((unsigned)ceil_div64(V, 128), (unsigned)(B * l_tiles)), dim3(256), 0, s, hidden, W,
+                               B * L, (int64_t)V, (int64_t)0, H, (uint64_t*)nullptr, (float*)nullptr, L, keys.as<uint32_t>());
+        } else {
+            const int l_tiles = (L + 31) / 32;
+            hipLaunchKernelGGL((dense_scores_kernel<1, 4, 1, 1>), dim3((unsigned)ceil_div64(V, 128), (unsigned)(B * l_tiles)), dim3(256), 0, s, hidden, W,
+                               B * L, (int64_t)V, (int64_t)0, H, (uint64_t*)nullptr, (float*)nullptr, L, keys.as<uint32_t>());
+        }
+    }
+    VS_HIP(hipGetLastError());
+    hipLaunchKernelGGL(pool_finish_kernel, dim3((unsigned)std::min<int64_t>(ceil_div64((int64_t)B * V, 256), 8192)), dim3(256), 0, s, keys.as<uint32_t>(),
+                       (int64_t)B * V, out);
+    VS_HIP(hipGetLastError());
+    VS_HIP(hipStreamSynchronize(s));                                     // `keys` is freed on return
     return VS_OK;
 }
 

@@ -70,10 +70,17 @@ class VDREncoder(PreTrainedModel):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
             raise NotImplementedError("vsearch_amd implements the inference path only (HIP head has no backward)")
         with torch.no_grad():
-            logits = self._vocab_logits(input_ids, token_type_ids, attention_mask)
-            if not logits.is_cuda:
+            out = self.bert_model(input_ids=input_ids, token_type_ids=token_type_ids, attention_mask=attention_mask)
+            hidden = self.ln(out.last_hidden_state)
+            if not hidden.is_cuda:
                 raise RuntimeError("VDREncoder runs on an MI355X: move the encoder with .to('cuda') (no CPU fallback)")
-            emb = sp.head_pool(logits)
+            w = self.bert_model.embeddings.word_embeddings.weight[self.config.shift_vocab_num:, :]
+            if hidden.shape[-1] % 32 == 0 and hidden.dtype == torch.float32 and hidden.shape[1] > 64:
+                # passage-shaped batches: fused projection + max-pool + elu1p, no [B, L, V] logits (1.9 GB at 64 x 256);
+                # short query batches are faster through the library GEMM + vs_head_pool
+                emb = sp.head_project_pool(hidden, w)
+            else:
+                emb = sp.head_pool(hidden @ w.t())
             return F.normalize(emb) if self.config.norm else emb
 
     def encode(self, texts: Union[List[str], str], max_len: int = None):

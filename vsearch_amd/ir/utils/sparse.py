@@ -102,6 +102,21 @@ def head_pool(logits: torch.Tensor):
     return out
 
 
+def head_project_pool(hidden_ln: torch.Tensor, weight: torch.Tensor):
+    """Fused encoder head (vdr.py:72-75): elu1p(max over positions of hidden_ln @ weight.T) without the [B, L, V] logits.
+    hidden_ln [B, L, H] and weight [V, H]: CUDA fp32, H % 32 == 0."""
+    assert hidden_ln.is_cuda and weight.is_cuda and hidden_ln.dim() == 3 and weight.dim() == 2
+    h = hidden_ln.detach().to(torch.float32).contiguous()
+    w = weight.detach().to(torch.float32).contiguous()
+    dev = _dev_of(h)
+    B, L, H = h.shape
+    V = w.shape[0]
+    out = torch.empty((B, V), dtype=torch.float32, device=h.device)
+    nat.check(nat.lib().vs_head_project_pool(C.c_void_p(h.data_ptr()), C.c_void_p(w.data_ptr()), B, L, H, V, C.c_void_p(out.data_ptr()),
+                                             dev, current_stream(dev)))
+    return out
+
+
 def dense_to_csr(x: torch.Tensor):
     """Tensor.to_sparse_csr() (retriever.py:304) for a CUDA fp32 [B, V] tensor -> (rowptr int64 [B+1],
     cols int32 [nnz], vals fp32 [nnz]) CUDA tensors."""
