@@ -388,3 +388,32 @@ def test_fused_head_project_pool(golden, B, L, H, vocab):
     torch.testing.assert_close(got, want, rtol=2e-5, atol=2e-6)
     if want_golden is not None:
         np.testing.assert_allclose(got.cpu().numpy(), want_golden, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("seed", range(5))
+def test_random_embed_mask_against_oracle(seed):
+    """Randomised mask stage (vdr.py:152-169): heavy ties (few distinct values), odd vocab sizes, every flag combination."""
+    rng = np.random.default_rng(seed)
+    vocab = int(rng.choice([1200, 4000, 30522]))
+    shift = int(rng.choice([0, 999]))
+    Vv = vocab - shift
+    B, L = int(rng.integers(1, 9)), int(rng.integers(1, 40))
+    ids = rng.integers(0, vocab, size=(B, L)).astype(np.int64)
+    emb = rng.integers(0, 12, size=(B, Vv)).astype(np.float32) / 4           # many exact ties at the k-th value
+    for topk in (0, 1, 17, Vv // 3, -1):
+        for lex in (False, True):
+            want = oracle.embed_mask(emb, ids, vocab, shift, topk=topk, activate_lexical=lex)
+            got = torch.from_numpy(emb).cuda()
+            sp.apply_embed_mask_(got, torch.from_numpy(ids), vocab, shift, topk, lex)
+            assert (got.cpu().numpy() == want).all(), (seed, topk, lex)
+    want = oracle.embed_mask(emb, ids, vocab, shift, bow=True)
+    got = torch.from_numpy(emb).cuda()
+    sp.apply_embed_mask_(got, torch.from_numpy(ids), vocab, shift, 0, True, bow=True)
+    assert (got.cpu().numpy() == want).all()
+    for norm in (False, True):
+        np.testing.assert_allclose(sp.build_bow_mask(torch.from_numpy(ids), vocab, shift, norm).numpy(), oracle.bow_mask(ids, vocab, shift, norm), rtol=1e-6)
+    k = int(rng.integers(0, Vv + 1))
+    assert (sp.build_topk_mask(torch.from_numpy(emb), k).numpy() == oracle.topk_mask(emb, k)).all()
+    rp, ci, va = sp.dense_to_csr(torch.from_numpy(emb).cuda())
+    ref = torch.from_numpy(emb).to_sparse_csr()
+    assert (rp.cpu() == ref.crow_indices()).all() and (ci.cpu() == ref.col_indices()).all() and (va.cpu() == ref.values()).all()
