@@ -366,3 +366,16 @@ def test_random_shapes_against_oracle(seed):
             idx.set_queries_per_pass(qt)
             ids, sc = idx.search(q, k)
             compare.check_topk_valid(allsc, ids, sc, exact=True, canonical=True)
+
+
+def test_dense_index_large_k_multipass():
+    """Dense index, k > 2048 (slices below an exclusive upper-bound key) and 4096 < N (radix-select path) with ties."""
+    rng = np.random.default_rng(5)
+    n, v = 9000, 96
+    mat = (rng.integers(0, 8, size=(n, v)).astype(np.float32)) / 4            # many tied scores
+    q = (rng.integers(0, 4, size=(3, v)).astype(np.float32)) / 2
+    idx = DeviceIndex.from_dense(mat)
+    want = q.astype(np.float64) @ mat.astype(np.float64).T
+    for k in (100, 2048, 2049, 5000, n):
+        ids, sc = idx.search(q, k)
+        compare.check_topk_valid(want.astype(np.float32), ids, sc, exact=True, canonical=True)

@@ -304,6 +304,7 @@ struct MergeArgs {
     int64_t out_ld;
     int32_t col0;
     uint64_t* upper_out;      // optional [B]: receives the k-th key (next pass's exclusive upper bound)
+    const uint64_t* upper_in; // optional [B]: only keys < upper_in[b] take part (passes after the first when k > 2048)
 };
 
 template <int UNUSED>
@@ -319,7 +320,11 @@ __global__ __launch_bounds__(kScanThreads) void merge_topk_kernel(MergeArgs a) {
         do {
             const int room = kWgCap - have;
             const int64_t take = min((int64_t)room, a.n_cand - consumed);
-            for (int i = tid; i < room; i += kScanThreads) buf[have + i] = i < take ? src[consumed + i] : 0ull;
+            for (int i = tid; i < room; i += kScanThreads) {
+                uint64_t key = i < take ? src[consumed + i] : 0ull;
+                if (a.upper_in && key >= a.upper_in[b]) key = 0ull;
+                buf[have + i] = key;
+            }
             consumed += take;
             wg_sort_desc<kScanThreads>(buf, kWgCap, tid);
             have = K;
@@ -348,6 +353,7 @@ __global__ __launch_bounds__(kScanThreads) void select_topk_kernel(MergeArgs a) 
     const int K = a.k;
     for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
         const uint64_t* src = a.cand + (size_t)b * a.n_cand;
+        const uint64_t upper = a.upper_in ? a.upper_in[b] : ~0ull;
         uint64_t prefix = 0;
         int pbits = 0, need = K, total_above = 0;
         for (;;) {
@@ -356,7 +362,8 @@ __global__ __launch_bounds__(kScanThreads) void select_topk_kernel(MergeArgs a) 
             for (int i = tid; i < bins; i += kScanThreads) hist[i] = 0;
             __syncthreads();
             for (int64_t i = tid; i < a.n_cand; i += kScanThreads) {
-                const uint64_t key = src[i];
+                uint64_t key = src[i];
+                if (key >= upper) key = 0ull;
                 if (pbits == 0 || (key >> (64 - pbits)) == prefix) atomicAdd(&hist[(int)((key >> (64 - pbits - width)) & (uint64_t)(bins - 1))], 1);
             }
             __syncthreads();
@@ -389,7 +396,8 @@ __global__ __launch_bounds__(kScanThreads) void select_topk_kernel(MergeArgs a) 
         for (int i = tid; i < kWgCap; i += kScanThreads) buf[i] = 0ull;
         __syncthreads();
         for (int64_t i = tid; i < a.n_cand; i += kScanThreads) {
-            const uint64_t key = src[i];
+            uint64_t key = src[i];
+            if (key >= upper) key = 0ull;
             if ((pbits >= 64 ? key : (key >> (64 - pbits))) >= prefix) {
                 const int pos = atomicAdd(&s_cnt, 1);
                 if (pos < kWgCap) buf[pos] = key;

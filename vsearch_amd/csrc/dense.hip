@@ -532,7 +532,6 @@ extern "C" int vs_head_project_pool(const float* hidden, const float* W, int32_t
 
 int vs_dense_search(vs_index* idx, const void* q, int q_dtype, int64_t ldq, int32_t B, int32_t k, int64_t id_offset,
                     int64_t* out_ids, float* out_scores, hipStream_t s) {
-    if (k > kMaxKShared) return fail(VS_EUNSUPPORTED, "dense search supports k <= %d", kMaxKShared);
     const int ldp = dense_ldp(idx->n_cols);
     const float* dq = nullptr;
     VS_TRY(prep_dense_queries(idx, q, q_dtype, ldq, B, ldp, s, &dq));
@@ -549,24 +548,29 @@ int vs_dense_search(vs_index* idx, const void* q, int q_dtype, int64_t ldq, int3
     const int64_t N = idx->n_rows;
     const int bs_max = (int)std::max<int64_t>(1, std::min<int64_t>(B, ((int64_t)1 << 30) / (N * 8)));
     VS_TRY(idx->ws_cand.reserve((size_t)bs_max * N * 8));
+    const int passes = ceil_div(k, kMaxKShared);               // k > 2048: select in slices below an exclusive upper-bound key
+    DevBuf upper;
+    if (passes > 1) VS_TRY(upper.alloc((size_t)bs_max * 8));
     for (int b0 = 0; b0 < B; b0 += bs_max) {
         const int bs = std::min(bs_max, B - b0);
         {
             ProfScope prof("dense_scores", s);
             VS_TRY(launch_dense_scores(idx, dq + (size_t)b0 * ldp, bs, ldp, idx->ws_cand.as<uint64_t>(), nullptr, s));
         }
-        VS_HIP(hipGetLastError());
-        MergeArgs m{};
-        m.cand = idx->ws_cand.as<uint64_t>();
-        m.n_cand = N;
-        m.B = bs;
-        m.k = k;
-        m.id_offset = id_offset;
-        m.out_ids = d_ids + (size_t)b0 * k;
-        m.out_scores = d_scores + (size_t)b0 * k;
-        m.out_ld = k;
-        m.col0 = 0;
-        {
+        for (int pass = 0; pass < passes; ++pass) {
+            const int col0 = pass * kMaxKShared;
+            MergeArgs m{};
+            m.cand = idx->ws_cand.as<uint64_t>();
+            m.n_cand = N;
+            m.B = bs;
+            m.k = std::min(k - col0, kMaxKShared);
+            m.id_offset = id_offset;
+            m.out_ids = d_ids + (size_t)b0 * k;
+            m.out_scores = d_scores + (size_t)b0 * k;
+            m.out_ld = k;
+            m.col0 = col0;
+            m.upper_out = passes > 1 ? upper.as<uint64_t>() : nullptr;
+            m.upper_in = pass > 0 ? upper.as<uint64_t>() : nullptr;
             ProfScope prof("merge_topk", s);
             if (N > 2 * kWgCap) hipLaunchKernelGGL(select_topk_kernel<0>, dim3(std::min(bs, idx->cu_count * 2)), dim3(kScanThreads), 0, s, m);
             else hipLaunchKernelGGL(merge_topk_kernel<0>, dim3(std::min(bs, idx->cu_count * 2)), dim3(kScanThreads), 0, s, m);
@@ -578,6 +582,7 @@ int vs_dense_search(vs_index* idx, const void* q, int q_dtype, int64_t ldq, int3
         VS_HIP(hipMemcpyAsync(out_scores, d_scores, (size_t)B * k * 4, hipMemcpyDeviceToHost, s));
         VS_HIP(hipStreamSynchronize(s));
     }
+    if (passes > 1) VS_HIP(hipStreamSynchronize(s));            // `upper` is freed on return
     return VS_OK;
 }
 
