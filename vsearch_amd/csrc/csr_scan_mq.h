@@ -81,7 +81,8 @@ __global__ __launch_bounds__(kScanThreads) void csr_scan_topk_mq(MqArgs a) {
     constexpr int S = G >= 32 ? 4 : (G >= 16 ? 2 : 1);                          // accumulator copies per row
     double* acc = reinterpret_cast<double*>(sortbuf + kMqCap);                  // [RPI][S][QT]
     unsigned long long* tau = reinterpret_cast<unsigned long long*>(acc + RPI * S * QT);   // [QT]
-    int* scratch = reinterpret_cast<int*>(tau + QT);                            // [64]
+    int* scratch = reinterpret_cast<int*>(tau + QT);                            // [48]
+    unsigned int* ccnt = reinterpret_cast<unsigned int*>(scratch + 48);         // [QT] candidate counts (keys live in global memory)
     float* qv = reinterpret_cast<float*>(scratch + 64);                         // [vals_cap]
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -89,7 +90,6 @@ __global__ __launch_bounds__(kScanThreads) void csr_scan_topk_mq(MqArgs a) {
     const int slot = w * RPW + g;
     const int K = a.k;
     uint64_t* my_gcand = a.gcand + (size_t)blockIdx.x * QT * kMqCap;
-    uint32_t* my_gcnt = a.gcnt + (size_t)blockIdx.x * QT;
     const int seg = (a.n_cols + 1 + kScanThreads - 1) / kScanThreads;
     const int64_t items = (int64_t)a.n_tiles * a.nchunk;
 
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(kScanThreads) void csr_scan_topk_mq(MqArgs a) {
         // ---- build the tile tables ----
         for (int i = tid; i <= a.n_cols; i += kScanThreads) tab[i] = 0;
         for (int i = tid; i < RPI * S * QT; i += kScanThreads) acc[i] = 0.0;
-        if (tid < QT) { tau[tid] = 0ull; my_gcnt[tid] = 0u; }
+        if (tid < QT) { tau[tid] = 0ull; ccnt[tid] = 0u; }
         __syncthreads();
         const int64_t e0 = a.qptr[q0], e1 = a.qptr[q0 + nq];
         for (int64_t e = e0 + tid; e < e1; e += kScanThreads) {
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(kScanThreads) void csr_scan_topk_mq(MqArgs a) {
                     }
                     const uint64_t key = make_key((float)sum, (uint32_t)row);
                     if (key > tau[lg]) {
-                        const uint32_t pos = atomicAdd(&my_gcnt[lg], 1u);
+                        const uint32_t pos = atomicAdd(&ccnt[lg], 1u);
                         my_gcand[(size_t)lg * kMqCap + pos] = key;
                     }
                 }
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(kScanThreads) void csr_scan_topk_mq(MqArgs a) {
             __syncthreads();
             const bool last = it1 >= iters;
             for (int qs = 0; qs < nq; ++qs) {
-                const uint32_t cnt = __hip_atomic_load(&my_gcnt[qs], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t cnt = ccnt[qs];
                 if (last || cnt > (uint32_t)(kMqCap - kMqSuperRows)) {
                     for (int i = tid; i < kMqCap; i += kScanThreads) sortbuf[i] = (uint32_t)i < cnt ? my_gcand[(size_t)qs * kMqCap + i] : 0ull;
                     wg_sort_desc<kScanThreads>(sortbuf, kMqCap, tid);
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(kScanThreads) void csr_scan_topk_mq(MqArgs a) {
                         for (int i = tid; i < K; i += kScanThreads) my_gcand[(size_t)qs * kMqCap + i] = sortbuf[i];
                         if (tid == 0) {
                             tau[qs] = sortbuf[K - 1];
-                            __hip_atomic_store(&my_gcnt[qs], (uint32_t)K, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            ccnt[qs] = (uint32_t)K;
                         }
                     }
                     __syncthreads();
