@@ -97,6 +97,12 @@ VS_API int vs_index_create_reserved(int64_t rows_cap, int64_t packets_cap, int32
 VS_API int vs_index_append_csr(vs_index* index, const void* rowptr, int rowptr_dtype, const void* colidx, int col_dtype,
                                const void* values, int val_dtype, int64_t n_rows);
 
+/* Native shard files (".vsx"): the device format written / read verbatim.  SparseIndex.init_index re-parses,
+ * slices and vstacks scipy .npz shards on every load (index.py:172-176); a .vsx file is a header + the three
+ * device arrays, so a 97 GB index loads at storage speed.                                                */
+VS_API int vs_index_save_native(const vs_index* index, const char* path);
+VS_API int vs_index_load_native(const char* path, int device, vs_index** out);
+
 /* Dense index (Index.vector = [n_rows, n_cols], index.py:25-44, retriever.py:292-297). */
 VS_API int vs_index_create_dense(const void* mat, int dtype, int store_dtype, int64_t n_rows, int32_t n_cols,
                                  int64_t ld, int device, vs_index** out);

@@ -417,3 +417,29 @@ def test_random_embed_mask_against_oracle(seed):
     rp, ci, va = sp.dense_to_csr(torch.from_numpy(emb).cuda())
     ref = torch.from_numpy(emb).to_sparse_csr()
     assert (rp.cpu() == ref.crow_indices()).all() and (ci.cpu() == ref.col_indices()).all() and (va.cpu() == ref.values()).all()
+
+
+def test_native_shard_file_roundtrip(tmp_path):
+    """.vsx = the device format verbatim: save -> load gives the same index (values, search results) without scipy."""
+    n = 700
+    ip, ix, d = oracle.synth_csr(17, 0, n, V, 300)
+    idx = SparseIndex(device="cuda")
+    idx.vector = csr_tensor(ip, ix, d)
+    idx.move_to_device("cuda")
+    idx.save(str(tmp_path / "a.vsx"))
+    back = SparseIndex(str(tmp_path / "a.vsx"), None, device="cuda")
+    v = back.vector
+    assert (v.crow_indices().cpu().numpy() == ip).all() and (v.col_indices().cpu().numpy() == ix).all() and (v.values().cpu().numpy() == d).all()
+    q = torch.from_numpy(oracle.synth_queries(1, 4))
+    a, b = idx.search(q, 20), back.search(q, 20)
+    assert (a.ids == b.ids).all() and (a.scores == b.scores).all()
+    bot = BoTIndex(device="cuda")
+    ipb, ixb, _ = oracle.synth_csr(3, 0, 500, V, 86, synth.KIND_BOT)
+    bot.vector = torch.sparse_csr_tensor(torch.from_numpy(ipb), torch.from_numpy(ixb.astype(np.int64)), torch.ones(len(ixb), dtype=torch.float16), size=(500, V))
+    bot.move_to_device("cuda")
+    bot.save(str(tmp_path / "b.vsx"))
+    bb = BoTIndex(str(tmp_path / "b.vsx"), None, device="cuda")
+    assert (bb.search(q, 10).ids == bot.search(q, 10).ids).all() and bb.vector.values().dtype == torch.float16
+    (tmp_path / "bad.vsx").write_bytes(b"not a shard file")
+    with pytest.raises(ValueError, match="native shard"):
+        SparseIndex(str(tmp_path / "bad.vsx"), None, device="cuda")

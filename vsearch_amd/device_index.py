@@ -97,6 +97,17 @@ class DeviceIndex:
         nat.check(nat.lib().vs_index_append_csr(self._h, p_rp, dt_rp, p_ci, dt_ci, p_v, dt_v if data is not None else nat.VS_F32,
                                                 int(indptr.shape[0]) - 1))
 
+    def save_native(self, path: str):
+        """Write the device format verbatim (.vsx shard file)."""
+        nat.check(nat.lib().vs_index_save_native(self._h, str(path).encode()))
+
+    @classmethod
+    def load_native(cls, path: str, device=0):
+        nat.require_device()
+        h = C.c_void_p()
+        nat.check(nat.lib().vs_index_load_native(str(path).encode(), int(device), C.byref(h)))
+        return cls(h)
+
     @classmethod
     def from_dense(cls, mat, store_dtype=None, device=0, max_density=0.0):
         """Dense [N, V] index. max_density > 0: store as CSR packets when the matrix is that sparse

@@ -276,6 +276,14 @@ class SparseIndex(Index):
         if not files:
             raise FileNotFoundError(f"no index file matches {index_file!r}")
         logger.info("***** Loading %s Index from %d files *****", self.index_type.value, len(files))
+        if len(files) == 1 and files[0].endswith(".vsx"):           # native shard file: the device format verbatim
+            self._drop_device()
+            self._vector = None
+            self._dev = DeviceIndex.load_native(files[0], device=_gpu_ordinal(self.device))
+            info = self._dev.info()
+            self._dtype = torch.float32 if info.store_dtype == nat.VS_F32 else torch.float16
+            self._shape = (info.n_rows, info.n_cols)
+            return
         # pass 1: sizes only (row pointers are read lazily from the .npz; the column shift can only shorten rows,
         # so the packet count before the shift is an upper bound for the reservation)
         rows_total, packets_cap, n_cols = 0, 0, None
@@ -317,6 +325,10 @@ class SparseIndex(Index):
     def save(self, path):
         """CSR index -> scipy ``.npz`` (keys indices, indptr, data, shape, format; int64 indices)."""
         from scipy.sparse import csr_array, save_npz
+        if str(path).endswith(".vsx"):                              # native shard file (loads without a CSR round trip)
+            self._device_index().save_native(path)
+            logger.info("Index successfully saved to %s", path)
+            return
         try:
             # values go to disk as float32: scipy.sparse has no float16, and the loader re-applies fp16 (fp16=True)
             if self._dev is not None:
