@@ -379,3 +379,47 @@ def test_dense_index_large_k_multipass():
     for k in (100, 2048, 2049, 5000, n):
         ids, sc = idx.search(q, k)
         compare.check_topk_valid(want.astype(np.float32), ids, sc, exact=True, canonical=True)
+
+
+def _zipf_csr(rng, n, nnz, s, perm, binary=False, dyadic=False):
+    """Rows with Zipf(s) column popularity, distinct sorted columns (numpy; the popular columns end up in most rows)."""
+    w = 1.0 / np.arange(1, V + 1) ** s
+    keys = rng.random((n, V)) ** (1.0 / w)                       # Efraimidis-Spirakis weighted sampling without replacement
+    cols = np.sort(perm[np.argpartition(-keys, nnz, axis=1)[:, :nnz]], axis=1).astype(np.int32)
+    ip = np.arange(0, (n + 1) * nnz, nnz, dtype=np.int64)
+    if dyadic:
+        vals = rng.integers(1, 256, size=cols.shape).astype(np.float32) / 64
+    else:
+        vals = (0.01 + 3 * rng.random(cols.shape)).astype(np.float32)
+    return ip, cols.reshape(-1), (None if binary else vals.reshape(-1))
+
+
+@pytest.mark.parametrize("binary", [False, True], ids=["fp32", "binary-dyadic"])
+@pytest.mark.parametrize("s", [0.75, 1.2])
+def test_skewed_column_popularity_shared_column_variant(monkeypatch, s, binary):
+    """Head columns shared by most queries AND most documents (SURVEY §8(d) 'Zipf column popularity' run): the
+    multi-query pass switches to its shared-column variant; both variants must agree with the oracle."""
+    rng = np.random.default_rng(5)
+    perm = rng.permutation(V)
+    n, B = 1500, 21
+    ip, ix, d = _zipf_csr(rng, n, 86 if binary else 300, s, perm, binary=binary)
+    qip, qix, qd = _zipf_csr(rng, B, 400, s, perm, dyadic=binary)
+    q = np.zeros((B, V), dtype=np.float32)
+    q[np.repeat(np.arange(B), 400), qix] = qd
+    idx = DeviceIndex.from_csr(ip, ix, d, V)
+    o_ids, o_sc, allsc = oracle.csr_search(ip, ix, d, V, q, 50, acc64=True, return_all=True)
+    res = {}
+    for forced in ("0", "1", None):
+        if forced is None:
+            monkeypatch.delenv("VS_MQ_SHARED", raising=False)
+        else:
+            monkeypatch.setenv("VS_MQ_SHARED", forced)
+        ids, sc = idx.search(q, 50)
+        assert idx.info().queries_per_pass == 8
+        res[forced] = (ids, sc)
+        if binary:                                                # integer path: bit-exact scores, canonical ids
+            assert (sc == o_sc).all() and (ids == o_ids).all()
+        else:
+            compare.check_topk_valid(allsc, ids, sc, rtol=RTOL)
+            compare.compare_topk(o_ids, o_sc, ids, sc, rtol=RTOL)
+    np.testing.assert_allclose(res["0"][1], res["1"][1], rtol=1e-6)

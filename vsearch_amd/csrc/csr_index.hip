@@ -631,28 +631,32 @@ int prep_queries(vs_index* idx, const void* q, int q_dtype, int64_t ldq, int B, 
 
 namespace {
 
-template <int G, int VM, int U>
+template <int G, int VM, int U, int DN>
 int launch_mq_gu(const MqArgs& a, int grid, size_t lds, hipStream_t s) {
-    VS_HIP(hipFuncSetAttribute((const void*)csr_scan_topk_mq<G, VM, kQT, U>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((csr_scan_topk_mq<G, VM, kQT, U>), dim3(grid), dim3(kScanThreads), lds, s, a);
+    VS_HIP(hipFuncSetAttribute((const void*)csr_scan_topk_mq<G, VM, kQT, U, DN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((csr_scan_topk_mq<G, VM, kQT, U, DN>), dim3(grid), dim3(kScanThreads), lds, s, a);
     VS_HIP(hipGetLastError());
     return VS_OK;
 }
 template <int G, int VM>
-int launch_mq_g(int u, const MqArgs& a, int grid, size_t lds, hipStream_t s) {
-    if (u <= 1) return launch_mq_gu<G, VM, 1>(a, grid, lds, s);
-    if (u == 2) return launch_mq_gu<G, VM, 2>(a, grid, lds, s);
-    return launch_mq_gu<G, VM, 3>(a, grid, lds, s);
+int launch_mq_g(int u, bool shared_cols, const MqArgs& a, int grid, size_t lds, hipStream_t s) {
+    if (shared_cols)          // the shared-column variant keeps 16 more registers live: at most 2 packets in flight
+        return u <= 1 ? launch_mq_gu<G, VM, 1, 1>(a, grid, lds, s) : launch_mq_gu<G, VM, 2, 1>(a, grid, lds, s);
+    if (u <= 1) return launch_mq_gu<G, VM, 1, 0>(a, grid, lds, s);
+    if (u == 2) return launch_mq_gu<G, VM, 2, 0>(a, grid, lds, s);
+    return launch_mq_gu<G, VM, 3, 0>(a, grid, lds, s);
 }
 template <int VM>
-int launch_mq_vm(int g, int u, const MqArgs& a, int grid, size_t lds, hipStream_t s) {
+int launch_mq_vm(int g, int u, bool shared_cols, const MqArgs& a, int grid, size_t lds, hipStream_t s) {
     switch (g) {
-        case 8: return launch_mq_g<8, VM>(u, a, grid, lds, s);
-        case 16: return launch_mq_g<16, VM>(u, a, grid, lds, s);
-        case 32: return launch_mq_g<32, VM>(u, a, grid, lds, s);
-        default: return launch_mq_g<64, VM>(u, a, grid, lds, s);
+        case 8: return launch_mq_g<8, VM>(u, shared_cols, a, grid, lds, s);
+        case 16: return launch_mq_g<16, VM>(u, shared_cols, a, grid, lds, s);
+        case 32: return launch_mq_g<32, VM>(u, shared_cols, a, grid, lds, s);
+        default: return launch_mq_g<64, VM>(u, shared_cols, a, grid, lds, s);
     }
 }
+
+constexpr double kMqSharedOverlap = 40.0;   // columns shared by two queries above which the shared-column variant runs
 
 // LDS entries left for the tile's weights once the fixed tables are placed
 inline int mq_lanes(const vs_index* idx) { return std::max(idx->lanes_per_row, 8); }
@@ -677,17 +681,20 @@ int mq_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64_t id_o
     const int V = idx->n_cols;
     // 1. sparsify the batch: counts -> (qptr, tiles, plan) -> (qcols, qvals)
     const size_t off_counts = 0, off_qptr = off_counts + (size_t)B * 8, off_plan = off_qptr + (size_t)(B + 1) * 8,
-                 off_tiles = off_plan + 64;
-    VS_TRY(idx->ws_mq_meta.reserve(off_tiles + (size_t)B * sizeof(int2)));
+                 off_tiles = off_plan + 64, off_freq = off_tiles + (((size_t)B * sizeof(int2) + 15) & ~(size_t)15);
+    VS_TRY(idx->ws_mq_meta.reserve(off_freq + (size_t)(V + 1) * 4));
     char* meta = idx->ws_mq_meta.as<char>();
     int64_t* counts = (int64_t*)(meta + off_counts);
     int64_t* qptr = (int64_t*)(meta + off_qptr);
     int64_t* dplan = (int64_t*)(meta + off_plan);
     int2* tiles = (int2*)(meta + off_tiles);
+    uint32_t* colfreq = (uint32_t*)(meta + off_freq);
+    VS_HIP(hipMemsetAsync(colfreq, 0, (size_t)(V + 1) * 4, s));
     hipLaunchKernelGGL(count_nz_kernel<0>, dim3(std::min(B, 2048)), dim3(kSpThreads), 0, s, dq, (int64_t)V, B, V, counts);
-    hipLaunchKernelGGL(mq_plan_kernel<0>, dim3(1), dim3(64), 0, s, counts, B, kQT, vals_cap, qptr, tiles, dplan);
+    hipLaunchKernelGGL(mq_colfreq_kernel<0>, dim3(std::min(B, 2048)), dim3(kSpThreads), 0, s, dq, (int64_t)V, B, V, colfreq);
+    hipLaunchKernelGGL(mq_plan_kernel<0>, dim3(1), dim3(64), 0, s, counts, B, kQT, vals_cap, qptr, tiles, dplan, colfreq, V);
     VS_HIP(hipGetLastError());
-    int64_t hplan[3] = {0, 0, 0};
+    int64_t hplan[4] = {0, 0, 0, 0};
     VS_HIP(hipMemcpyAsync(hplan, dplan, sizeof(hplan), hipMemcpyDeviceToHost, s));
     VS_HIP(hipStreamSynchronize(s));
     if (hplan[1] > vals_cap) return VS_OK;                       // some query is too dense for the tile tables
@@ -744,9 +751,13 @@ int mq_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64_t id_o
         // packets per lane per trip: enough to cover an average row in one trip, at most 3
         const double ppr = idx->n_rows > 0 ? (double)idx->n_packets / (double)idx->n_rows : 1.0;
         const int u = std::max(1, std::min(3, (int)((ppr + mq_lanes(idx) - 1) / mq_lanes(idx))));
-        int rc = idx->store_dtype == VS_F32 ? launch_mq_vm<VM_F32>(mq_lanes(idx), u, a, grid, lds, s)
-               : idx->store_dtype == VS_F16 ? launch_mq_vm<VM_F16>(mq_lanes(idx), u, a, grid, lds, s)
-                                            : launch_mq_vm<VM_BIN>(mq_lanes(idx), u, a, grid, lds, s);
+        // expected number of columns two queries of the batch share; uniform 776-nnz queries: ~20
+        const double overlap = B > 1 ? (double)hplan[3] / ((double)B * (double)(B - 1)) : 0.0;
+        bool shared_cols = overlap > kMqSharedOverlap;
+        if (const char* e = getenv("VS_MQ_SHARED")) shared_cols = atoi(e) != 0;
+        int rc = idx->store_dtype == VS_F32 ? launch_mq_vm<VM_F32>(mq_lanes(idx), u, shared_cols, a, grid, lds, s)
+               : idx->store_dtype == VS_F16 ? launch_mq_vm<VM_F16>(mq_lanes(idx), u, shared_cols, a, grid, lds, s)
+                                            : launch_mq_vm<VM_BIN>(mq_lanes(idx), u, shared_cols, a, grid, lds, s);
         VS_TRY(rc);
     }
     // 3. merge chunks

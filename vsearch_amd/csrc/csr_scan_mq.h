@@ -68,7 +68,12 @@ __host__ __device__ inline size_t mq_fixed_lds_bytes(int32_t n_cols, int rows_in
     return tab + (size_t)kMqCap * 8 + (size_t)rows_in_flight * QT * 8 + (size_t)QT * 8 + 64 * 4;
 }
 
-template <int G, int VM, int QT, int U>
+// DN = 1: "shared-column" variant for batches whose queries overlap heavily (skewed column popularity: the
+// head columns are non-zero in most queries AND most documents).  Columns used by >= T of the tile's 8
+// queries (T as low as the LDS slack allows, >= 3) are stored as zero-padded 8-float rows; a hit on such a
+// column costs two ds_read_b128 + 8 multiply-adds into per-lane fp64 registers (flushed once per row)
+// instead of up to 8 trips through the one-hit-at-a-time remainder loop.
+template <int G, int VM, int QT, int U, int DN>
 __global__ __launch_bounds__(kScanThreads) void csr_scan_topk_mq(MqArgs a) {
     static_assert(QT == 8 && G >= 8, "the packed hit word assumes 8 query slots per tile; lanes 0..7 of a row group finish them");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -111,7 +116,7 @@ __global__ __launch_bounds__(kScanThreads) void csr_scan_topk_mq(MqArgs a) {
             atomicOr(&tab[a.qcols[e]], 1u << qs);
         }
         __syncthreads();
-        {   // offsets: exclusive scan of popc(mask) in column order (contiguous segment per thread)
+        if constexpr (DN == 0) {   // offsets: exclusive scan of popc(mask) in column order (contiguous segment per thread)
             const int i0 = tid * seg, i1 = min(a.n_cols + 1, i0 + seg);
             int mine = 0;
             for (int i = i0; i < i1; ++i) mine += __popc(tab[i]);
@@ -121,13 +126,67 @@ __global__ __launch_bounds__(kScanThreads) void csr_scan_topk_mq(MqArgs a) {
                 tab[i] = m | ((uint32_t)(off * 4) << QT);        // byte offset into qv
                 off += __popc(m);
             }
-        }
-        __syncthreads();
-        for (int64_t e = e0 + tid; e < e1; e += kScanThreads) {
-            int qs = 0;
-            while (e >= a.qptr[q0 + qs + 1]) ++qs;
-            const uint32_t t = tab[a.qcols[e]];
-            qv[(t >> (QT + 2)) + __popc(t & ((1u << qs) - 1u))] = a.qvals[e];
+            __syncthreads();
+            for (int64_t e = e0 + tid; e < e1; e += kScanThreads) {
+                int qs = 0;
+                while (e >= a.qptr[q0 + qs + 1]) ++qs;
+                const uint32_t t = tab[a.qcols[e]];
+                qv[(t >> (QT + 2)) + __popc(t & ((1u << qs) - 1u))] = a.qvals[e];
+            }
+        } else {
+            // shared columns (popc >= T) first, as 32-byte zero-padded rows; tab = 0x100 | byte offset << 8 (mask byte
+            // 0: the one-hit paths never see them; bit 8 is free because offsets are multiples of 4); the rest packed
+            int* hist = scratch + 56;                                  // [6]: columns with popc 3..8
+            if (tid < 6) hist[tid] = 0;
+            __syncthreads();
+            const int i0 = tid * seg, i1 = min(a.n_cols + 1, i0 + seg);
+            for (int i = i0; i < i1; ++i) {
+                const int pc = __popc(tab[i]);
+                if (pc >= 3) atomicAdd(&hist[pc - 3], 1);
+            }
+            __syncthreads();
+            int T = 9;
+            {
+                const int slack = a.vals_cap - (int)(e1 - e0);
+                int extra = 0;
+                for (int pc = 8; pc >= 3; --pc) {
+                    extra += hist[pc - 3] * (8 - pc);
+                    if (extra > slack) break;
+                    T = pc;
+                }
+            }
+            int mine = 0;
+            for (int i = i0; i < i1; ++i) {
+                const int pc = __popc(tab[i]);
+                mine += pc >= T ? (1 << 16) : pc;
+            }
+            int total = 0;
+            const int off = block_excl_scan(mine, scratch, tid, &total);
+            const int n_shared = total >> 16;
+            int off_d = off >> 16, off_p = (off & 0xFFFF) + 8 * n_shared;
+            for (int i = i0; i < i1; ++i) {
+                const uint32_t m = tab[i];
+                const int pc = __popc(m);
+                if (pc >= T) {
+                    tab[i] = m | 0x100u | ((uint32_t)(off_d * 32) << QT);       // mask kept for the fill below
+                    ++off_d;
+                } else {
+                    tab[i] = m | ((uint32_t)(off_p * 4) << QT);
+                    off_p += pc;
+                }
+            }
+            for (int i = tid; i < 8 * n_shared; i += kScanThreads) qv[i] = 0.f;
+            __syncthreads();
+            for (int64_t e = e0 + tid; e < e1; e += kScanThreads) {
+                int qs = 0;
+                while (e >= a.qptr[q0 + qs + 1]) ++qs;
+                const uint32_t t = tab[a.qcols[e]];
+                if (t & 0x100u) qv[((t >> QT) - 1u) / 4 + qs] = a.qvals[e];
+                else qv[(t >> (QT + 2)) + __popc(t & ((1u << qs) - 1u))] = a.qvals[e];
+            }
+            __syncthreads();
+            for (int i = i0; i < i1; ++i)
+                if (tab[i] & 0x100u) tab[i] &= ~0xFFu;                          // hide shared columns from the one-hit paths
         }
         __syncthreads();
 
@@ -137,6 +196,8 @@ __global__ __launch_bounds__(kScanThreads) void csr_scan_topk_mq(MqArgs a) {
         // are otherwise a chain of dependent loads: pointer -> packets -> table)
         uint32_t np0 = 0, np1 = 0;
         if (r0 + slot < r1) { np0 = a.pk_ptr[r0 + slot]; np1 = a.pk_ptr[r0 + slot + 1]; }
+        double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0, d4 = 0.0, d5 = 0.0, d6 = 0.0, d7 = 0.0;   // DN: per-lane sums over shared columns
+        bool shared_seen = false;                                                                  // wave-uniform
         for (int64_t it0 = 0; it0 < iters || it0 == 0; it0 += SB) {
             const int64_t it1 = min(iters, it0 + SB);
             for (int64_t it = it0; it < it1; ++it) {
@@ -185,6 +246,25 @@ __global__ __launch_bounds__(kScanThreads) void csr_scan_topk_mq(MqArgs a) {
                             uint32_t t[8];
 #pragma unroll
                             for (int i = 0; i < 4; ++i) { t[2 * i] = tab[cwv[i] & 0xFFFF]; t[2 * i + 1] = tab[cwv[i] >> 16]; }
+                            if constexpr (DN) {
+                                const uint32_t anyd = (t[0] | t[1] | t[2] | t[3] | t[4] | t[5] | t[6] | t[7]) & 0x100u;
+                                if (__builtin_amdgcn_ballot_w64(anyd != 0)) {
+                                    shared_seen = true;
+                                    uint32_t dm = 0;
+#pragma unroll
+                                    for (int i = 0; i < 8; ++i) dm |= ((t[i] >> 8) & 1u) << i;
+                                    while (dm) {
+                                        const int i = __ffs(dm) - 1;
+                                        dm &= dm - 1;
+                                        const uint32_t ts = sel8(t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], i);
+                                        const float vs_ = sel8(vu[u][0], vu[u][1], vu[u][2], vu[u][3], vu[u][4], vu[u][5], vu[u][6], vu[u][7], i);
+                                        const float4* wp = reinterpret_cast<const float4*>(qvb + ((ts >> QT) - 1u));
+                                        const float4 w0 = wp[0], w1 = wp[1];
+                                        d0 += (double)(vs_ * w0.x); d1 += (double)(vs_ * w0.y); d2 += (double)(vs_ * w0.z); d3 += (double)(vs_ * w0.w);
+                                        d4 += (double)(vs_ * w1.x); d5 += (double)(vs_ * w1.y); d6 += (double)(vs_ * w1.z); d7 += (double)(vs_ * w1.w);
+                                    }
+                                }
+                            }
                             // first hits, two packet positions (i, i+4) per LDS round trip: a position hits with
                             // p ~ 0.2, so "exactly one of the pair" is the common case and is served by ONE weight
                             // fetch + ONE ds_add_f64 instead of two mostly-empty ones; a pair whose both positions
@@ -229,6 +309,19 @@ __global__ __launch_bounds__(kScanThreads) void csr_scan_topk_mq(MqArgs a) {
                         }
                     }
                 }
+                if constexpr (DN) {
+                    if (shared_seen) {
+                        shared_seen = false;
+                        if (d0 != 0.0) { atomicAdd(&myacc[0], d0); d0 = 0.0; }
+                        if (d1 != 0.0) { atomicAdd(&myacc[1], d1); d1 = 0.0; }
+                        if (d2 != 0.0) { atomicAdd(&myacc[2], d2); d2 = 0.0; }
+                        if (d3 != 0.0) { atomicAdd(&myacc[3], d3); d3 = 0.0; }
+                        if (d4 != 0.0) { atomicAdd(&myacc[4], d4); d4 = 0.0; }
+                        if (d5 != 0.0) { atomicAdd(&myacc[5], d5); d5 = 0.0; }
+                        if (d6 != 0.0) { atomicAdd(&myacc[6], d6); d6 = 0.0; }
+                        if (d7 != 0.0) { atomicAdd(&myacc[7], d7); d7 = 0.0; }
+                    }
+                }
                 __builtin_amdgcn_wave_barrier();     // this wave's adds precede its reads (LDS executes a wave's ops in order)
                 if (row < r1 && lg < nq) {
                     double sum = 0.0;
@@ -271,11 +364,30 @@ __global__ __launch_bounds__(kScanThreads) void csr_scan_topk_mq(MqArgs a) {
     }
 }
 
+// column use counts of a dense [B, V] query batch (one workgroup per query)
+template <int UNUSED>
+__global__ __launch_bounds__(kSpThreads) void mq_colfreq_kernel(const float* x, int64_t ld, int32_t B, int32_t V, uint32_t* colfreq) {
+    for (int b = blockIdx.x; b < B; b += gridDim.x)
+        for (int i = threadIdx.x; i < V; i += kSpThreads)
+            if (x[(size_t)b * ld + i] != 0.f) atomicAdd(&colfreq[i], 1u);
+}
+
 // Single-thread planner: row pointers of the sparse query batch + greedy tiling (<= QT queries and
 // <= vals_cap non-zeros per tile).  plan[0] = n_tiles, plan[1] = max nnz of one query, plan[2] = total nnz.
+// plan[3] = sum over columns of f (f - 1), f = number of queries of the batch using the column: divided by
+// B (B - 1) it is the expected number of columns two queries share (uniform 776-nnz queries: ~20; skewed
+// column popularity: hundreds) -- the host picks the shared-column kernel variant from it.
 template <int UNUSED>
-__global__ void mq_plan_kernel(const int64_t* counts, int32_t B, int32_t qt, int32_t vals_cap, int64_t* qptr, int2* tiles, int64_t* plan) {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+__global__ void mq_plan_kernel(const int64_t* counts, int32_t B, int32_t qt, int32_t vals_cap, int64_t* qptr, int2* tiles, int64_t* plan,
+                               const uint32_t* colfreq, int32_t n_cols) {
+    if (blockIdx.x != 0) return;
+    {
+        int64_t sh = 0;
+        for (int c = threadIdx.x; c < n_cols; c += 64) { const int64_t f = colfreq[c]; sh += f * (f - 1); }
+        for (int o = 32; o > 0; o >>= 1) sh += __shfl_xor(sh, o, 64);
+        if (threadIdx.x == 0) plan[3] = sh;
+    }
+    if (threadIdx.x != 0) return;
     int64_t acc = 0, mx = 0;
     qptr[0] = 0;
     for (int b = 0; b < B; ++b) {
