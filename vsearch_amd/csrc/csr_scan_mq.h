@@ -41,6 +41,38 @@ __device__ __forceinline__ T sel8(T x0, T x1, T x2, T x3, T x4, T x5, T x6, T x7
     return b2 ? c1 : c0;
 }
 
+// LDS byte address of tab[c] for the two uint16 column ids of a packet dword: one SDWA shift each (the
+// compiler's and/bfe + shift pair costs two VALU ops per index non-zero; tab sits at LDS offset 0)
+__device__ __forceinline__ uint32_t tab_addr_lo(uint32_t cw) {
+    uint32_t r;
+    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(2u), "v"(cw));
+    return r;
+}
+__device__ __forceinline__ uint32_t tab_addr_hi(uint32_t cw) {
+    uint32_t r;
+    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(2u), "v"(cw));
+    return r;
+}
+
+// LDS access by byte address (the kernel's dynamic LDS block starts at LDS address 0 -- checked at kernel entry):
+// lets table entries carry ready-to-use addresses, with no base add in front of the ds_read
+typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
+typedef __attribute__((address_space(3))) float lds_f32_t;
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) f32x4_t lds_f32x4_t;
+__device__ __forceinline__ uint32_t lds_u32(uint32_t addr) { return *reinterpret_cast<lds_u32_t*>(addr); }
+__device__ __forceinline__ float lds_f32(uint32_t addr) { return *reinterpret_cast<lds_f32_t*>(addr); }
+__device__ __forceinline__ f32x4_t lds_f32x4(uint32_t addr) { return *reinterpret_cast<lds_f32x4_t*>(addr); }
+
+constexpr uint32_t kMqSharedFlag = 0x80000000u;   // tab entry of a shared column (DN variant): flag | LDS address << 8, mask byte 0
+
+template <class T>
+__device__ __forceinline__ T sel8b(T x0, T x1, T x2, T x3, T x4, T x5, T x6, T x7, bool b0, bool b1, bool b2) {
+    const T a0 = b0 ? x1 : x0, a1 = b0 ? x3 : x2, a2 = b0 ? x5 : x4, a3 = b0 ? x7 : x6;
+    const T c0 = b1 ? a1 : a0, c1 = b1 ? a3 : a2;
+    return b2 ? c1 : c0;
+}
+
 struct MqArgs {
     const uint32_t* pk_ptr;
     const uint4* cols;
@@ -90,6 +122,8 @@ __global__ __launch_bounds__(kScanThreads) void csr_scan_topk_mq(MqArgs a) {
     unsigned int* ccnt = reinterpret_cast<unsigned int*>(scratch + 48);         // [QT] candidate counts (keys live in global memory)
     float* qv = reinterpret_cast<float*>(scratch + 64);                         // [vals_cap]
 
+    const uint32_t qv_addr = (uint32_t)(reinterpret_cast<char*>(qv) - smem);    // LDS byte address of qv (smem starts at 0)
+    if ((uint32_t)(size_t)((__attribute__((address_space(3))) char*)smem) != 0u) __builtin_trap();
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int g = lane / G, lg = lane % G;
     const int slot = w * RPW + g;
@@ -123,7 +157,9 @@ __global__ __launch_bounds__(kScanThreads) void csr_scan_topk_mq(MqArgs a) {
             int off = block_excl_scan(mine, scratch, tid, nullptr);
             for (int i = i0; i < i1; ++i) {
                 const uint32_t m = tab[i];
-                tab[i] = m | ((uint32_t)(off * 4) << QT);        // byte offset into qv
+                // LDS byte address of the column's weights; unused columns stay 0 so that a lane without a hit
+                // fetches LDS address 0 (one broadcast address: no bank conflicts, result unused)
+                if (m) tab[i] = m | ((qv_addr + (uint32_t)(off * 4)) << QT);
                 off += __popc(m);
             }
             __syncthreads();
@@ -131,7 +167,7 @@ __global__ __launch_bounds__(kScanThreads) void csr_scan_topk_mq(MqArgs a) {
                 int qs = 0;
                 while (e >= a.qptr[q0 + qs + 1]) ++qs;
                 const uint32_t t = tab[a.qcols[e]];
-                qv[(t >> (QT + 2)) + __popc(t & ((1u << qs) - 1u))] = a.qvals[e];
+                *reinterpret_cast<float*>(smem + (t >> QT) + 4 * __popc(t & ((1u << qs) - 1u))) = a.qvals[e];
             }
         } else {
             // shared columns (popc >= T) first, as 32-byte zero-padded rows; tab = 0x100 | byte offset << 8 (mask byte
@@ -168,10 +204,10 @@ __global__ __launch_bounds__(kScanThreads) void csr_scan_topk_mq(MqArgs a) {
                 const uint32_t m = tab[i];
                 const int pc = __popc(m);
                 if (pc >= T) {
-                    tab[i] = m | 0x100u | ((uint32_t)(off_d * 32) << QT);       // mask kept for the fill below
+                    tab[i] = m | kMqSharedFlag | ((qv_addr + (uint32_t)(off_d * 32)) << QT);   // mask kept for the fill below
                     ++off_d;
                 } else {
-                    tab[i] = m | ((uint32_t)(off_p * 4) << QT);
+                    if (m) tab[i] = m | ((qv_addr + (uint32_t)(off_p * 4)) << QT);
                     off_p += pc;
                 }
             }
@@ -181,12 +217,13 @@ __global__ __launch_bounds__(kScanThreads) void csr_scan_topk_mq(MqArgs a) {
                 int qs = 0;
                 while (e >= a.qptr[q0 + qs + 1]) ++qs;
                 const uint32_t t = tab[a.qcols[e]];
-                if (t & 0x100u) qv[((t >> QT) - 1u) / 4 + qs] = a.qvals[e];
-                else qv[(t >> (QT + 2)) + __popc(t & ((1u << qs) - 1u))] = a.qvals[e];
+                const uint32_t addr = (t & ~kMqSharedFlag) >> QT;
+                if (t & kMqSharedFlag) *reinterpret_cast<float*>(smem + addr + 4 * qs) = a.qvals[e];
+                else *reinterpret_cast<float*>(smem + addr + 4 * __popc(t & ((1u << qs) - 1u))) = a.qvals[e];
             }
             __syncthreads();
             for (int i = i0; i < i1; ++i)
-                if (tab[i] & 0x100u) tab[i] &= ~0xFFu;                          // hide shared columns from the one-hit paths
+                if (tab[i] & kMqSharedFlag) tab[i] &= ~0xFFu;                   // hide shared columns from the one-hit paths
         }
         __syncthreads();
 
@@ -239,59 +276,59 @@ __global__ __launch_bounds__(kScanThreads) void csr_scan_topk_mq(MqArgs a) {
                         // Hits are sparse (a position hits with p ~ 0.026 x QT) and almost always single: per position
                         // a straight-line, exec-masked "first hit" and "second hit" (static registers, no select
                         // trees, independent chains); >= 3 queries sharing one column fall into a rare generic loop.
-                        const char* qvb = reinterpret_cast<const char*>(qv);
 #pragma unroll
                         for (int u = 0; u < U; ++u) {
                             const uint32_t cwv[4] = {cwu[u].x, cwu[u].y, cwu[u].z, cwu[u].w};
                             uint32_t t[8];
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) { t[2 * i] = tab[cwv[i] & 0xFFFF]; t[2 * i + 1] = tab[cwv[i] >> 16]; }
+                            for (int i = 0; i < 4; ++i) {
+                                t[2 * i] = lds_u32(tab_addr_lo(cwv[i]));
+                                t[2 * i + 1] = lds_u32(tab_addr_hi(cwv[i]));
+                            }
                             if constexpr (DN) {
-                                const uint32_t anyd = (t[0] | t[1] | t[2] | t[3] | t[4] | t[5] | t[6] | t[7]) & 0x100u;
+                                const uint32_t anyd = (t[0] | t[1] | t[2] | t[3] | t[4] | t[5] | t[6] | t[7]) & kMqSharedFlag;
                                 if (__builtin_amdgcn_ballot_w64(anyd != 0)) {
                                     shared_seen = true;
                                     uint32_t dm = 0;
 #pragma unroll
-                                    for (int i = 0; i < 8; ++i) dm |= ((t[i] >> 8) & 1u) << i;
+                                    for (int i = 0; i < 8; ++i) dm |= (t[i] >> 31) << i;
                                     while (dm) {
                                         const int i = __ffs(dm) - 1;
                                         dm &= dm - 1;
                                         const uint32_t ts = sel8(t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], i);
                                         const float vs_ = sel8(vu[u][0], vu[u][1], vu[u][2], vu[u][3], vu[u][4], vu[u][5], vu[u][6], vu[u][7], i);
-                                        const float4* wp = reinterpret_cast<const float4*>(qvb + ((ts >> QT) - 1u));
-                                        const float4 w0 = wp[0], w1 = wp[1];
+                                        const uint32_t wa = (ts & ~kMqSharedFlag) >> QT;
+                                        const f32x4_t w0 = lds_f32x4(wa), w1 = lds_f32x4(wa + 16);
                                         d0 += (double)(vs_ * w0.x); d1 += (double)(vs_ * w0.y); d2 += (double)(vs_ * w0.z); d3 += (double)(vs_ * w0.w);
                                         d4 += (double)(vs_ * w1.x); d5 += (double)(vs_ * w1.y); d6 += (double)(vs_ * w1.z); d7 += (double)(vs_ * w1.w);
                                     }
                                 }
                             }
-                            // first hits, two packet positions (i, i+4) per LDS round trip: a position hits with
-                            // p ~ 0.2, so "exactly one of the pair" is the common case and is served by ONE weight
-                            // fetch + ONE ds_add_f64 instead of two mostly-empty ones; a pair whose both positions
-                            // hit leaves position i+4 to the remainder loop.
-                            uint32_t r[8];                                             // remaining hit bits per position
-                            uint32_t m1[4];
+                            // First hits, two packet positions (i, i+4) per LDS round trip: a position hits with p ~ 0.2, so
+                            // "exactly one of the pair" is the common case and is served by ONE weight fetch + ONE ds_add_f64.
+                            // hw = mask(i) | mask(i+4) << 8 (one v_perm); its lowest set bit is the first hit (position i
+                            // before i+4, lower query slot first); the other bits go to the remainder loop.
+                            uint32_t hw[4], hb[4], rm[4];
                             float wv[4];
 #pragma unroll
                             for (int i = 0; i < 4; ++i) {                              // all four weight fetches first (independent)
-                                const uint32_t ma = t[i] & 0xFFu, mb = t[i + 4] & 0xFFu;
-                                const bool use_a = ma != 0;
-                                m1[i] = use_a ? ma : mb;
-                                const uint32_t ts = use_a ? t[i] : t[i + 4];
+                                hw[i] = __builtin_amdgcn_perm(t[i + 4], t[i], 0x0c0c0400u);
+                                hb[i] = (uint32_t)__builtin_ctz(hw[i] | 0x10000u);     // 16 when there is no hit
+                                const bool use_a = hb[i] < 8u;
+                                uint32_t ts = use_a ? t[i] : t[i + 4];
+                                if constexpr (DN) ts &= ~kMqSharedFlag;                // a shared column's entry carries the flag (mask 0: fetch unused)
                                 const float vs_ = use_a ? vu[u][i] : vu[u][i + 4];
-                                // lanes without a hit read entry 0 (one broadcast address: no bank conflict, result unused)
-                                wv[i] = vs_ * *reinterpret_cast<const float*>(qvb + (m1[i] ? (ts >> QT) : 0u));
-                                r[i] = ma & (ma - 1);
-                                r[i + 4] = use_a ? mb : (mb & (mb - 1));
+                                // lanes without a hit read a zero entry's address: LDS address 0, one broadcast, result unused
+                                wv[i] = vs_ * lds_f32(ts >> QT);
+                                rm[i] = hw[i] & (hw[i] - 1);
                             }
 #pragma unroll
                             for (int i = 0; i < 4; ++i)
-                                if (m1[i]) atomicAdd(&myacc[__ffs(m1[i]) - 1], (double)wv[i]);         // ds_add_f64
-                            // columns shared by >= 2 queries of the tile (~10 % of hits): one loop over the packed
-                            // remainder word -- few iterations, and far fewer LDS instructions than a second
-                            // exec-masked pass over all 8 positions
-                            uint32_t mlo = r[0] | (r[1] << 8) | (r[2] << 16) | (r[3] << 24);
-                            uint32_t mhi = r[4] | (r[5] << 8) | (r[6] << 16) | (r[7] << 24);
+                                if (hw[i]) atomicAdd(&myacc[hb[i] & 7u], (double)wv[i]);               // ds_add_f64
+                            // second hits of a pair and columns shared by >= 2 queries of the tile: one loop over the packed
+                            // remainder words (16 bits per pair) -- few iterations, one hit per lane per iteration
+                            uint32_t mlo = rm[0] | (rm[1] << 16);
+                            uint32_t mhi = rm[2] | (rm[3] << 16);
                             while (mlo | mhi) {
                                 const bool in_lo = mlo != 0;
                                 const uint32_t word = in_lo ? mlo : mhi;
@@ -299,12 +336,13 @@ __global__ __launch_bounds__(kScanThreads) void csr_scan_topk_mq(MqArgs a) {
                                 const uint32_t cleared = word & (word - 1);
                                 mlo = in_lo ? cleared : mlo;
                                 mhi = in_lo ? mhi : cleared;
-                                const int i = (bit >> 3) | (in_lo ? 0 : 4);
+                                // position = pair + 4 * half, pair = (in_lo ? 0 : 2) + bit / 16, half = (bit / 8) & 1
+                                const bool b0 = bit & 16, b1 = !in_lo, b2 = bit & 8;
                                 const int qs = bit & 7;
-                                const uint32_t ts = sel8(t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], i);
-                                const float vs_ = sel8(vu[u][0], vu[u][1], vu[u][2], vu[u][3], vu[u][4], vu[u][5], vu[u][6], vu[u][7], i);
-                                const uint32_t boff = (ts >> QT) + 4u * __popc(ts & ((1u << qs) - 1u));
-                                atomicAdd(&myacc[qs], (double)(vs_ * *reinterpret_cast<const float*>(qvb + boff)));
+                                const uint32_t ts = sel8b(t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], b0, b1, b2);
+                                const float vs_ = sel8b(vu[u][0], vu[u][1], vu[u][2], vu[u][3], vu[u][4], vu[u][5], vu[u][6], vu[u][7], b0, b1, b2);
+                                const uint32_t addr = (ts >> QT) + 4u * __popc(ts & ((1u << qs) - 1u));
+                                atomicAdd(&myacc[qs], (double)(vs_ * lds_f32(addr)));
                             }
                         }
                     }
