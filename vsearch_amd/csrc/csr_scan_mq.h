@@ -73,6 +73,12 @@ __device__ __forceinline__ T sel8b(T x0, T x1, T x2, T x3, T x4, T x5, T x6, T x
     return b2 ? c1 : c0;
 }
 
+template <class T>
+__device__ __forceinline__ T sel4b(T x0, T x1, T x2, T x3, bool b0, bool b1) {
+    const T a0 = b0 ? x1 : x0, a1 = b0 ? x3 : x2;
+    return b1 ? a1 : a0;
+}
+
 struct MqArgs {
     const uint32_t* pk_ptr;
     const uint4* cols;
@@ -327,20 +333,26 @@ __global__ __launch_bounds__(kScanThreads) void csr_scan_topk_mq(MqArgs a) {
                                 if (hw[i]) atomicAdd(&myacc[hb[i] & 7u], (double)wv[i]);               // ds_add_f64
                             // second hits of a pair and columns shared by >= 2 queries of the tile: one loop over the packed
                             // remainder words (16 bits per pair) -- few iterations, one hit per lane per iteration
+                            // (two loops, one per pair of pairs: a 4-way select per hit instead of an 8-way one)
                             uint32_t mlo = rm[0] | (rm[1] << 16);
-                            uint32_t mhi = rm[2] | (rm[3] << 16);
-                            while (mlo | mhi) {
-                                const bool in_lo = mlo != 0;
-                                const uint32_t word = in_lo ? mlo : mhi;
-                                const int bit = __ffs(word) - 1;
-                                const uint32_t cleared = word & (word - 1);
-                                mlo = in_lo ? cleared : mlo;
-                                mhi = in_lo ? mhi : cleared;
-                                // position = pair + 4 * half, pair = (in_lo ? 0 : 2) + bit / 16, half = (bit / 8) & 1
-                                const bool b0 = bit & 16, b1 = !in_lo, b2 = bit & 8;
+                            while (mlo) {
+                                const int bit = __builtin_ctz(mlo);
+                                mlo &= mlo - 1;
+                                const bool b0 = bit & 16, b2 = bit & 8;                // position = (bit / 16) + 4 * ((bit / 8) & 1)
                                 const int qs = bit & 7;
-                                const uint32_t ts = sel8b(t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], b0, b1, b2);
-                                const float vs_ = sel8b(vu[u][0], vu[u][1], vu[u][2], vu[u][3], vu[u][4], vu[u][5], vu[u][6], vu[u][7], b0, b1, b2);
+                                const uint32_t ts = sel4b(t[0], t[1], t[4], t[5], b0, b2);
+                                const float vs_ = sel4b(vu[u][0], vu[u][1], vu[u][4], vu[u][5], b0, b2);
+                                const uint32_t addr = (ts >> QT) + 4u * __popc(ts & ((1u << qs) - 1u));
+                                atomicAdd(&myacc[qs], (double)(vs_ * lds_f32(addr)));
+                            }
+                            uint32_t mhi = rm[2] | (rm[3] << 16);
+                            while (mhi) {
+                                const int bit = __builtin_ctz(mhi);
+                                mhi &= mhi - 1;
+                                const bool b0 = bit & 16, b2 = bit & 8;                // position = 2 + (bit / 16) + 4 * ((bit / 8) & 1)
+                                const int qs = bit & 7;
+                                const uint32_t ts = sel4b(t[2], t[3], t[6], t[7], b0, b2);
+                                const float vs_ = sel4b(vu[u][2], vu[u][3], vu[u][6], vu[u][7], b0, b2);
                                 const uint32_t addr = (ts >> QT) + 4u * __popc(ts & ((1u << qs) - 1u));
                                 atomicAdd(&myacc[qs], (double)(vs_ * lds_f32(addr)));
                             }
