@@ -423,3 +423,26 @@ def test_skewed_column_popularity_shared_column_variant(monkeypatch, s, binary):
             compare.check_topk_valid(allsc, ids, sc, rtol=RTOL)
             compare.compare_topk(o_ids, o_sc, ids, sc, rtol=RTOL)
     np.testing.assert_allclose(res["0"][1], res["1"][1], rtol=1e-6)
+
+
+@pytest.mark.parametrize("B,k", [(1, 100), (3, 17), (2, 400)])
+def test_small_batch_many_chunks_merge_prefilter(B, k):
+    """A small batch cuts the rows into up to one chunk per CU; the merge of the per-chunk (sorted) top-k lists takes the
+    sorted-run shortcut.  Adversarial layout: every top document sits in the first chunk."""
+    rng = np.random.default_rng(11)
+    n, nnz = 150_000, 16
+    q = oracle.synth_queries(1, B)
+    cols = np.sort(rng.integers(0, V, size=(n, nnz)).astype(np.int32), axis=1)
+    hot = np.nonzero(q[0])[0][:nnz].astype(np.int32)               # rows 0..599 hit query 0's columns with growing weights
+    cols[:600] = np.sort(hot)
+    keep = np.ones((n, nnz), dtype=bool)
+    keep[:, 1:] = cols[:, 1:] != cols[:, :-1]                       # drop duplicate columns in a row
+    ip = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(keep.sum(1), out=ip[1:])
+    vals = (0.01 + 3 * rng.random((n, nnz))).astype(np.float32)
+    vals[:600] *= (1 + np.arange(600, dtype=np.float32)[:, None] / 600)
+    idx = DeviceIndex.from_csr(ip, cols[keep], vals[keep], V)
+    ids, sc = idx.search(q, k)
+    allsc = idx.scores(q)
+    compare.check_topk_valid(allsc, ids, sc, rtol=RTOL)
+    assert set(ids[0, :min(k, 100)]) <= set(range(600))

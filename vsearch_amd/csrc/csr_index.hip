@@ -682,14 +682,14 @@ int mq_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64_t id_o
     // 1. sparsify the batch: counts -> (qptr, tiles, plan) -> (qcols, qvals)
     const size_t off_counts = 0, off_qptr = off_counts + (size_t)B * 8, off_plan = off_qptr + (size_t)(B + 1) * 8,
                  off_tiles = off_plan + 64, off_freq = off_tiles + (((size_t)B * sizeof(int2) + 15) & ~(size_t)15);
-    VS_TRY(idx->ws_mq_meta.reserve(off_freq + (size_t)(V + 1) * 4));
+    VS_TRY(idx->ws_mq_meta.reserve(off_freq + (size_t)(V + 4) * 4 + 8));
     char* meta = idx->ws_mq_meta.as<char>();
     int64_t* counts = (int64_t*)(meta + off_counts);
     int64_t* qptr = (int64_t*)(meta + off_qptr);
     int64_t* dplan = (int64_t*)(meta + off_plan);
     int2* tiles = (int2*)(meta + off_tiles);
     uint32_t* colfreq = (uint32_t*)(meta + off_freq);
-    VS_HIP(hipMemsetAsync(colfreq, 0, (size_t)(V + 1) * 4, s));
+    VS_HIP(hipMemsetAsync(colfreq, 0, (size_t)(V + 4) * 4 + 8, s));          // counts + the 64-bit overlap sum behind them
     hipLaunchKernelGGL(count_nz_kernel<0>, dim3(std::min(B, 2048)), dim3(kSpThreads), 0, s, dq, (int64_t)V, B, V, counts);
     hipLaunchKernelGGL(mq_colfreq_kernel<0>, dim3(std::min(B, 2048)), dim3(kSpThreads), 0, s, dq, (int64_t)V, B, V, colfreq);
     hipLaunchKernelGGL(mq_plan_kernel<0>, dim3(1), dim3(64), 0, s, counts, B, kQT, vals_cap, qptr, tiles, dplan, colfreq, V);
@@ -771,6 +771,7 @@ int mq_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64_t id_o
     m.out_scores = d_scores;
     m.out_ld = k;
     m.col0 = 0;
+    m.run_len = k;                                 // every chunk's list is sorted
     {
         ProfScope prof("merge_topk", s);
         hipLaunchKernelGGL(merge_topk_kernel<0>, dim3(std::min(B, idx->cu_count * 2)), dim3(kScanThreads), 0, s, m);
@@ -860,6 +861,7 @@ int vs_csr_search(vs_index* idx, const void* q, int q_dtype, int64_t ldq, int32_
             m.out_scores = d_scores + (size_t)b0 * k;
             m.out_ld = k;
             m.col0 = col0;
+            m.run_len = kk;
             m.upper_out = passes > 1 ? upper.as<uint64_t>() + b0 : nullptr;
             {
                 ProfScope prof("merge_topk", s);

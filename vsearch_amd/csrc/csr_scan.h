@@ -305,11 +305,13 @@ struct MergeArgs {
     int32_t col0;
     uint64_t* upper_out;      // optional [B]: receives the k-th key (next pass's exclusive upper bound)
     const uint64_t* upper_in; // optional [B]: only keys < upper_in[b] take part (passes after the first when k > 2048)
+    int32_t run_len;          // > 0: the list is a sequence of descending-sorted runs of this length (per-chunk top-k lists)
 };
 
 template <int UNUSED>
 __global__ __launch_bounds__(kScanThreads) void merge_topk_kernel(MergeArgs a) {
     __shared__ uint64_t buf[kWgCap];
+    __shared__ int cnt_sh;
     const int tid = threadIdx.x;
     const int K = a.k;                                       // K <= kMaxKShared
     for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
@@ -317,7 +319,45 @@ __global__ __launch_bounds__(kScanThreads) void merge_topk_kernel(MergeArgs a) {
         int64_t consumed = 0;
         int have = 0;                                        // buf[0..have) = best so far
         __syncthreads();
-        do {
+        // Sorted runs (many row chunks, small batch): the first p = ceil(K / runs) keys of every run hold >= K keys, so
+        // their K-th largest is a lower bound of the answer's K-th key; typically only a few hundred candidates pass
+        // it, and ONE small sort replaces n_cand / 4096 full-buffer rounds.
+        bool done = false;
+        if (a.run_len > 0 && !a.upper_in && a.n_cand > kWgCap && a.n_cand % a.run_len == 0) {
+            const int runs = (int)(a.n_cand / a.run_len);
+            const int p = min(a.run_len, (K + runs - 1) / runs);
+            const int heads = runs * p;
+            if (heads >= K && heads <= kWgCap) {
+                int n2 = 64;
+                while (n2 < heads) n2 <<= 1;
+                for (int i = tid; i < n2; i += kScanThreads) buf[i] = i < heads ? src[(size_t)(i / p) * a.run_len + (i % p)] : 0ull;
+                wg_sort_desc<kScanThreads>(buf, n2, tid);
+                const uint64_t bound = buf[K - 1];
+                __syncthreads();
+                if (tid == 0) cnt_sh = 0;
+                __syncthreads();
+                for (int64_t i = tid; i < a.n_cand; i += kScanThreads) {
+                    const uint64_t key = src[i];
+                    if (key >= bound && key != 0ull) {
+                        const int pos = atomicAdd(&cnt_sh, 1);
+                        if (pos < kWgCap) buf[pos] = key;
+                    }
+                }
+                __syncthreads();
+                const int cnt = cnt_sh;
+                if (cnt <= kWgCap) {
+                    int n3 = 64;
+                    while (n3 < cnt) n3 <<= 1;
+                    n3 = max(n3, 64);
+                    while (n3 < K) n3 <<= 1;
+                    for (int i = cnt + tid; i < n3; i += kScanThreads) buf[i] = 0ull;
+                    wg_sort_desc<kScanThreads>(buf, n3, tid);
+                    done = true;
+                }
+                __syncthreads();
+            }
+        }
+        if (!done) do {
             const int room = kWgCap - have;
             const int64_t take = min((int64_t)room, a.n_cand - consumed);
             for (int i = tid; i < room; i += kScanThreads) {
@@ -335,6 +375,7 @@ __global__ __launch_bounds__(kScanThreads) void merge_topk_kernel(MergeArgs a) {
             a.out_scores[(size_t)b * a.out_ld + a.col0 + i] = key_score(key);
             if (a.upper_out && i == K - 1) a.upper_out[b] = key;
         }
+        __syncthreads();
     }
 }
 

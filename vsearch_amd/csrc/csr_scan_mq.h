@@ -415,11 +415,17 @@ __global__ __launch_bounds__(kScanThreads) void csr_scan_topk_mq(MqArgs a) {
 }
 
 // column use counts of a dense [B, V] query batch (one workgroup per query)
+// colfreq[V] = sum over columns of f (f - 1): a query joining a column already used by f others adds 2 f
 template <int UNUSED>
 __global__ __launch_bounds__(kSpThreads) void mq_colfreq_kernel(const float* x, int64_t ld, int32_t B, int32_t V, uint32_t* colfreq) {
-    for (int b = blockIdx.x; b < B; b += gridDim.x)
+    unsigned long long* share = reinterpret_cast<unsigned long long*>(colfreq + ((V + 2) & ~1));
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        unsigned long long mine = 0;
         for (int i = threadIdx.x; i < V; i += kSpThreads)
-            if (x[(size_t)b * ld + i] != 0.f) atomicAdd(&colfreq[i], 1u);
+            if (x[(size_t)b * ld + i] != 0.f) mine += 2ull * atomicAdd(&colfreq[i], 1u);
+        for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
+        if ((threadIdx.x & 63) == 0 && mine) atomicAdd(share, mine);
+    }
 }
 
 // Single-thread planner: row pointers of the sparse query batch + greedy tiling (<= QT queries and
@@ -430,14 +436,8 @@ __global__ __launch_bounds__(kSpThreads) void mq_colfreq_kernel(const float* x, 
 template <int UNUSED>
 __global__ void mq_plan_kernel(const int64_t* counts, int32_t B, int32_t qt, int32_t vals_cap, int64_t* qptr, int2* tiles, int64_t* plan,
                                const uint32_t* colfreq, int32_t n_cols) {
-    if (blockIdx.x != 0) return;
-    {
-        int64_t sh = 0;
-        for (int c = threadIdx.x; c < n_cols; c += 64) { const int64_t f = colfreq[c]; sh += f * (f - 1); }
-        for (int o = 32; o > 0; o >>= 1) sh += __shfl_xor(sh, o, 64);
-        if (threadIdx.x == 0) plan[3] = sh;
-    }
-    if (threadIdx.x != 0) return;
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    plan[3] = (int64_t)*reinterpret_cast<const unsigned long long*>(colfreq + ((n_cols + 2) & ~1));
     int64_t acc = 0, mx = 0;
     qptr[0] = 0;
     for (int b = 0; b < B; ++b) {
