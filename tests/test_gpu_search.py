@@ -409,11 +409,11 @@ def test_skewed_column_popularity_shared_column_variant(monkeypatch, s, binary):
     idx = DeviceIndex.from_csr(ip, ix, d, V)
     o_ids, o_sc, allsc = oracle.csr_search(ip, ix, d, V, q, 50, acc64=True, return_all=True)
     res = {}
-    for forced in ("0", "1", None):
+    for forced in ("0", "1", None):                               # kernel variants: pairs, shared columns; auto
         if forced is None:
-            monkeypatch.delenv("VS_MQ_SHARED", raising=False)
+            monkeypatch.delenv("VS_MQ_MODE", raising=False)
         else:
-            monkeypatch.setenv("VS_MQ_SHARED", forced)
+            monkeypatch.setenv("VS_MQ_MODE", forced)
         ids, sc = idx.search(q, 50)
         assert idx.info().queries_per_pass == 8
         res[forced] = (ids, sc)
@@ -446,3 +446,35 @@ def test_small_batch_many_chunks_merge_prefilter(B, k):
     allsc = idx.scores(q)
     compare.check_topk_valid(allsc, ids, sc, rtol=RTOL)
     assert set(ids[0, :min(k, 100)]) <= set(range(600))
+
+
+@pytest.mark.parametrize("mode", ["0", "1"], ids=["pairs", "shared-columns"])
+@pytest.mark.parametrize("store", [nat.VS_F32, nat.VS_F16, nat.VS_NONE], ids=["fp32", "fp16", "binary"])
+def test_multi_query_kernel_variants_agree_with_oracle(monkeypatch, mode, store):
+    """Every variant of the Qt = 8 pass, forced, on ragged rows (0..2000 nnz) and a ragged batch (11 queries)."""
+    monkeypatch.setenv("VS_MQ_MODE", mode)
+    rng = np.random.default_rng(3)
+    n = 3000
+    lens = rng.integers(0, 200, size=n)
+    lens[::97] = 2000
+    lens[5] = 0
+    ip = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(lens, out=ip[1:])
+    ix = np.concatenate([np.sort(rng.choice(V, size=l, replace=False)) for l in lens]).astype(np.int32)
+    if store == nat.VS_NONE:
+        d, dq = None, None
+    else:
+        d = (0.01 + 3 * rng.random(len(ix))).astype(np.float32)
+        if store == nat.VS_F16:
+            d = d.astype(np.float16).astype(np.float32)
+    q = oracle.synth_queries(1, 11, val_law=synth.VAL_DYADIC if store != nat.VS_F32 else synth.VAL_GRID)
+    idx = DeviceIndex.from_csr(ip, ix, d, V, store_dtype=store) if store != nat.VS_NONE else DeviceIndex.from_csr(ip, ix, None, V)
+    for k in (1, 64, 300):
+        ids, sc = idx.search(q, k)
+        assert idx.info().queries_per_pass == 8
+        o_ids, o_sc, allsc = oracle.csr_search(ip, ix, d, V, q, k, acc64=True, return_all=True)
+        if store == nat.VS_NONE:
+            assert (sc == o_sc).all() and (ids == o_ids).all()
+        else:
+            compare.check_topk_valid(allsc, ids, sc, rtol=RTOL)
+            compare.compare_topk(o_ids, o_sc, ids, sc, rtol=RTOL)

@@ -46,9 +46,9 @@ def main():
         del cols, vals
         for qt, shared in ((0, "0"), (0, "1"), (0, None), (1, None)):
             if shared is None:
-                os.environ.pop("VS_MQ_SHARED", None)
+                os.environ.pop("VS_MQ_MODE", None)
             else:
-                os.environ["VS_MQ_SHARED"] = shared
+                os.environ["VS_MQ_MODE"] = shared
             idx.set_queries_per_pass(qt)
             idx.search(q, K)
             torch.cuda.synchronize(); t = time.time()
@@ -57,7 +57,7 @@ def main():
             allsc = idx.scores(q[:4])
             allsc = allsc.cpu().numpy() if hasattr(allsc, "cpu") else allsc
             compare.check_topk_valid(allsc, ids[:4].cpu().numpy(), sc[:4].cpu().numpy(), rtol=1e-4)
-            print(f"zipf s={s}: N={N} B={B} qt_pref={qt} shared={shared} used_qt={idx.info().queries_per_pass}  {dt*1e3:.1f} ms  {B/dt:.0f} q/s  (top-k valid)", flush=True)
+            print(f"zipf s={s}: N={N} B={B} qt_pref={qt} mode={shared} used_qt={idx.info().queries_per_pass}  {dt*1e3:.1f} ms  {B/dt:.0f} q/s  (top-k valid)", flush=True)
         idx.close()
 
 

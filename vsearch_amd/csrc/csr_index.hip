@@ -754,7 +754,7 @@ int mq_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64_t id_o
         // expected number of columns two queries of the batch share; uniform 776-nnz queries: ~20
         const double overlap = B > 1 ? (double)hplan[3] / ((double)B * (double)(B - 1)) : 0.0;
         bool shared_cols = overlap > kMqSharedOverlap;
-        if (const char* e = getenv("VS_MQ_SHARED")) shared_cols = atoi(e) != 0;
+        if (const char* e = getenv("VS_MQ_MODE")) shared_cols = atoi(e) != 0;      // testing: force a variant (0 pairs, 1 shared columns)
         int rc = idx->store_dtype == VS_F32 ? launch_mq_vm<VM_F32>(mq_lanes(idx), u, shared_cols, a, grid, lds, s)
                : idx->store_dtype == VS_F16 ? launch_mq_vm<VM_F16>(mq_lanes(idx), u, shared_cols, a, grid, lds, s)
                                             : launch_mq_vm<VM_BIN>(mq_lanes(idx), u, shared_cols, a, grid, lds, s);
