@@ -196,7 +196,10 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "csr_scan_topk", "launches": scan_launches,
                          "avg_launch_ms": avg_launch_s * 1e3, "algorithmic_bytes_per_launch": algo_bytes_per_launch,
-                         "bytes_per_pass": info.bytes_per_pass, "merge_ms_total": merge_ms},
+                         "bytes_per_pass": info.bytes_per_pass, "merge_ms_total": merge_ms,
+                         "note": "achieved = algorithmic bytes (bytes_per_pass x passes, SURVEY 8(d)) / measured kernel time; traffic = "
+                                 "PMC-measured HBM bytes of the launch. achieved can exceed the HBM peak because concurrent query tiles "
+                                 "sweep the same rows and share the stream through L2 / Infinity Cache (traffic << algorithmic)"},
         }
         if world == 1:
             line["parity"] = parity_check(local_rank)
