@@ -102,16 +102,23 @@ def test_k_gt_n_raises_like_topk(sparse2000):
         idx.search(oracle.synth_queries(1, 2), 2001)
 
 
-def test_multipass_large_k():
-    """k > 2048: repeated passes with an exclusive upper-bound key; result = full canonical ranking."""
+@pytest.mark.parametrize("qt", [0, 1], ids=["multi-query", "dense-image"])
+def test_multipass_large_k(qt):
+    """k beyond one pass's capacity (512 ranks for the Qt = 8 pass, 2048 for Qt = 1): repeated passes with an exclusive
+    upper-bound key ("search after"); result = full canonical ranking."""
     n = 5000
     ip, ix, d = oracle.synth_csr(2, 0, n, V, 64)
     idx = DeviceIndex.from_csr(ip, ix, d, V)
-    q = oracle.synth_queries(6, 3)
-    ids, sc = idx.search(q, n)
+    idx.set_queries_per_pass(qt)
+    q = oracle.synth_queries(6, 11)
     _, _, allsc = oracle.csr_search(ip, ix, d, V, q, 1, acc64=True, return_all=True)
-    compare.check_topk_valid(allsc, ids, sc, rtol=RTOL)
-    assert all(len(set(r.tolist())) == n for r in ids)
+    for k in (513, 1300, n):
+        ids, sc = idx.search(q, k)
+        assert idx.info().queries_per_pass == (8 if qt == 0 else 1)
+        compare.check_topk_valid(allsc, ids, sc, rtol=RTOL)
+        assert all(len(set(r.tolist())) == k for r in ids)
+        o_ids, o_sc = oracle.csr_search(ip, ix, d, V, q, k, acc64=True)
+        compare.compare_topk(o_ids, o_sc, ids, sc, rtol=RTOL)
 
 
 @pytest.mark.parametrize("tag,exact", [("f32", False), ("dyadic", True)])

@@ -673,11 +673,13 @@ int mq_vals_cap(const vs_index* idx) {
 
 // Multi-query pass (Qt = kQT).  Returns VS_OK and sets *done = false when the batch does not qualify
 // (a query denser than the LDS weight capacity): the caller then takes the dense-image path.
+// One pass delivers ranks [col0, col0 + k) of every query into columns col0.. of the [B, out_ld] outputs; `upper`
+// ([B], nullable) holds the exclusive upper-bound keys on entry and the k-th keys of this pass on return.
 int mq_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64_t id_offset, int64_t* d_ids, float* d_scores,
-              const ScanPlan& plan, hipStream_t s, bool* done) {
+              const ScanPlan& plan, hipStream_t s, bool* done, int32_t out_ld, int32_t col0, uint64_t* upper) {
     *done = false;
     const int vals_cap = mq_vals_cap(idx);
-    if (vals_cap <= 0 || k > kMaxKMq) return VS_OK;
+    if (vals_cap <= 0 || k > kMaxKMq) return VS_OK;             // (callers split larger k into passes)
     const int V = idx->n_cols;
     // 1. sparsify the batch: counts -> (qptr, tiles, plan) -> (qcols, qvals)
     const size_t off_counts = 0, off_qptr = off_counts + (size_t)B * 8, off_plan = off_qptr + (size_t)(B + 1) * 8,
@@ -745,6 +747,7 @@ int mq_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64_t id_o
     a.cand = idx->ws_cand.as<uint64_t>();
     a.gcand = idx->ws_mq_cand.as<uint64_t>();
     a.gcnt = reinterpret_cast<uint32_t*>(a.gcand + (size_t)grid * kQT * kMqCap);
+    a.upper = col0 > 0 ? upper : nullptr;
     const size_t lds = mq_fixed_lds_bytes<kQT>(V, mq_acc_rows(idx)) + (size_t)vals_cap * 4;
     {
         ProfScope prof("csr_scan_topk", s);
@@ -769,8 +772,9 @@ int mq_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64_t id_o
     m.id_offset = id_offset;
     m.out_ids = d_ids;
     m.out_scores = d_scores;
-    m.out_ld = k;
-    m.col0 = 0;
+    m.out_ld = out_ld;
+    m.col0 = col0;
+    m.upper_out = upper;
     m.run_len = k;                                 // every chunk's list is sorted
     {
         ProfScope prof("merge_topk", s);
@@ -799,17 +803,28 @@ int vs_csr_search(vs_index* idx, const void* q, int q_dtype, int64_t ldq, int32_
         d_scores = idx->ws_out_scores.as<float>();
     }
     idx->last_qt = 1;
-    if (idx->qt_pref != 1 && k <= kMaxKMq) {
+    if (idx->qt_pref != 1) {
         bool done = false;
-        // large batches are cut so that the candidate scratch stays bounded
-        const size_t per_q_mq = (size_t)plan.nchunk * k * 8;
+        // k > kMaxKMq: "search after" passes of kMaxKMq ranks each (the k-th key of a pass is the next pass's exclusive
+        // upper bound); large batches are cut so that the candidate scratch stays bounded
+        const int mq_passes = ceil_div(k, kMaxKMq);
+        const int kk_mq = std::min<int>(k, kMaxKMq);
+        DevBuf mq_upper;
+        if (mq_passes > 1) VS_TRY(mq_upper.alloc((size_t)B * 8));
+        const size_t per_q_mq = (size_t)plan.nchunk * kk_mq * 8;
         const int bs_mq = (int)std::max<size_t>(1, std::min<size_t>((size_t)B, ((size_t)1 << 30) / per_q_mq));
         bool all = true;
-        for (int b0 = 0; b0 < B && all; b0 += bs_mq) {
-            const int bs = std::min(bs_mq, B - b0);
-            VS_TRY(mq_search(idx, dq + (size_t)b0 * idx->n_cols, bs, k, id_offset, d_ids + (size_t)b0 * k, d_scores + (size_t)b0 * k, plan, s, &done));
-            all = all && done;
+        for (int pass = 0; pass < mq_passes && all; ++pass) {
+            const int col0 = pass * kMaxKMq;
+            const int kk = std::min(k - col0, kMaxKMq);
+            for (int b0 = 0; b0 < B && all; b0 += bs_mq) {
+                const int bs = std::min(bs_mq, B - b0);
+                VS_TRY(mq_search(idx, dq + (size_t)b0 * idx->n_cols, bs, kk, id_offset, d_ids + (size_t)b0 * k, d_scores + (size_t)b0 * k, plan, s,
+                                 &done, k, col0, mq_passes > 1 ? mq_upper.as<uint64_t>() + b0 : nullptr));
+                all = all && done;
+            }
         }
+        if (mq_passes > 1) VS_HIP(hipStreamSynchronize(s));      // `mq_upper` is freed on return
         if (all) {
             idx->last_qt = kQT;
             if (!out_dev) {

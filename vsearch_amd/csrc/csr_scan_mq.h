@@ -98,6 +98,7 @@ struct MqArgs {
     uint64_t* cand;           // [B, nchunk, k] output keys, sorted descending
     uint64_t* gcand;          // [grid, QT, kMqCap] scratch
     uint32_t* gcnt;           // [grid, QT] scratch counters
+    const uint64_t* upper;    // optional [B]: only keys < upper[b] take part ("search after": passes beyond the first when k > kMaxKMq)
 };
 
 template <int QT>
@@ -143,6 +144,7 @@ __global__ __launch_bounds__(kScanThreads) void csr_scan_topk_mq(MqArgs a) {
         const int q0 = a.tiles[tile].x, nq = a.tiles[tile].y;
         const int64_t r0 = (int64_t)c * a.rows_per_chunk;
         const int64_t r1 = min(a.n_rows, r0 + a.rows_per_chunk);
+        const uint64_t my_upper = (a.upper && lg < nq) ? a.upper[q0 + lg] : ~0ull;
         __syncthreads();
         // ---- build the tile tables ----
         for (int i = tid; i <= a.n_cols; i += kScanThreads) tab[i] = 0;
@@ -382,7 +384,7 @@ __global__ __launch_bounds__(kScanThreads) void csr_scan_topk_mq(MqArgs a) {
                         *pa = 0.0;
                     }
                     const uint64_t key = make_key((float)sum, (uint32_t)row);
-                    if (key > tau[lg]) {
+                    if (key > tau[lg] && key < my_upper) {
                         const uint32_t pos = atomicAdd(&ccnt[lg], 1u);
                         my_gcand[(size_t)lg * kMqCap + pos] = key;
                     }
