@@ -136,8 +136,10 @@ VS_API int vs_index_scores(vs_index* index, const void* q, int q_dtype, int64_t 
 VS_API int  vs_index_info(const vs_index* index, vs_index_info_t* out);
 
 /* Scan selection (tuning / tests; no reference counterpart): 0 = auto -- score tiles of 8 sparse queries
- * per pass over the index when the batch qualifies (k <= 512, every query sparse enough for the LDS
- * tile tables), else one query per pass with a dense fp32 query image;  1 = always the latter.      */
+ * per pass over the index when every query is sparse enough for the LDS tile tables (512 ranks per
+ * pass; larger k takes several passes), else one query per pass with a dense fp32 query image;
+ * 1 = always the latter.  Environment variable VS_MQ_MODE = 0 | 1 (tests only) forces the plain /
+ * shared-column variant of the 8-query kernel instead of choosing from the batch's query overlap. */
 VS_API int  vs_index_set_queries_per_pass(vs_index* index, int qt);
 
 /* SparseIndex.save (index.py:181-202) needs crow/col/values back: int64 rowptr [n_rows+1], int64
