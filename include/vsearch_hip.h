@@ -173,9 +173,10 @@ VS_API int vs_embed_mask(float* emb, int64_t ld, const int64_t* ids, int32_t B, 
                          int32_t topk, int activate_lexical, int bow, int device, void* stream);
 
 /* Tensor.to_sparse_csr() (retriever.py:304): non-zeros of dense x [B, V] as CSR -- int64 rowptr
- * [B+1], int32 cols / fp32 vals with room for `cap` entries.  cols == NULL: rowptr only (two-call
- * protocol), so build_index can emit CSR batch by batch and never hold the dense [N, V] matrix
- * (retriever.py:281).                                                                            */
+ * [B+1], int32 cols / fp32 vals.  Two-call protocol: (1) cols == vals == NULL: rowptr is WRITTEN
+ * (sizes the outputs: nnz = rowptr[B]); (2) cols / vals with cap >= nnz: the same rowptr is READ and
+ * the non-zeros are written in column order.  build_index emits CSR batch by batch this way and
+ * never holds the dense [N, V] matrix (retriever.py:281).                                        */
 VS_API int vs_dense_to_csr(const float* x, int32_t B, int32_t V, int64_t ld, int64_t* rowptr, int32_t* cols, float* vals,
                            int64_t cap, int device, void* stream);
 

@@ -95,6 +95,14 @@ struct DevBuf {
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
+// Small per-device scratch buffers that outlive a call (never freed: hipFree synchronises the device, and a
+// malloc/free pair per call costs more than the sparsify kernels themselves).  The library is driven by one host
+// thread; a slot is owned by one entry point.
+inline DevBuf& device_scratch(int device, int slot) {
+    static DevBuf* pool = new DevBuf[16 * 8];
+    return pool[(device & 15) * 8 + (slot & 7)];
+}
+
 // Copies `bytes` from src (host or device) into a device staging buffer if needed and returns a
 // device pointer usable on `stream`.
 inline int to_device(const void* src, size_t bytes, DevBuf& stage, hipStream_t stream, const void** out) {

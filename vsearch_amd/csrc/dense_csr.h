@@ -44,36 +44,61 @@ __global__ __launch_bounds__(kSpThreads) void count_nz_kernel(const float* x, in
     }
 }
 
+// rowptr = exclusive prefix sums of the per-row counts (ONE workgroup of kSpThreads threads; contiguous segment per thread)
 template <int UNUSED>
-__global__ void scan_counts_kernel(const int64_t* counts, int32_t B, int64_t* rowptr) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        int64_t acc = 0;
-        rowptr[0] = 0;
-        for (int b = 0; b < B; ++b) { acc += counts[b]; rowptr[b + 1] = acc; }
+__global__ __launch_bounds__(kSpThreads) void scan_counts_kernel(const int64_t* counts, int32_t B, int64_t* rowptr) {
+    __shared__ int64_t wave_tot[kSpThreads / 64];
+    if (blockIdx.x != 0) return;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int seg = (B + kSpThreads - 1) / kSpThreads;
+    const int i0 = min(B, tid * seg), i1 = min(B, i0 + seg);
+    int64_t mine = 0;
+    for (int i = i0; i < i1; ++i) mine += counts[i];
+    int64_t incl = mine;
+    for (int o = 1; o < 64; o <<= 1) {
+        const int64_t t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
     }
+    if (lane == 63) wave_tot[w] = incl;
+    __syncthreads();
+    int64_t pos = incl - mine;
+    for (int k = 0; k < w; ++k) pos += wave_tot[k];
+    for (int i = i0; i < i1; ++i) { rowptr[i] = pos; pos += counts[i]; }
+    if (i0 < B && i1 == B) rowptr[B] = pos;
 }
 
+// Ordered compaction, one workgroup per row, 1024 columns per step: coalesced reads, the position of a non-zero =
+// row base + non-zeros in earlier steps + earlier waves (LDS) + earlier lanes (ballot / mbcnt).
 template <int UNUSED>
 __global__ __launch_bounds__(kSpThreads) void fill_csr_kernel(const float* x, int64_t ld, int32_t B, int32_t V, const int64_t* rowptr,
                                                               int32_t* cols, float* vals, int64_t cap) {
-    __shared__ int scratch[32];
-    const int tid = threadIdx.x;
-    const int seg = (V + kSpThreads - 1) / kSpThreads;
+    __shared__ int wave_cnt[2][kSpThreads / 64];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
-        const int i0 = tid * seg, i1 = min(V, i0 + seg);
-        int c = 0;
-        for (int i = i0; i < i1; ++i) c += x[(size_t)b * ld + i] != 0.f;
-        int64_t pos = rowptr[b] + block_excl_scan(c, scratch, tid, nullptr);
-        for (int i = i0; i < i1; ++i) {
-            const float v = x[(size_t)b * ld + i];
-            if (v != 0.f) {
-                if (pos < cap) { cols[pos] = i; vals[pos] = v; }
-                ++pos;
+        int64_t base = rowptr[b];
+        int buf = 0;
+        for (int c0 = 0; c0 < V; c0 += kSpThreads, buf ^= 1) {
+            const int i = c0 + tid;
+            const float v = i < V ? x[(size_t)b * ld + i] : 0.f;
+            const bool nz = v != 0.f;
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(nz);
+            if (lane == 0) wave_cnt[buf][w] = __builtin_popcountll(bal);
+            __syncthreads();                                   // (double-buffered: one barrier per step)
+            int before = 0, total = 0;
+#pragma unroll
+            for (int k = 0; k < kSpThreads / 64; ++k) {
+                const int n = wave_cnt[buf][k];
+                before += k < w ? n : 0;
+                total += n;
             }
+            if (nz) {
+                const int64_t pos = base + before + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                if (pos < cap) { cols[pos] = i; vals[pos] = v; }
+            }
+            base += total;
         }
         __syncthreads();
     }
 }
-
 
 }  // namespace vs

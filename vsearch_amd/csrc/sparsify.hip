@@ -3,8 +3,8 @@
 // (retriever.py:304) and the encoder head's pooling tail (vdr.py:73-75).
 //
 // One workgroup per embedding row: the row (V = 29 523 fp32 = 118 KB) sits in LDS as order keys; the
-// k-th largest value is found by a 4-pass 8-bit radix select on LDS histograms; ties at the threshold
-// go to the lowest column ids (torch.topk leaves them unspecified).
+// k-th largest value is found by a 4-pass 8-bit radix select on lane-split LDS histograms; ties at the
+// threshold go to the lowest column ids (torch.topk leaves them unspecified).
 #include "common.h"
 #include "topk_keys.h"
 #include "dense_csr.h"
@@ -47,13 +47,31 @@ struct MaskArgs {
     int* flags;            // |1: token id out of range
 };
 
+// block-wide sum of one 64-bit value per thread (kSpThreads threads); red: kSpThreads / 64 slots in LDS
+__device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v, unsigned long long* red, int tid) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();                                   // the previous round's readers are done with `red`
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    unsigned long long tot = 0;
+#pragma unroll
+    for (int i = 0; i < kSpThreads / 64; ++i) tot += red[i];
+    return tot;
+}
+
+// One workgroup per row.  Global traffic is one coalesced read and one coalesced write of the row; the
+// select runs on the LDS copy (4-pass radix select, see below).  Ties at the threshold go to the lowest
+// columns (torch.topk leaves them open).
 __global__ __launch_bounds__(kSpThreads) void mask_rows_kernel(MaskArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint32_t* keys = reinterpret_cast<uint32_t*>(smem);                       // [V]
     const int vwords = (a.V + 31) / 32;
     uint32_t* lex = keys + ((a.V + 3) & ~3);                                   // [vwords] lexical bitmap
-    int* hist = reinterpret_cast<int*>(lex + ((vwords + 3) & ~3));             // [256]
-    int* scratch = hist + 256;                                                 // [32]
+    uint32_t* tie = lex + ((vwords + 3) & ~3);                                 // [vwords] threshold-valued columns that are selected
+    unsigned long long* red = reinterpret_cast<unsigned long long*>(tie + ((vwords + 3) & ~3));   // [16]
+    int* scratch = reinterpret_cast<int*>(red + kSpThreads / 64);              // [32]
+    int* sel_sh = scratch + 32;                                                // [4]
+    int* hist = sel_sh + 4;                                                    // [256 * 8]
     const int tid = threadIdx.x;
     const int seg = (a.V + kSpThreads - 1) / kSpThreads;
 
@@ -61,10 +79,10 @@ __global__ __launch_bounds__(kSpThreads) void mask_rows_kernel(MaskArgs a) {
         __syncthreads();
         const float* xr = a.x ? a.x + (size_t)b * a.ld : nullptr;
         const bool need_keys = !a.bow && a.topk > 0;
-        if (need_keys) for (int i = tid; i < a.V; i += kSpThreads) keys[i] = flip_f32(xr[i]);
-        for (int i = tid; i < vwords; i += kSpThreads) lex[i] = 0;
+        const bool need_vals = !a.bow && a.emb;                                // `emb *= mask` rewrites from the LDS copy
+        if (need_keys || need_vals) for (int i = tid; i < a.V; i += kSpThreads) keys[i] = flip_f32(xr[i]);
+        for (int i = tid; i < vwords; i += kSpThreads) { lex[i] = 0; tie[i] = 0; }
         __syncthreads();
-        int lex_count = 0;
         if (a.ids && (a.bow || a.activate_lexical)) {
             int bad = 0;
             for (int l = tid; l < a.L; l += kSpThreads) {
@@ -75,56 +93,61 @@ __global__ __launch_bounds__(kSpThreads) void mask_rows_kernel(MaskArgs a) {
             if (bad) atomicOr(a.flags, 1);
         }
         __syncthreads();
-        (void)lex_count;
 
-        // ---- radix select of the k-th largest key ----
-        uint32_t T = 0;          // threshold key
-        int r_eq = 0;            // how many elements equal to T are selected (lowest columns first)
+        uint32_t T = 0;          // k-th largest key
+        bool all_eq = true;      // every element equal to T is selected
         if (need_keys) {
+            // 4-pass MSD radix select, 8 bits per pass.  Histogram bins are split 8 ways by lane: the top byte of an
+            // order key is the fp32 exponent, the same for nearly every element of a row, and 64 lanes adding to ONE LDS
+            // address serialise; the bin holding the k-th key is found with a block scan over the 256 bins (descending).
             uint32_t prefix = 0, pmask = 0;
-            int remaining = a.topk;
+            int remaining = a.topk, n_eq = 0;
             for (int shift = 24; shift >= 0; shift -= 8) {
-                for (int i = tid; i < 256; i += kSpThreads) hist[i] = 0;
+                for (int i = tid; i < 256 * 8; i += kSpThreads) hist[i] = 0;
                 __syncthreads();
                 for (int i = tid; i < a.V; i += kSpThreads) {
                     const uint32_t kx = keys[i];
-                    if ((kx & pmask) == prefix) atomicAdd(&hist[(kx >> shift) & 255], 1);
+                    if ((kx & pmask) == prefix) atomicAdd(&hist[((kx >> shift) & 255u) * 8 + (tid & 7)], 1);
                 }
                 __syncthreads();
-                // every thread walks the 256 bins from the top (uniform result, no extra barrier data)
-                int acc = 0, digit = 0;
-                for (int d = 255; d >= 0; --d) {
-                    const int h = hist[d];
-                    if (acc + h >= remaining) { digit = d; break; }
-                    acc += h;
+                int h = 0;                                   // thread t < 256 owns bin 255 - t
+                if (tid < 256) {
+                    const int* hb = hist + (255 - tid) * 8;
+                    h = hb[0] + hb[1] + hb[2] + hb[3] + hb[4] + hb[5] + hb[6] + hb[7];
                 }
-                remaining -= acc;
-                prefix |= (uint32_t)digit << shift;
+                const int above = block_excl_scan(h, scratch, tid, nullptr);      // keys in strictly higher bins
+                if (tid < 256 && above < remaining && remaining <= above + h) { sel_sh[0] = 255 - tid; sel_sh[1] = above; sel_sh[2] = h; }
+                __syncthreads();
+                prefix |= (uint32_t)sel_sh[0] << shift;
                 pmask |= 255u << shift;
+                remaining -= sel_sh[1];
+                n_eq = sel_sh[2];
                 __syncthreads();
             }
             T = prefix;
-            r_eq = remaining;    // >= 1
-        }
-
-        // ---- rank of equal-to-threshold elements: contiguous segment per thread + block scan ----
-        const int i0 = tid * seg, i1 = min(a.V, i0 + seg);
-        int eq_before = 0;
-        if (need_keys) {
-            int my_eq = 0;
-            for (int i = i0; i < i1; ++i) my_eq += keys[i] == T;
-            eq_before = block_excl_scan(my_eq, scratch, tid, nullptr);
+            const int r_eq = remaining;                                         // >= 1 elements equal to T are selected
+            all_eq = n_eq == r_eq;
+            if (!all_eq) {       // rare: rank the equal elements by column (contiguous segment per thread + block scan)
+                const int i0 = tid * seg, i1 = min(a.V, i0 + seg);
+                int my_eq = 0;
+                for (int i = i0; i < i1; ++i) my_eq += keys[i] == T;
+                int before = block_excl_scan(my_eq, scratch, tid, nullptr);
+                for (int i = i0; i < i1; ++i)
+                    if (keys[i] == T) {
+                        if (before < r_eq) atomicOr(&tie[i >> 5], 1u << (i & 31));
+                        ++before;
+                    }
+                __syncthreads();
+            }
         }
         float bow_val = 1.0f;
         if (a.bow < 0) {         // bow with L2 normalisation: value = 1 / max(sqrt(count), 1e-12)
-            int c = 0;
+            unsigned long long c = 0;
             for (int i = tid; i < vwords; i += kSpThreads) c += __popc(lex[i]);
-            int total = 0;
-            block_excl_scan(c, scratch, tid, &total);
-            const float nrm = fmaxf(sqrtf((float)total), 1e-12f);
-            bow_val = 1.0f / nrm;
+            c = block_sum_u64(c, red, tid);
+            bow_val = 1.0f / fmaxf(sqrtf((float)c), 1e-12f);
         }
-        for (int i = i0; i < i1; ++i) {
+        for (int i = tid; i < a.V; i += kSpThreads) {
             const bool lx = (lex[i >> 5] >> (i & 31)) & 1u;
             bool sel;
             if (a.bow) sel = lx;
@@ -134,8 +157,7 @@ __global__ __launch_bounds__(kSpThreads) void mask_rows_kernel(MaskArgs a) {
                 else if (a.topk < 0) tk = true;
                 else {
                     const uint32_t kx = keys[i];
-                    tk = kx > T;
-                    if (kx == T) { tk = eq_before < r_eq; ++eq_before; }
+                    tk = kx > T || (kx == T && (all_eq || ((tie[i >> 5] >> (i & 31)) & 1u)));
                 }
                 sel = tk || (a.activate_lexical && lx);
             }
@@ -143,7 +165,7 @@ __global__ __launch_bounds__(kSpThreads) void mask_rows_kernel(MaskArgs a) {
             if (a.emb) {
                 float* e = a.emb + (size_t)b * a.ld + i;
                 if (a.bow) *e = sel ? bow_val : 0.f;
-                else if (!sel) *e = *e * 0.f;                  // `emb *= mask` (vdr.py:169)
+                else if (!sel) *e = unflip_f32(keys[i]) * 0.f;         // `emb *= mask` (vdr.py:169): x * 0 keeps NaN / sign like torch
             }
         }
     }
@@ -162,7 +184,7 @@ int check_device(int device) {
 
 size_t mask_lds_bytes(int V) {
     const int vwords = (V + 31) / 32;
-    return ((size_t)((V + 3) & ~3) + ((vwords + 3) & ~3) + 256 + 32) * 4;
+    return ((size_t)((V + 3) & ~3) + 2 * (size_t)((vwords + 3) & ~3) + 2 * (kSpThreads / 64) + 32 + 4 + 256 * 8) * 4;
 }
 
 // Runs mask_rows_kernel with host/device staging of emb / ids / mask.
@@ -170,9 +192,10 @@ int run_mask(MaskArgs a, const float* x_in, float* emb_io, const int64_t* ids, u
     VS_TRY(check_device(device));
     const size_t lds = mask_lds_bytes(a.V);
     if (lds > 160 * 1024) return fail(VS_EUNSUPPORTED, "V = %d needs %zu B of LDS (> 160 KiB)", a.V, lds);
-    DevBuf st_x, st_ids, st_mask, flags;
-    VS_TRY(flags.alloc(4));
-    VS_HIP(hipMemsetAsync(flags.p, 0, 4, s));
+    DevBuf st_x, st_ids, st_mask;
+    DevBuf& flags = device_scratch(device, 0);
+    VS_TRY(flags.reserve(4));
+    if (ids) VS_HIP(hipMemsetAsync(flags.p, 0, 4, s));
     a.flags = flags.as<int>();
     const size_t row_span = a.B > 0 ? ((size_t)(a.B - 1) * a.ld + a.V) * 4 : 0;
     const float* src = emb_io ? emb_io : x_in;
@@ -198,10 +221,14 @@ int run_mask(MaskArgs a, const float* x_in, float* emb_io, const int64_t* ids, u
     VS_HIP(hipGetLastError());
     if (emb_io && x_host) VS_HIP(hipMemcpyAsync(emb_io, st_x.p, row_span, hipMemcpyDeviceToHost, s));
     if (m_host) VS_HIP(hipMemcpyAsync(mask_out, st_mask.p, (size_t)a.B * a.V, hipMemcpyDeviceToHost, s));
-    int hflags = 0;
-    VS_HIP(hipMemcpyAsync(&hflags, flags.p, 4, hipMemcpyDeviceToHost, s));
-    VS_HIP(hipStreamSynchronize(s));
-    if (hflags & 1) return fail(VS_EINVAL, "token id out of range [0, %d)", a.vocab);
+    if (ids) {                     // a bad token id must surface as an error (the reference's scatter_ asserts on it)
+        int hflags = 0;
+        VS_HIP(hipMemcpyAsync(&hflags, flags.p, 4, hipMemcpyDeviceToHost, s));
+        VS_HIP(hipStreamSynchronize(s));
+        if (hflags & 1) return fail(VS_EINVAL, "token id out of range [0, %d)", a.vocab);
+    } else if (x_host || m_host || st_x.p || !s) {
+        VS_HIP(hipStreamSynchronize(s));                 // host buffers / staging die with this call; device-only + stream: asynchronous
+    }
     return VS_OK;
 }
 
@@ -272,41 +299,53 @@ extern "C" int vs_embed_mask(float* emb, int64_t ld, const int64_t* ids, int32_t
 extern "C" int vs_dense_to_csr(const float* x, int32_t B, int32_t V, int64_t ld, int64_t* rowptr, int32_t* cols, float* vals,
                                int64_t cap, int device, void* stream) {
     if (!x || !rowptr || B <= 0 || V <= 0 || ld < V) return fail(VS_EINVAL, "bad argument");
+    if ((cols == nullptr) != (vals == nullptr)) return fail(VS_EINVAL, "cols and vals must be given together");
     VS_TRY(check_device(device));
     hipStream_t s = (hipStream_t)stream;
-    DevBuf st_x, counts, d_rp, st_c, st_v;
+    DevBuf st_x, st_c, st_v;
     const void* dx = nullptr;
     VS_TRY(to_device(x, ((size_t)(B - 1) * ld + V) * 4, st_x, s, &dx));
-    VS_TRY(counts.alloc((size_t)B * 8));
-    VS_TRY(d_rp.alloc((size_t)(B + 1) * 8));
-    hipLaunchKernelGGL(count_nz_kernel<0>, dim3(std::min(B, 2048)), dim3(kSpThreads), 0, s, (const float*)dx, ld, B, V, counts.as<int64_t>());
-    hipLaunchKernelGGL(scan_counts_kernel<0>, dim3(1), dim3(64), 0, s, counts.as<int64_t>(), B, d_rp.as<int64_t>());
-    VS_HIP(hipGetLastError());
-    std::vector<int64_t> rp((size_t)B + 1);
-    VS_HIP(hipMemcpyAsync(rp.data(), d_rp.p, rp.size() * 8, hipMemcpyDeviceToHost, s));
-    VS_HIP(hipStreamSynchronize(s));
-    if (is_device_ptr(rowptr)) VS_HIP(hipMemcpyAsync(rowptr, d_rp.p, rp.size() * 8, hipMemcpyDeviceToDevice, s));
-    else memcpy(rowptr, rp.data(), rp.size() * 8);
-    if (cols && vals) {
-        const int64_t nnz = rp[B];
-        if (nnz > cap) return fail(VS_EINVAL, "capacity %lld < nnz %lld", (long long)cap, (long long)nnz);
-        const bool o_host = !is_device_ptr(cols);
-        int32_t* dc = cols;
-        float* dv = vals;
-        if (o_host) {
-            VS_TRY(st_c.alloc(std::max<size_t>((size_t)nnz * 4, 4)));
-            VS_TRY(st_v.alloc(std::max<size_t>((size_t)nnz * 4, 4)));
-            dc = st_c.as<int32_t>();
-            dv = st_v.as<float>();
-        }
-        hipLaunchKernelGGL(fill_csr_kernel<0>, dim3(std::min(B, 2048)), dim3(kSpThreads), 0, s, (const float*)dx, ld, B, V, d_rp.as<int64_t>(), dc, dv, nnz);
+    DevBuf& counts = device_scratch(device, 1);
+    DevBuf& d_rp = device_scratch(device, 2);
+    VS_TRY(counts.reserve((size_t)B * 8));
+    VS_TRY(d_rp.reserve((size_t)(B + 1) * 8));
+    const bool rp_dev = is_device_ptr(rowptr);
+    if (!cols) {
+        // sizing call: rowptr out
+        hipLaunchKernelGGL(count_nz_kernel<0>, dim3(std::min(B, 2048)), dim3(kSpThreads), 0, s, (const float*)dx, ld, B, V, counts.as<int64_t>());
+        int64_t* rp_out = rp_dev ? rowptr : d_rp.as<int64_t>();
+        hipLaunchKernelGGL(scan_counts_kernel<0>, dim3(1), dim3(kSpThreads), 0, s, counts.as<int64_t>(), B, rp_out);
         VS_HIP(hipGetLastError());
-        if (o_host && nnz > 0) {
-            VS_HIP(hipMemcpyAsync(cols, dc, (size_t)nnz * 4, hipMemcpyDeviceToHost, s));
-            VS_HIP(hipMemcpyAsync(vals, dv, (size_t)nnz * 4, hipMemcpyDeviceToHost, s));
+        if (!rp_dev) {
+            VS_HIP(hipMemcpyAsync(rowptr, d_rp.p, (size_t)(B + 1) * 8, hipMemcpyDeviceToHost, s));
+            VS_HIP(hipStreamSynchronize(s));
+        } else if (st_x.p || !s) {
+            VS_HIP(hipStreamSynchronize(s));
         }
+        return VS_OK;
     }
-    VS_HIP(hipStreamSynchronize(s));
+    // fill call: rowptr (from the sizing call) in, cols / vals out
+    const int64_t* rp_in = rowptr;
+    if (!rp_dev) {
+        VS_HIP(hipMemcpyAsync(d_rp.p, rowptr, (size_t)(B + 1) * 8, hipMemcpyHostToDevice, s));
+        rp_in = d_rp.as<int64_t>();
+    }
+    const bool o_host = !is_device_ptr(cols);
+    int32_t* dc = cols;
+    float* dv = vals;
+    if (o_host) {
+        VS_TRY(st_c.alloc(std::max<size_t>((size_t)cap * 4, 4)));
+        VS_TRY(st_v.alloc(std::max<size_t>((size_t)cap * 4, 4)));
+        dc = st_c.as<int32_t>();
+        dv = st_v.as<float>();
+    }
+    hipLaunchKernelGGL(fill_csr_kernel<0>, dim3(std::min(B, 2048)), dim3(kSpThreads), 0, s, (const float*)dx, ld, B, V, rp_in, dc, dv, cap);
+    VS_HIP(hipGetLastError());
+    if (o_host && cap > 0) {
+        VS_HIP(hipMemcpyAsync(cols, dc, (size_t)cap * 4, hipMemcpyDeviceToHost, s));
+        VS_HIP(hipMemcpyAsync(vals, dv, (size_t)cap * 4, hipMemcpyDeviceToHost, s));
+    }
+    if (o_host || !rp_dev || st_x.p || !s) VS_HIP(hipStreamSynchronize(s));
     return VS_OK;
 }
 
