@@ -936,11 +936,12 @@ extern "C" int vs_merge_topk(const int64_t* cand_ids, const float* cand_scores, 
     VS_HIP(hipSetDevice(device));
     hipStream_t s = (hipStream_t)stream;
     const size_t n = (size_t)B * n_cand;
-    DevBuf st_ids, st_sc, keys, o_ids, o_sc;
+    DevBuf st_ids, st_sc, o_ids, o_sc;
+    DevBuf& keys = device_scratch(device, 3);                 // kept between calls: the sharded search merges once per batch
     const void *d_ids = nullptr, *d_sc = nullptr;
     VS_TRY(to_device(cand_ids, n * 8, st_ids, s, &d_ids));
     VS_TRY(to_device(cand_scores, n * 4, st_sc, s, &d_sc));
-    VS_TRY(keys.alloc(n * 8));
+    VS_TRY(keys.reserve(n * 8));
     hipLaunchKernelGGL(keys_from_pairs_kernel, dim3((unsigned)std::min<int64_t>(ceil_div64((int64_t)n, 256), 4096)), dim3(256), 0, s,
                        (const int64_t*)d_ids, (const float*)d_sc, (int64_t)n, keys.as<uint64_t>());
     VS_HIP(hipGetLastError());
@@ -969,7 +970,7 @@ extern "C" int vs_merge_topk(const int64_t* cand_ids, const float* cand_scores, 
         VS_HIP(hipMemcpyAsync(out_ids, di, (size_t)B * k * 8, hipMemcpyDeviceToHost, s));
         VS_HIP(hipMemcpyAsync(out_scores, ds, (size_t)B * k * 4, hipMemcpyDeviceToHost, s));
     }
-    VS_HIP(hipStreamSynchronize(s));                          // temporaries die here
+    if (!out_dev || st_ids.p || st_sc.p || !s) VS_HIP(hipStreamSynchronize(s));      // host buffers / staging die here
     return VS_OK;
 }
 

@@ -507,8 +507,8 @@ extern "C" int vs_head_project_pool(const float* hidden, const float* W, int32_t
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { (void)hipGetLastError(); return fail(VS_ENODEVICE, "no HIP device visible"); }
     VS_HIP(hipSetDevice(device));
     hipStream_t s = (hipStream_t)stream;
-    DevBuf keys;
-    VS_TRY(keys.alloc((size_t)B * V * 4));
+    DevBuf& keys = device_scratch(device, 4);                            // kept between calls: one per encoder batch
+    VS_TRY(keys.reserve((size_t)B * V * 4));
     VS_HIP(hipMemsetAsync(keys.p, 0, (size_t)B * V * 4, s));            // key 0 < key of any real number
     {
         ProfScope prof("head_project_pool", s);
@@ -526,7 +526,7 @@ extern "C" int vs_head_project_pool(const float* hidden, const float* W, int32_t
     hipLaunchKernelGGL(pool_finish_kernel, dim3((unsigned)std::min<int64_t>(ceil_div64((int64_t)B * V, 256), 8192)), dim3(256), 0, s, keys.as<uint32_t>(),
                        (int64_t)B * V, out);
     VS_HIP(hipGetLastError());
-    VS_HIP(hipStreamSynchronize(s));                                     // `keys` is freed on return
+    if (!s) VS_HIP(hipStreamSynchronize(s));                             // with a stream the call is asynchronous
     return VS_OK;
 }
 
