@@ -443,3 +443,21 @@ def test_native_shard_file_roundtrip(tmp_path):
     (tmp_path / "bad.vsx").write_bytes(b"not a shard file")
     with pytest.raises(ValueError, match="native shard"):
         SparseIndex(str(tmp_path / "bad.vsx"), None, device="cuda")
+
+
+def test_retireve_negatives(tiny_retriever):
+    """In-training hard negatives (retriever.py:150-206): hits containing an answer string are skipped; short pools are padded."""
+    r = tiny_retriever
+    texts = make_texts(40, 7)
+    r.build_index(texts, batch_size=16, index_type=IndexType.SPARSE)
+    q_emb = r.encoder_q.embed(texts[:3], batch_size=3, topk=32)
+    top = r.retrieve(q_emb, k=5, a=768).ids.cpu().numpy()
+    answers = [[texts[int(top[i, 0])].split()[3]] for i in range(3)]          # a token of the best hit = the "answer"
+    negs = r.retireve_negatives(q_emb, answers, ret_neg_num=2, ret_topk=20, pool_size=6)
+    assert len(negs) == 3 and all(len(n) == 2 for n in negs)
+    from vsearch_amd.inference.score.eval_wiki21m import has_answer
+    for a, ns in zip(answers, negs):
+        assert all(n in texts and not has_answer(a, n, "string") for n in ns)
+    everything = [[t.split()[1] for t in texts]] * 3                            # every passage "answers": pool empty -> random padding
+    padded = r.retrieve_negatives(q_emb, everything, ret_neg_num=3, ret_topk=10)
+    assert all(len(n) == 3 and all(x in texts for x in n) for n in padded)
