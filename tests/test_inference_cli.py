@@ -53,6 +53,11 @@ def test_build_search_eval_end_to_end(tmp_path):
                                     f"--save_file={tmp_path/'res.json'}", "--topk=5"])
     assert [r["ids"][0] for r in res] == [3, 17, 29]
     assert json.load(open(tmp_path / "res.json"))[0]["question"] == queries[0]
+    from vsearch_amd.inference.build_index import convert_index               # npz shards -> one native shard file -> same results
+    convert_index.main([f"--index_file={tmp_path}/index*.npz", f"--save_file={tmp_path/'all.vsx'}", "--fp32"])
+    res_v = search_sparse_index.main([f"--checkpoint={ck}", f"--query_file={tmp_path/'q.jsonl'}", f"--index_file={tmp_path/'all.vsx'}",
+                                      f"--save_file={tmp_path/'res_v.json'}", "--topk=5"])
+    assert [r["ids"] for r in res_v] == [r["ids"] for r in res]
     (tmp_path / "qa.csv").write_text("".join(f"{q}\t{[docs[i].split()[3]]!r}\n" for q, i in zip(queries, (3, 17, 29))))
     from vsearch_amd.inference.score import eval_wiki21m
     acc = eval_wiki21m.main([f"--result_file={tmp_path/'res.json'}", f"--text_file={tmp_path/'corpus.jsonl'}", f"--qa_file={tmp_path/'qa.csv'}"])
