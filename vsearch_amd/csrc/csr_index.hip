@@ -727,7 +727,7 @@ int mq_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64_t id_o
     const int64_t rows_per_chunk = ceil_div64(idx->n_rows, nchunk);
     const int64_t items = (int64_t)n_tiles * nchunk;
     const int grid = (int)std::min<int64_t>(items, idx->cu_count);
-    VS_TRY(idx->ws_mq_cand.reserve((size_t)grid * kQT * kMqCap * 8 + (size_t)grid * kQT * 4));
+    VS_TRY(idx->ws_mq_cand.reserve((size_t)grid * kQT * kMqCap * 8));
     VS_TRY(idx->ws_cand.reserve((size_t)B * nchunk * k * 8));
     MqArgs a{};
     a.pk_ptr = idx->pk_ptr.as<uint32_t>();
@@ -746,7 +746,6 @@ int mq_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64_t id_o
     a.vals_cap = vals_cap;
     a.cand = idx->ws_cand.as<uint64_t>();
     a.gcand = idx->ws_mq_cand.as<uint64_t>();
-    a.gcnt = reinterpret_cast<uint32_t*>(a.gcand + (size_t)grid * kQT * kMqCap);
     a.upper = col0 > 0 ? upper : nullptr;
     const size_t lds = mq_fixed_lds_bytes<kQT>(V, mq_acc_rows(idx)) + (size_t)vals_cap * 4;
     {

@@ -4,15 +4,16 @@
 // side.  A dense fp32 image of one query fills 118 KB of LDS, so Qt = 1.  Queries on this path are
 // sparse (768 + lexical dims out of V = 29 523), so the tile is kept as
 //     tab[c]  (uint32, c in [0, V]):  low QT bits = which queries of the tile have weight at column c,
-//                                     high bits   = offset of column c's weights in `vals`
-//     vals[]  (fp32): the tile's non-zero weights, grouped by column, ordered by query slot
-// One LDS gather per index non-zero answers "does any of the QT queries touch this column?".  The hit
-// bits of a lane's 8-nnz packet are packed into one 64-bit word; only lanes with hits (~2.6 % x QT per
-// nnz) walk that word -- one hit per iteration: pick the packet position (select tree), fetch the
-// weight and add the product into the row's accumulator.  Accumulators are doubles in LDS
-// (ds_add_f64, a few copies per row to keep lanes off the same address): fp32 x fp32 products are
-// exact in fp64, so a score is the correctly rounded sum whatever the order of the adds --
-// reproducible, and bit-identical to the oracle's fp64-accumulated scores.
+//                                     high bits   = LDS byte address of column c's weights (0 = unused column)
+//     qv[]    (fp32): the tile's non-zero weights, grouped by column, ordered by query slot
+// One LDS gather per index non-zero answers "does any of the QT queries touch this column?".  A position
+// hits with p ~ 0.026 x QT and most hits are single, so packet positions are paired (i, i + 4): the two
+// masks of a pair form a 16-bit hit word whose lowest set bit is served by straight-line, exec-masked
+// code (one weight fetch + one ds_add_f64 per pair, four independent chains per packet); the remaining
+// bits go through short loops, one hit per lane per trip.  Accumulators are doubles in LDS (ds_add_f64,
+// a few copies per row to keep lanes off the same address): an fp32 x fp32 product is exact in fp64 and
+// the fp64 sum of <= 2^16 of them carries ~29 spare bits, so the fp32 score does not depend on the order
+// of the adds -- reproducible, and equal to the oracle's fp64-accumulated score.
 //
 // Top-k: per (workgroup, query slot) candidate keys go to an L2-resident global buffer (appends
 // become rare once the k-th-best threshold tightens); every kMqSuperRows rows the workgroup meets
@@ -96,8 +97,7 @@ struct MqArgs {
     int32_t n_tiles;
     int32_t vals_cap;         // LDS capacity for tile weights (entries)
     uint64_t* cand;           // [B, nchunk, k] output keys, sorted descending
-    uint64_t* gcand;          // [grid, QT, kMqCap] scratch
-    uint32_t* gcnt;           // [grid, QT] scratch counters
+    uint64_t* gcand;          // [grid, QT, kMqCap] scratch (candidate keys; the counters live in LDS)
     const uint64_t* upper;    // optional [B]: only keys < upper[b] take part ("search after": passes beyond the first when k > kMaxKMq)
 };
 
