@@ -38,6 +38,7 @@ class BiEncoder(PreTrainedModel):
         else:
             self.encoder_p = encoder_p if encoder_p is not None else self._make_tower(config.encoder_p)
         self.default_batch_size = None
+        self.post_init()                                   # transformers >= 5: from_pretrained relies on the bookkeeping done here
 
     @staticmethod
     def _make_tower(cfg: Dict[str, any]):

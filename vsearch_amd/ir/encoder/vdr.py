@@ -50,6 +50,7 @@ class VDREncoder(PreTrainedModel):
             self.bert_model = AutoModel.from_pretrained(config.model_id, add_pooling_layer=False)
         self.tokenizer = tokenizer if tokenizer is not None else (
             None if getattr(config, "random_init", False) else AutoTokenizer.from_pretrained(config.model_id))
+        self.post_init()
 
     # -- helpers -------------------------------------------------------------------------------------
     def build_bow_mask(self, input_ids):
