@@ -562,6 +562,24 @@ ScanPlan plan_scan(const vs_index* idx, int B) {
     return p;
 }
 
+// Row chunks for `units` concurrent scans (query tiles, or single queries on the Qt = 1 path).  Work items = units x
+// chunks.  Every item pays a table / image build and top-k sorts, and -- more important -- workgroups that sweep the
+// SAME rows at the same time for different units share the stream through L2 / Infinity Cache, so chunks are as few
+// and as long as still fill the CUs: many units -> 1-2 chunks, one unit -> one chunk per CU.
+int choose_chunks(const vs_index* idx, int units, int max_nchunk) {
+    const int cus = idx->cu_count;
+    const int max_chunks = (int)std::max<int64_t>(1, std::min<int64_t>(max_nchunk, idx->n_rows / 512));
+    int best = std::min(max_chunks, std::max(1, (cus + units - 1) / units));
+    double best_eff = 0.0;
+    for (int c = best; c <= max_chunks; ++c) {
+        const int64_t it = (int64_t)units * c;
+        const double eff = (double)it / (double)(((it + cus - 1) / cus) * cus);          // fill of the last round
+        if (eff > best_eff + 1e-9) { best_eff = eff; best = c; }
+        if (eff >= 0.92) break;
+    }
+    return best;
+}
+
 template <int G, int VM>
 int launch_scan_g(int mode, const ScanArgs& a, int grid, size_t lds, hipStream_t s) {
     // mode 0: scores, 1: wave top-k, 2: shared top-k
@@ -707,23 +725,8 @@ int mq_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64_t id_o
     float* qvals = reinterpret_cast<float*>(qcols + qnnz);
     hipLaunchKernelGGL(fill_csr_kernel<0>, dim3(std::min(B, 2048)), dim3(kSpThreads), 0, s, dq, (int64_t)V, B, V, qptr, qcols, qvals, qnnz);
     VS_HIP(hipGetLastError());
-    // 2. scan.  Work items = (tile, row chunk).  Every item pays a table build and top-k sorts, so chunks are as
-    // long as the machine allows: with many tiles the rows are cut into few chunks (each workgroup streams a long
-    // row range for its own tile), with few tiles into up to one chunk per CU.
-    int nchunk = plan.nchunk;
-    {
-        const int cus = idx->cu_count;
-        const int max_chunks = (int)std::max<int64_t>(1, std::min<int64_t>(plan.nchunk, idx->n_rows / 512));
-        int best = std::min(max_chunks, std::max(1, (cus + n_tiles - 1) / n_tiles));
-        double best_eff = 0.0;
-        for (int c = best; c <= max_chunks; ++c) {
-            const int64_t it = (int64_t)n_tiles * c;
-            const double eff = (double)it / (double)(((it + cus - 1) / cus) * cus);      // fill of the last round
-            if (eff > best_eff + 1e-9) { best_eff = eff; best = c; }
-            if (eff >= 0.92) break;
-        }
-        nchunk = best;
-    }
+    // 2. scan.  Work items = (tile, row chunk)
+    const int nchunk = choose_chunks(idx, n_tiles, plan.nchunk);
     const int64_t rows_per_chunk = ceil_div64(idx->n_rows, nchunk);
     const int64_t items = (int64_t)n_tiles * nchunk;
     const int grid = (int)std::min<int64_t>(items, idx->cu_count);
@@ -845,6 +848,9 @@ int vs_csr_search(vs_index* idx, const void* q, int q_dtype, int64_t ldq, int32_
     const size_t per_q = (size_t)plan.nchunk * kk_max * 8;
     const int bs_max = (int)std::max<size_t>(1, std::min<size_t>((size_t)B, ((size_t)512 << 20) / per_q));
     VS_TRY(idx->ws_cand.reserve(per_q * bs_max));
+    // few, long row chunks when many queries run side by side (they share the index stream on chip)
+    const int nchunk1 = choose_chunks(idx, std::min(B, bs_max), plan.nchunk);
+    const int64_t rows_per_chunk1 = ceil_div64(idx->n_rows, nchunk1);
     for (int pass = 0; pass < passes; ++pass) {
         const int col0 = pass * kMaxKShared;
         const int kk = std::min(k - col0, kMaxKShared);
@@ -859,15 +865,15 @@ int vs_csr_search(vs_index* idx, const void* q, int q_dtype, int64_t ldq, int32_
             a.n_cols = idx->n_cols;
             a.B = bs;
             a.k = kk;
-            a.nchunk = plan.nchunk;
-            a.rows_per_chunk = plan.rows_per_chunk;
+            a.nchunk = nchunk1;
+            a.rows_per_chunk = rows_per_chunk1;
             a.cand = idx->ws_cand.as<uint64_t>();
             a.upper = passes > 1 ? upper.as<uint64_t>() + b0 : nullptr;
-            const int grid = (int)std::min<int64_t>((int64_t)bs * plan.nchunk, idx->cu_count);
+            const int grid = (int)std::min<int64_t>((int64_t)bs * nchunk1, idx->cu_count);
             VS_TRY(launch_scan(idx, kk <= kMaxKWave ? 1 : 2, a, grid, s));
             MergeArgs m{};
             m.cand = a.cand;
-            m.n_cand = (int64_t)plan.nchunk * kk;
+            m.n_cand = (int64_t)nchunk1 * kk;
             m.B = bs;
             m.k = kk;
             m.id_offset = id_offset;
