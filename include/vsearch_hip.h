@@ -138,9 +138,16 @@ VS_API int  vs_index_info(const vs_index* index, vs_index_info_t* out);
 /* Scan selection (tuning / tests; no reference counterpart): 0 = auto -- score tiles of 8 sparse queries
  * per pass over the index when every query is sparse enough for the LDS tile tables (512 ranks per
  * pass; larger k takes several passes), else one query per pass with a dense fp32 query image;
- * 1 = always the latter.  Environment variable VS_MQ_MODE = 0 | 1 (tests only) forces the plain /
- * shared-column variant of the 8-query kernel instead of choosing from the batch's query overlap. */
+ * 1 = always the latter.                                                                          */
 VS_API int  vs_index_set_queries_per_pass(vs_index* index, int qt);
+
+/* Tuning / test options by name (no reference counterpart):
+ *   "queries_per_pass"  as above
+ *   "blocked_postings"  -1 = auto (long-row valued indexes, when HBM has room for the second copy), 0 = off, 1 = on:
+ *                       sparse queries are scored from a row-blocked, column-grouped copy of the index that is built on
+ *                       first use -- a query tile reads only the posting lists of its own columns
+ *   "mq_variant"        -1 = auto (from the batch's query overlap), 0 = plain, 1 = shared-column variant of the 8-query scan */
+VS_API int  vs_index_set_option(vs_index* index, const char* name, int value);
 
 /* SparseIndex.save (index.py:181-202) needs crow/col/values back: int64 rowptr [n_rows+1], int64
  * colidx [nnz], values [nnz] as val_dtype (VS_F32 | VS_F16).  Pass NULL colidx/values to get rowptr

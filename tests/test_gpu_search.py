@@ -403,7 +403,7 @@ def _zipf_csr(rng, n, nnz, s, perm, binary=False, dyadic=False):
 
 @pytest.mark.parametrize("binary", [False, True], ids=["fp32", "binary-dyadic"])
 @pytest.mark.parametrize("s", [0.75, 1.2])
-def test_skewed_column_popularity_shared_column_variant(monkeypatch, s, binary):
+def test_skewed_column_popularity_shared_column_variant(s, binary):
     """Head columns shared by most queries AND most documents (SURVEY §8(d) 'Zipf column popularity' run): the
     multi-query pass switches to its shared-column variant; both variants must agree with the oracle."""
     rng = np.random.default_rng(5)
@@ -416,11 +416,9 @@ def test_skewed_column_popularity_shared_column_variant(monkeypatch, s, binary):
     idx = DeviceIndex.from_csr(ip, ix, d, V)
     o_ids, o_sc, allsc = oracle.csr_search(ip, ix, d, V, q, 50, acc64=True, return_all=True)
     res = {}
+    idx.set_option("blocked_postings", 0)
     for forced in ("0", "1", None):                               # kernel variants: pairs, shared columns; auto
-        if forced is None:
-            monkeypatch.delenv("VS_MQ_MODE", raising=False)
-        else:
-            monkeypatch.setenv("VS_MQ_MODE", forced)
+        idx.set_option("mq_variant", -1 if forced is None else int(forced))
         ids, sc = idx.search(q, 50)
         assert idx.info().queries_per_pass == 8
         res[forced] = (ids, sc)
@@ -455,11 +453,10 @@ def test_small_batch_many_chunks_merge_prefilter(B, k):
     assert set(ids[0, :min(k, 100)]) <= set(range(600))
 
 
-@pytest.mark.parametrize("mode", ["0", "1"], ids=["pairs", "shared-columns"])
+@pytest.mark.parametrize("mode", ["0", "1", "bp"], ids=["pairs", "shared-columns", "blocked-postings"])
 @pytest.mark.parametrize("store", [nat.VS_F32, nat.VS_F16, nat.VS_NONE], ids=["fp32", "fp16", "binary"])
-def test_multi_query_kernel_variants_agree_with_oracle(monkeypatch, mode, store):
+def test_multi_query_kernel_variants_agree_with_oracle(mode, store):
     """Every variant of the Qt = 8 pass, forced, on ragged rows (0..2000 nnz) and a ragged batch (11 queries)."""
-    monkeypatch.setenv("VS_MQ_MODE", mode)
     rng = np.random.default_rng(3)
     n = 3000
     lens = rng.integers(0, 200, size=n)
@@ -476,7 +473,12 @@ def test_multi_query_kernel_variants_agree_with_oracle(monkeypatch, mode, store)
             d = d.astype(np.float16).astype(np.float32)
     q = oracle.synth_queries(1, 11, val_law=synth.VAL_DYADIC if store != nat.VS_F32 else synth.VAL_GRID)
     idx = DeviceIndex.from_csr(ip, ix, d, V, store_dtype=store) if store != nat.VS_NONE else DeviceIndex.from_csr(ip, ix, None, V)
-    for k in (1, 64, 300):
+    if mode == "bp":
+        idx.set_option("blocked_postings", 1)
+    else:
+        idx.set_option("blocked_postings", 0)
+        idx.set_option("mq_variant", int(mode))
+    for k in (1, 64, 300, 1100):
         ids, sc = idx.search(q, k)
         assert idx.info().queries_per_pass == 8
         o_ids, o_sc, allsc = oracle.csr_search(ip, ix, d, V, q, k, acc64=True, return_all=True)

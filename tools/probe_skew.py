@@ -44,11 +44,9 @@ def main():
         q = torch.zeros((B, V), device="cuda")
         q.scatter_(1, qc, 0.01 + 3 * torch.rand(qc.shape, device="cuda", generator=gen))
         del cols, vals
-        for qt, shared in ((0, "0"), (0, "1"), (0, None), (1, None)):
-            if shared is None:
-                os.environ.pop("VS_MQ_MODE", None)
-            else:
-                os.environ["VS_MQ_MODE"] = shared
+        for qt, shared in ((0, "0"), (0, "1"), (0, None), (0, "bp"), (1, None)):
+            idx.set_option("blocked_postings", 1 if shared == "bp" else 0)
+            idx.set_option("mq_variant", int(shared) if shared in ("0", "1") else -1)
             idx.set_queries_per_pass(qt)
             idx.search(q, K)
             torch.cuda.synchronize(); t = time.time()

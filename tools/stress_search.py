@@ -64,12 +64,10 @@ def run(budget=120.0, seed0=0):
         k = int(min(n, rng.choice([1, 5, 100, 257, 600, 2100])))
         idx = DeviceIndex.from_csr(ip, ix, d, V, store_dtype=store) if d is not None else DeviceIndex.from_csr(ip, ix, None, V)
         allsc = idx.scores(q)
-        for mode in ("0", "1", None):
+        for mode in ("0", "1", "bp", None):
             for qt in (0, 1):
-                if mode is None:
-                    os.environ.pop("VS_MQ_MODE", None)
-                else:
-                    os.environ["VS_MQ_MODE"] = mode
+                idx.set_option("blocked_postings", 1 if mode == "bp" else (0 if mode in ("0", "1") else -1))
+                idx.set_option("mq_variant", int(mode) if mode in ("0", "1") else -1)
                 idx.set_queries_per_pass(qt)
                 ids, sc = idx.search(q, k)
                 try:
@@ -85,7 +83,6 @@ def run(budget=120.0, seed0=0):
         it += 1
         if it % 10 == 0:
             print(f"{it} cases ok", flush=True)
-    os.environ.pop("VS_MQ_MODE", None)
     print(f"stress ok: {it} random cases", flush=True)
     return it
 

@@ -45,6 +45,7 @@ _SIGNATURES = {
     "vs_index_search": ([_vp, _vp, _int, _i64, _i32, _i32, _i64, _vp, _vp, _vp], _int),
     "vs_index_scores": ([_vp, _vp, _int, _i64, _i32, _vp, _vp], _int),
     "vs_index_info": ([_vp, C.POINTER(IndexInfo)], _int),
+    "vs_index_set_option": ([_vp, C.c_char_p, _int], _int),
     "vs_index_set_queries_per_pass": ([_vp, _int], _int),
     "vs_index_export_csr": ([_vp, _vp, _vp, _vp, _int], _int),
     "vs_index_export_dense": ([_vp, _vp, _int, _i64], _int),

@@ -1,6 +1,8 @@
 // api.hip -- library-level entry points and the kind dispatch of Index.search (index.py:88-94).
 #include "common.h"
 
+#include <string>
+
 using namespace vs;
 
 int vs_csr_search(vs_index*, const void*, int, int64_t, int32_t, int32_t, int64_t, int64_t*, float*, hipStream_t);
@@ -64,6 +66,25 @@ extern "C" int vs_index_set_queries_per_pass(vs_index* idx, int qt) {
     if (qt != 0 && qt != 1) return fail(VS_EINVAL, "queries_per_pass: 0 = auto, 1 = dense-image pass");
     idx->qt_pref = qt;
     return VS_OK;
+}
+
+extern "C" int vs_index_set_option(vs_index* idx, const char* name, int value) {
+    if (!idx || !name) return fail(VS_EINVAL, "NULL argument");
+    const std::string n(name);
+    if (n == "queries_per_pass") return vs_index_set_queries_per_pass(idx, value);
+    if (n == "blocked_postings") {
+        if (value < -1 || value > 1) return fail(VS_EINVAL, "blocked_postings: -1 = auto, 0 = off, 1 = on");
+        idx->bp_pref = value;
+        if (value == 0) { idx->bp_dir.release(); idx->bp_doc.release(); idx->bp_val.release(); idx->bp_ready = false; }
+        idx->bp_tried = false;
+        return VS_OK;
+    }
+    if (n == "mq_variant") {
+        if (value < -1 || value > 1) return fail(VS_EINVAL, "mq_variant: -1 = auto, 0 = plain, 1 = shared columns");
+        idx->mq_variant = value;
+        return VS_OK;
+    }
+    return fail(VS_EINVAL, "unknown option '%s'", name);
 }
 
 extern "C" int vs_profile_enable(int on) {

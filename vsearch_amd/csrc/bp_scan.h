@@ -1,0 +1,312 @@
+// bp_scan.h -- "blocked postings": a second, column-grouped copy of a long-row CSR index for SPARSE queries.
+//
+// The CSR scan (csr_scan_mq.h) looks every index non-zero up in the tile table, although only ~2.6 % x Qt of
+// them carry a query weight -- and at Qt = 8 that lookup + hit handling (VALU issue), not HBM, bounds the pass.
+// Here the rows are cut into blocks of kBpRows documents; inside a block the non-zeros are grouped by column
+// (dir[b][c] .. dir[b][c+1] = the postings (document-in-block uint16, value) of column c).  A query tile then
+// walks ONLY the posting lists of its own columns: every visited non-zero is a hit, the lanes of a 16-lane group
+// read one list with contiguous loads, and the products go to fp64 accumulators [document][query slot] in LDS
+// (same numerics as the CSR pass: fp32 product, fp64 sum, order-independent).  One block = 1024 documents x 8
+// queries of accumulators (64 KB); after each block a thread finishes one document (8 sums -> order keys ->
+// candidate buffers), exactly like the per-row epilogue of the CSR pass.  Bytes read per tile = the tile's
+// share of the postings (~21 % of the index at 8 x 776 query non-zeros) + the directory entries.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+#include "csr_scan.h"
+#include "dense_csr.h"
+
+namespace vs {
+
+constexpr int kBpRows = 1024;         // documents per block (= threads per workgroup: one document per thread at block end)
+constexpr int kBpCap = 2048;          // candidate slots per (workgroup, query slot)
+constexpr int kBpMaxK = kBpCap - kBpRows;
+constexpr int kBpGroup = 4;           // lanes walking one posting list, 8 consecutive postings (16-byte loads) per lane and round
+constexpr int kBpBatch = 4;           // posting lists whose loads are in flight together per group (the walk is latency-bound otherwise)
+
+// First posting of block b: room for the block's non-zeros (its packets x 8) plus one pad posting per column.
+__host__ __device__ inline size_t bp_block_base(uint32_t first_packet, int64_t b, int32_t n_cols) {
+    return (size_t)first_packet * 8 + (size_t)b * (size_t)((n_cols + 2) & ~1);
+}
+__host__ __device__ inline size_t bp_postings_capacity(int64_t n_packets, int64_t n_blocks, int32_t n_cols) {
+    return (size_t)n_packets * 8 + (size_t)n_blocks * (size_t)((n_cols + 2) & ~1) + 64;      // + slack: the scan's 16-byte loads may run past a list
+}
+
+// ---- builder: one workgroup per block; counts per column -> directory -> scatter ----------------------
+template <int VM>
+__global__ __launch_bounds__(kScanThreads) void bp_build_kernel(const uint32_t* pk_ptr, const uint4* cols, const void* vals, int64_t n_rows,
+                                                                int32_t n_cols, uint32_t* dir, uint16_t* pdoc, void* pval) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(smem);                  // [n_cols + 1]
+    __shared__ int scratch[32];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int64_t n_blocks = (n_rows + kBpRows - 1) / kBpRows;
+    const int seg = (n_cols + 1 + kScanThreads - 1) / kScanThreads;
+    for (int64_t b = blockIdx.x; b < n_blocks; b += gridDim.x) {
+        const int64_t r0 = b * kBpRows, r1 = min(n_rows, r0 + kBpRows);
+        const uint32_t P0 = pk_ptr[r0], P1 = pk_ptr[r1];
+        __syncthreads();
+        for (int i = tid; i <= n_cols; i += kScanThreads) cnt[i] = 0;
+        __syncthreads();
+        for (uint32_t p = P0 + tid; p < P1; p += kScanThreads) {
+            const uint4 cw = cols[p];
+            const uint32_t cwv[4] = {cw.x, cw.y, cw.z, cw.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                atomicAdd(&cnt[cwv[i] & 0xFFFFu], 1u);                  // padding lands in cnt[n_cols], never read back
+                atomicAdd(&cnt[cwv[i] >> 16], 1u);
+            }
+        }
+        __syncthreads();
+        if (tid == 0) cnt[n_cols] = 0;
+        __syncthreads();
+        {   // exclusive scan in column order; dir[b][c] = first posting of column c, dir[b][n_cols] = postings in the block
+            const int i0 = tid * seg, i1 = min(n_cols + 1, i0 + seg);
+            // every list starts on an even posting (4-byte aligned document ids: the scan uses 16-byte loads); an odd list
+            // is followed by one pad posting (document 0, value 0 -- the arrays are zero-filled before the build)
+            int mine = 0;
+            for (int i = i0; i < i1; ++i) mine += ((int)cnt[i] + 1) & ~1;
+            int off = block_excl_scan(mine, scratch, tid, nullptr);
+            uint32_t* d = dir + (size_t)b * (n_cols + 1);
+            for (int i = i0; i < i1; ++i) {
+                const int c = ((int)cnt[i] + 1) & ~1;
+                cnt[i] = (uint32_t)off;                                  // becomes the column's write cursor
+                d[i] = (uint32_t)off;
+                off += c;
+            }
+        }
+        __syncthreads();
+        const size_t base = bp_block_base(P0, b, n_cols);
+        for (int64_t r = r0 + w; r < r1; r += kScanWaves) {
+            const uint32_t p0 = pk_ptr[r], p1 = pk_ptr[r + 1];
+            const uint16_t dl = (uint16_t)(r - r0);
+            for (uint32_t p = p0 + lane; p < p1; p += 64) {
+                const uint4 cw = cols[p];
+                const uint32_t cwv[4] = {cw.x, cw.y, cw.z, cw.w};
+                float v[8];
+                if constexpr (VM == VM_F32) {
+                    const float4* vp = reinterpret_cast<const float4*>(vals);
+                    const float4 v0 = vp[2 * (size_t)p], v1 = vp[2 * (size_t)p + 1];
+                    v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
+                } else {
+                    const uint4 hv = reinterpret_cast<const uint4*>(vals)[p];
+                    const __half2* h = reinterpret_cast<const __half2*>(&hv);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { const float2 f = __half22float2(h[i]); v[2 * i] = f.x; v[2 * i + 1] = f.y; }
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const uint32_t c = (i & 1) ? (cwv[i >> 1] >> 16) : (cwv[i >> 1] & 0xFFFFu);
+                    if (c < (uint32_t)n_cols) {
+                        const uint32_t pos = atomicAdd(&cnt[c], 1u);
+                        pdoc[base + pos] = dl;
+                        if constexpr (VM == VM_F32) reinterpret_cast<float*>(pval)[base + pos] = v[i];
+                        else reinterpret_cast<__half*>(pval)[base + pos] = __float2half(v[i]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+struct BpArgs {
+    const uint32_t* pk_ptr;   // [n_rows + 1] (block b's postings start at 8 * pk_ptr[b * kBpRows])
+    const uint32_t* dir;      // [n_blocks, n_cols + 1]
+    const uint16_t* pdoc;
+    const void* pval;
+    int64_t n_rows;
+    int32_t n_cols;
+    int32_t k;
+    int32_t nchunk;
+    int64_t blocks_per_chunk;
+    const int64_t* qptr;      // sparse queries (CSR over the batch) and the tile plan -- as MqArgs
+    const int32_t* qcols;
+    const float* qvals;
+    const int2* tiles;
+    int32_t n_tiles;
+    int32_t ent_cap;          // LDS capacity for tile entries
+    uint64_t* cand;           // [B, nchunk, k] output keys, sorted descending
+    uint64_t* gcand;          // [grid, QT, kBpCap] scratch
+    const uint64_t* upper;    // optional [B] exclusive upper bounds ("search after")
+};
+
+template <int QT>
+__host__ __device__ inline size_t bp_lds_bytes(int ent_cap) {
+    return (size_t)kBpRows * QT * 8 + (size_t)kBpCap * 8 + (size_t)QT * 16 + 64 * 4 + (size_t)ent_cap * 8;
+}
+
+template <int VM, int QT>
+__global__ __launch_bounds__(kScanThreads) void bp_scan_topk(BpArgs a) {
+    static_assert(kBpRows == kScanThreads, "one document per thread at block end");
+    static_assert(kBpBatch == kBpGroup, "one directory-owning lane per list of a batch");
+    static_assert(QT == 8, "the accumulator swizzle assumes 8 slots per document");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* acc = reinterpret_cast<double*>(smem);                                  // [kBpRows][QT]
+    uint64_t* sortbuf = reinterpret_cast<uint64_t*>(acc + kBpRows * QT);            // [kBpCap]
+    unsigned long long* tau = reinterpret_cast<unsigned long long*>(sortbuf + kBpCap);   // [QT]
+    unsigned long long* upper_sh = tau + QT;                                        // [QT] exclusive upper bounds ("search after")
+    int* scratch = reinterpret_cast<int*>(upper_sh + QT);                           // [48]
+    unsigned int* ccnt = reinterpret_cast<unsigned int*>(scratch + 48);             // [QT]
+    uint2* ent = reinterpret_cast<uint2*>(scratch + 64);                            // [ent_cap]: x = column | slot << 16, y = weight bits
+
+    const int tid = threadIdx.x;
+    const int gid = tid / kBpGroup, gl = tid % kBpGroup;
+    constexpr int NG = kScanThreads / kBpGroup;                                     // 64 groups
+    const int K = a.k;
+    uint64_t* my_gcand = a.gcand + (size_t)blockIdx.x * QT * kBpCap;
+    const int64_t n_blocks = (a.n_rows + kBpRows - 1) / kBpRows;
+    const int64_t items = (int64_t)a.n_tiles * a.nchunk;
+    const size_t dir_ld = (size_t)a.n_cols + 1;
+
+    for (int64_t item = blockIdx.x; item < items; item += gridDim.x) {
+        const int tile = (int)(item / a.nchunk), c = (int)(item % a.nchunk);
+        const int q0 = a.tiles[tile].x, nq = a.tiles[tile].y;
+        const int64_t b0 = (int64_t)c * a.blocks_per_chunk, b1 = min(n_blocks, b0 + a.blocks_per_chunk);
+        __syncthreads();
+        const int64_t e0 = a.qptr[q0], e1 = a.qptr[q0 + nq];
+        const int n_ent = (int)(e1 - e0);
+        for (int i = tid; i < n_ent; i += kScanThreads) {
+            const int64_t e = e0 + i;
+            int qs = 0;
+            while (e >= a.qptr[q0 + qs + 1]) ++qs;
+            ent[i] = make_uint2((uint32_t)a.qcols[e] | ((uint32_t)qs << 16), __float_as_uint(a.qvals[e]));
+        }
+        for (int i = tid; i < kBpRows * QT; i += kScanThreads) acc[i] = 0.0;
+        if (tid < QT) { tau[tid] = 0ull; ccnt[tid] = 0u; }
+        if (tid < QT) upper_sh[tid] = (a.upper && tid < nq) ? a.upper[q0 + tid] : ~0ull;
+        __syncthreads();
+
+        for (int64_t b = b0; b < b1 || b == b0; ++b) {
+            if (b < b1) {
+                const uint32_t* dirb = a.dir + (size_t)b * dir_ld;
+                const size_t base = bp_block_base(a.pk_ptr[b * kBpRows], b, a.n_cols);
+                // block-uniform base pointers + 32-bit byte offsets: the loads take the scalar-base form, no 64-bit address per lane
+                const char* bdoc = reinterpret_cast<const char*>(a.pdoc + base);
+                const char* bval = reinterpret_cast<const char*>(a.pval) + base * (VM == VM_F32 ? 4 : 2);
+                // A slot = the quad's next kBpGroup entries; lane l owns the directory pair (first, end) of entry l of the slot and
+                // fetches the next slot's pair while the current one is walked.  A lane takes 8 consecutive postings of a list per
+                // round (one 16-byte load of document ids, two of values); the kBpBatch lists of a slot are loaded before any
+                // multiply-add, so ~32 postings per lane are in flight.
+                uint32_t nlo = 0, nhi = 0;
+                {
+                    const int e = gid + NG * gl;
+                    if (e < n_ent) {
+                        const uint32_t cc = ent[e].x & 0xFFFFu;
+                        nlo = dirb[cc];
+                        nhi = dirb[cc + 1];
+                    }
+                }
+                for (int j = 0; gid + NG * (kBpGroup * j) < n_ent; ++j) {
+                    const uint32_t clo = nlo, chi = nhi;
+                    nlo = 0; nhi = 0;
+                    {
+                        const int e = gid + NG * (gl + kBpGroup * (j + 1));
+                        if (e < n_ent) {
+                            const uint32_t cc = ent[e].x & 0xFFFFu;
+                            nlo = dirb[cc];
+                            nhi = dirb[cc + 1];
+                        }
+                    }
+                    uint32_t pp[kBpBatch], o1[kBpBatch], qoff[kBpBatch];
+                    float ww[kBpBatch];
+                    bool more = false;
+#pragma unroll
+                    for (int u = 0; u < kBpBatch; ++u) {                                 // kBpBatch == kBpGroup: owner lane u holds entry u of this slot
+                        const uint32_t lo = __shfl(clo, u, kBpGroup), hi = __shfl(chi, u, kBpGroup);
+                        const int e = gid + NG * (u + kBpGroup * j);
+                        const uint2 en = ent[e < n_ent ? e : 0];
+                        qoff[u] = en.x >> 16; ww[u] = __uint_as_float(en.y);
+                        pp[u] = lo + 8u * gl; o1[u] = hi;
+                        more = more || (pp[u] < o1[u]);
+                    }
+                    // rounds of 32 postings per list; lists longer than one round (popular columns) simply take more rounds
+                    while (__builtin_amdgcn_ballot_w64(more)) {
+                        uint4 dd[kBpBatch];
+                        float vv[kBpBatch][8];
+#pragma unroll
+                        for (int u = 0; u < kBpBatch; ++u) {
+                            if (pp[u] < o1[u]) {
+                                dd[u] = *reinterpret_cast<const uint4*>(bdoc + pp[u] * 2u);
+                                if constexpr (VM == VM_F32) {
+                                    const float4* vp = reinterpret_cast<const float4*>(bval + pp[u] * 4u);
+                                    const float4 v0 = vp[0], v1 = vp[1];
+                                    vv[u][0] = v0.x; vv[u][1] = v0.y; vv[u][2] = v0.z; vv[u][3] = v0.w;
+                                    vv[u][4] = v1.x; vv[u][5] = v1.y; vv[u][6] = v1.z; vv[u][7] = v1.w;
+                                } else {
+                                    const uint4 hv = *reinterpret_cast<const uint4*>(bval + pp[u] * 2u);
+                                    const __half2* h = reinterpret_cast<const __half2*>(&hv);
+#pragma unroll
+                                    for (int t = 0; t < 4; ++t) { const float2 f = __half22float2(h[t]); vv[u][2 * t] = f.x; vv[u][2 * t + 1] = f.y; }
+                                }
+                            }
+                        }
+                        more = false;
+#pragma unroll
+                        for (int u = 0; u < kBpBatch; ++u) {
+                            if (pp[u] < o1[u]) {
+                                const uint32_t nv = min(8u, o1[u] - pp[u]);
+                                const uint32_t dw[4] = {dd[u].x, dd[u].y, dd[u].z, dd[u].w};
+#pragma unroll
+                                for (int t = 0; t < 8; ++t) {
+                                    const uint32_t d = (t & 1) ? (dw[t >> 1] >> 16) : (dw[t >> 1] & 0xFFFFu);
+                                    // past the list's end the 16-byte loads picked up the next list's postings (valid documents of this
+                                    // block) or zero padding: those lanes add 0.0 -- no branch per posting
+                                    const float prod = (uint32_t)t < nv ? ww[u] * vv[u][t] : 0.f;
+                                    atomicAdd(&acc[d * QT + (qoff[u] ^ (d & 7u))], (double)prod);
+                                }
+                            }
+                            pp[u] += 8u * kBpGroup;
+                            more = more || (pp[u] < o1[u]);
+                            __builtin_amdgcn_sched_barrier(0);       // one list at a time: 8 fp64 products live, not 32
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            if (b < b1) {       // one document per thread: its QT sums -> order keys -> candidates
+                const int64_t row = b * kBpRows + tid;
+                double* pa = acc + (size_t)tid * QT;
+                if (row < a.n_rows) {
+#pragma unroll
+                    for (int q = 0; q < QT; ++q) {
+                        const double sum = pa[q ^ (tid & 7)];            // slot swizzled by document: a document's 64-byte row would
+                        pa[q ^ (tid & 7)] = 0.0;                         // otherwise put every add of a wave on two bank groups
+                        if (q < nq) {
+                            const uint64_t key = make_key((float)sum, (uint32_t)row);
+                            if (key > tau[q] && key < upper_sh[q]) {
+                                const uint32_t pos = atomicAdd(&ccnt[q], 1u);
+                                my_gcand[(size_t)q * kBpCap + pos] = key;
+                            }
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            const bool last = b + 1 >= b1;
+            for (int qs = 0; qs < nq; ++qs) {
+                const uint32_t cnt = ccnt[qs];
+                if (last || cnt > (uint32_t)(kBpCap - kBpRows)) {
+                    for (int i = tid; i < kBpCap; i += kScanThreads) sortbuf[i] = (uint32_t)i < cnt ? my_gcand[(size_t)qs * kBpCap + i] : 0ull;
+                    wg_sort_desc<kScanThreads>(sortbuf, kBpCap, tid);
+                    if (last) {
+                        uint64_t* out = a.cand + ((size_t)(q0 + qs) * a.nchunk + c) * (size_t)K;
+                        for (int i = tid; i < K; i += kScanThreads) out[i] = sortbuf[i];
+                    } else if (cnt > (uint32_t)K) {
+                        for (int i = tid; i < K; i += kScanThreads) my_gcand[(size_t)qs * kBpCap + i] = sortbuf[i];
+                        if (tid == 0) {
+                            tau[qs] = sortbuf[K - 1];
+                            ccnt[qs] = (uint32_t)K;
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+            __syncthreads();
+            if (last) break;
+        }
+    }
+}
+
+}  // namespace vs

@@ -189,6 +189,13 @@ struct vs_index {
     vs::DevBuf pk_ptr;   // uint32 [n_rows + 1]
     vs::DevBuf cols;     // uint16 [n_packets * 8]
     vs::DevBuf vals;     // fp32 / fp16 [n_packets * 8] (absent for binary)
+    // blocked postings (bp_scan.h): column-grouped copy for sparse queries, built on first use when HBM allows
+    vs::DevBuf bp_dir;   // uint32 [n_blocks, n_cols + 1]
+    vs::DevBuf bp_doc;   // uint16 [n_packets * 8]
+    vs::DevBuf bp_val;   // fp32 / fp16 [n_packets * 8]
+    bool bp_ready = false, bp_tried = false;
+    int bp_pref = -1;    // option "blocked_postings": -1 auto, 0 never, 1 always
+    int mq_variant = -1; // option "mq_variant": -1 auto (from the batch's query overlap), 0 plain, 1 shared columns
     // dense
     vs::DevBuf mat;      // [n_rows, n_cols] store_dtype
     // scratch owned by the handle (grow-only)

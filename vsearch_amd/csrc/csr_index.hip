@@ -3,6 +3,7 @@
 #include "common.h"
 #include "csr_scan.h"
 #include "csr_scan_mq.h"
+#include "bp_scan.h"
 #include "synth_device.h"
 
 #include <algorithm>
@@ -303,6 +304,8 @@ int append_csr_rows(vs_index* idx, const void* rowptr, int rowptr_dtype, const v
     if (hflags & 2) return fail(VS_EINVAL, "store_dtype VS_NONE (binary index) requires every value == 1");
     idx->n_rows = row_base + n_chunk;
     idx->n_packets = acc;
+    idx->bp_ready = false;                 // the column-grouped copy no longer matches: rebuilt on the next sparse search
+    idx->bp_tried = false;
     idx->nnz += nnz_chunk;
     idx->lanes_per_row = pick_lanes_per_row(idx->n_packets, idx->n_rows);
     return VS_OK;
@@ -689,6 +692,49 @@ int mq_vals_cap(const vs_index* idx) {
     return (int)((total - fixed) / 4);
 }
 
+// ---- blocked postings (bp_scan.h): second, column-grouped copy of a long-row valued index ------------------------
+bool bp_wanted(const vs_index* idx) {
+    if (idx->bp_pref == 0 || idx->store_dtype == VS_NONE || idx->n_rows <= 0 || idx->n_packets <= 0) return false;
+    if (((size_t)idx->n_cols + 1) * 4 + 4096 > 160 * 1024) return false;            // the builder keeps one counter per column in LDS
+    if (idx->bp_pref == 1) return true;
+    // pays off when rows are long (the directory costs 4 (V + 1) bytes per 1024 documents) and the index is big enough
+    return idx->n_rows >= 16384 && (double)idx->nnz / (double)idx->n_rows >= 256.0;
+}
+
+int bp_build(vs_index* idx, hipStream_t s) {
+    idx->bp_tried = true;
+    idx->bp_ready = false;
+    const int64_t n_blocks = ceil_div64(idx->n_rows, kBpRows);
+    const size_t cap = bp_postings_capacity(idx->n_packets, n_blocks, idx->n_cols);
+    const size_t b_dir = (size_t)n_blocks * ((size_t)idx->n_cols + 1) * 4, b_doc = cap * 2, b_val = cap * (idx->store_dtype == VS_F32 ? 4 : 2);
+    size_t free_b = 0, total_b = 0;
+    VS_HIP(hipMemGetInfo(&free_b, &total_b));
+    const size_t margin = idx->bp_pref == 1 ? ((size_t)256 << 20) : ((size_t)4 << 30);  // leave room for scratch / other tensors
+    if (free_b < b_dir + b_doc + b_val + margin) return VS_OK;                          // no room: the CSR scan serves every query
+    if (idx->bp_dir.alloc(b_dir) != VS_OK || idx->bp_doc.alloc(b_doc) != VS_OK || idx->bp_val.alloc(b_val) != VS_OK) {
+        idx->bp_dir.release(); idx->bp_doc.release(); idx->bp_val.release();
+        (void)hipGetLastError();
+        return VS_OK;
+    }
+    VS_HIP(hipMemsetAsync(idx->bp_doc.p, 0, b_doc, s));          // pad postings: document 0, value 0
+    VS_HIP(hipMemsetAsync(idx->bp_val.p, 0, b_val, s));
+    const size_t lds = ((size_t)idx->n_cols + 1) * 4;
+    const int grid = (int)std::min<int64_t>(n_blocks, (int64_t)idx->cu_count * 8);
+    ProfScope prof("bp_build", s);
+    if (idx->store_dtype == VS_F32) {
+        VS_HIP(hipFuncSetAttribute((const void*)bp_build_kernel<VM_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((bp_build_kernel<VM_F32>), dim3(grid), dim3(kScanThreads), lds, s, idx->pk_ptr.as<uint32_t>(), idx->cols.as<uint4>(),
+                           (const void*)idx->vals.p, idx->n_rows, idx->n_cols, idx->bp_dir.as<uint32_t>(), idx->bp_doc.as<uint16_t>(), idx->bp_val.p);
+    } else {
+        VS_HIP(hipFuncSetAttribute((const void*)bp_build_kernel<VM_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((bp_build_kernel<VM_F16>), dim3(grid), dim3(kScanThreads), lds, s, idx->pk_ptr.as<uint32_t>(), idx->cols.as<uint4>(),
+                           (const void*)idx->vals.p, idx->n_rows, idx->n_cols, idx->bp_dir.as<uint32_t>(), idx->bp_doc.as<uint16_t>(), idx->bp_val.p);
+    }
+    VS_HIP(hipGetLastError());
+    idx->bp_ready = true;
+    return VS_OK;
+}
+
 // Multi-query pass (Qt = kQT).  Returns VS_OK and sets *done = false when the batch does not qualify
 // (a query denser than the LDS weight capacity): the caller then takes the dense-image path.
 // One pass delivers ranks [col0, col0 + k) of every query into columns col0.. of the [B, out_ld] outputs; `upper`
@@ -697,7 +743,8 @@ int mq_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64_t id_o
               const ScanPlan& plan, hipStream_t s, bool* done, int32_t out_ld, int32_t col0, uint64_t* upper) {
     *done = false;
     const int vals_cap = mq_vals_cap(idx);
-    if (vals_cap <= 0 || k > kMaxKMq) return VS_OK;             // (callers split larger k into passes)
+    const bool use_bp = idx->bp_ready;
+    if (vals_cap <= 0 || k > (use_bp ? kBpMaxK : kMaxKMq)) return VS_OK;     // (callers split larger k into passes)
     const int V = idx->n_cols;
     // 1. sparsify the batch: counts -> (qptr, tiles, plan) -> (qcols, qvals)
     const size_t off_counts = 0, off_qptr = off_counts + (size_t)B * 8, off_plan = off_qptr + (size_t)(B + 1) * 8,
@@ -726,7 +773,46 @@ int mq_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64_t id_o
     hipLaunchKernelGGL(fill_csr_kernel<0>, dim3(std::min(B, 2048)), dim3(kSpThreads), 0, s, dq, (int64_t)V, B, V, qptr, qcols, qvals, qnnz);
     VS_HIP(hipGetLastError());
     // 2. scan.  Work items = (tile, row chunk)
-    const int nchunk = choose_chunks(idx, n_tiles, plan.nchunk);
+    int nchunk = choose_chunks(idx, n_tiles, plan.nchunk);
+    if (use_bp) {
+        // blocked postings: chunks are runs of 1024-document blocks
+        const int64_t n_blocks = ceil_div64(idx->n_rows, kBpRows);
+        nchunk = (int)std::min<int64_t>(nchunk, n_blocks);
+        const int64_t blocks_per_chunk = ceil_div64(n_blocks, nchunk);
+        const int64_t items = (int64_t)n_tiles * nchunk;
+        const int grid = (int)std::min<int64_t>(items, idx->cu_count);
+        VS_TRY(idx->ws_mq_cand.reserve((size_t)grid * kQT * kBpCap * 8));
+        VS_TRY(idx->ws_cand.reserve((size_t)B * nchunk * k * 8));
+        BpArgs a{};
+        a.pk_ptr = idx->pk_ptr.as<uint32_t>();
+        a.dir = idx->bp_dir.as<uint32_t>();
+        a.pdoc = idx->bp_doc.as<uint16_t>();
+        a.pval = idx->bp_val.p;
+        a.n_rows = idx->n_rows;
+        a.n_cols = V;
+        a.k = k;
+        a.nchunk = nchunk;
+        a.blocks_per_chunk = blocks_per_chunk;
+        a.qptr = qptr;
+        a.qcols = qcols;
+        a.qvals = qvals;
+        a.tiles = tiles;
+        a.n_tiles = n_tiles;
+        a.ent_cap = vals_cap;
+        a.cand = idx->ws_cand.as<uint64_t>();
+        a.gcand = idx->ws_mq_cand.as<uint64_t>();
+        a.upper = col0 > 0 ? upper : nullptr;
+        const size_t lds = bp_lds_bytes<kQT>(vals_cap);
+        ProfScope prof("csr_scan_topk", s);
+        if (idx->store_dtype == VS_F32) {
+            VS_HIP(hipFuncSetAttribute((const void*)bp_scan_topk<VM_F32, kQT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((bp_scan_topk<VM_F32, kQT>), dim3(grid), dim3(kScanThreads), lds, s, a);
+        } else {
+            VS_HIP(hipFuncSetAttribute((const void*)bp_scan_topk<VM_F16, kQT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((bp_scan_topk<VM_F16, kQT>), dim3(grid), dim3(kScanThreads), lds, s, a);
+        }
+        VS_HIP(hipGetLastError());
+    } else {
     const int64_t rows_per_chunk = ceil_div64(idx->n_rows, nchunk);
     const int64_t items = (int64_t)n_tiles * nchunk;
     const int grid = (int)std::min<int64_t>(items, idx->cu_count);
@@ -758,16 +844,16 @@ int mq_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64_t id_o
         const int u = std::max(1, std::min(3, (int)((ppr + mq_lanes(idx) - 1) / mq_lanes(idx))));
         // expected number of columns two queries of the batch share; uniform 776-nnz queries: ~20
         const double overlap = B > 1 ? (double)hplan[3] / ((double)B * (double)(B - 1)) : 0.0;
-        bool shared_cols = overlap > kMqSharedOverlap;
-        if (const char* e = getenv("VS_MQ_MODE")) shared_cols = atoi(e) != 0;      // testing: force a variant (0 pairs, 1 shared columns)
+        const bool shared_cols = idx->mq_variant >= 0 ? idx->mq_variant == 1 : overlap > kMqSharedOverlap;
         int rc = idx->store_dtype == VS_F32 ? launch_mq_vm<VM_F32>(mq_lanes(idx), u, shared_cols, a, grid, lds, s)
                : idx->store_dtype == VS_F16 ? launch_mq_vm<VM_F16>(mq_lanes(idx), u, shared_cols, a, grid, lds, s)
                                             : launch_mq_vm<VM_BIN>(mq_lanes(idx), u, shared_cols, a, grid, lds, s);
         VS_TRY(rc);
     }
+    }
     // 3. merge chunks
     MergeArgs m{};
-    m.cand = a.cand;
+    m.cand = idx->ws_cand.as<uint64_t>();
     m.n_cand = (int64_t)nchunk * k;
     m.B = B;
     m.k = k;
@@ -806,6 +892,7 @@ int vs_csr_search(vs_index* idx, const void* q, int q_dtype, int64_t ldq, int32_
     }
     idx->last_qt = 1;
     if (idx->qt_pref != 1) {
+        if (!idx->bp_ready && !idx->bp_tried && bp_wanted(idx)) VS_TRY(bp_build(idx, s));
         bool done = false;
         // k > kMaxKMq: "search after" passes of kMaxKMq ranks each (the k-th key of a pass is the next pass's exclusive
         // upper bound); large batches are cut so that the candidate scratch stays bounded

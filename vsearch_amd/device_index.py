@@ -151,6 +151,10 @@ class DeviceIndex:
         """0 = auto (tiles of 8 sparse queries per index pass when the batch qualifies), 1 = one query per pass."""
         nat.check(nat.lib().vs_index_set_queries_per_pass(self._h, int(qt)))
 
+    def set_option(self, name: str, value: int):
+        """Tuning / test options: "blocked_postings" (-1 auto, 0 off, 1 on), "mq_variant" (-1 auto, 0 plain, 1 shared columns)."""
+        nat.check(nat.lib().vs_index_set_option(self._h, name.encode(), int(value)))
+
     def _q_args(self, q):
         if q.ndim != 2:
             raise ValueError("queries must be [B, V]")
