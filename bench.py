@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--k", type=int, default=K)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scan", choices=["auto", "csr", "postings"], default="auto",
+                    help="auto: blocked postings when HBM has room for the second copy (default); csr: the 8-query CSR scan only")
     ap.add_argument("--cpu-sample-docs", type=int, default=100_000)
     ap.add_argument("--store", choices=["fp32", "fp16"], default="fp32",
                     help="value dtype streamed by the scan (fp16 = the reference's fp16=True load default, index.py:135)")
@@ -133,10 +135,13 @@ def main():
     t0 = time.perf_counter()
     store = nat.VS_F16 if args.store == "fp16" else nat.VS_F32
     index = DeviceIndex.synthetic(INDEX_SEED, row0, n_local, V, NNZ_DOC, 0, 0, store, local_rank)
+    index.set_option("blocked_postings", {"auto": -1, "csr": 0, "postings": 1}[args.scan])
+    batches = make_query_batches(min(4, args.steps + args.warmup), args.batch, device)
+    index.search(batches[0][:8], min(args.k, n_local))            # first sparse search builds the column-grouped copy: part of the build
+    torch.cuda.synchronize()
     info = index.info()
     build_s = time.perf_counter() - t0
     searcher = ShardedSearcher.from_device_index(index, row0, args.docs)
-    batches = make_query_batches(min(4, args.steps + args.warmup), args.batch, device)
 
     def barrier():
         if world > 1:
@@ -166,21 +171,27 @@ def main():
 
     if rank == 0:
         qps = args.steps * args.batch / elapsed
-        # dominant kernel: csr_scan_topk. One launch scores `queries_per_launch` queries, Qt per pass.
+        # dominant kernel = the scan ("csr_scan_topk" profile scope): bp_scan_topk on the blocked-postings path, csr_scan_topk_mq
+        # on the CSR path.  Algorithmic bytes = what that kernel has to read for this batch (vs_index_info.last_scan_bytes):
+        #   CSR path:      passes x bytes_per_pass                                   (every pass streams the whole index)
+        #   postings path: the posting lists of the batch's (query, column) entries + one directory pair per entry and block
+        info = index.info()
         qt = max(1, info.queries_per_pass)
-        queries_per_launch = args.steps * args.batch / max(1, scan_launches)
-        passes_per_launch = -(-queries_per_launch // qt)
-        algo_bytes_per_launch = passes_per_launch * info.bytes_per_pass
+        launches_per_step = max(1, scan_launches) / args.steps
+        algo_bytes_per_launch = info.last_scan_bytes / launches_per_step
         avg_launch_s = scan_ms / 1e3 / max(1, scan_launches)
         achieved = algo_bytes_per_launch / avg_launch_s / 1e9
+        path = {0: "csr scan, one query per pass", 1: "csr scan, 8 queries per pass", 2: "blocked postings, 8 queries per tile"}[info.last_path]
+        csr_equiv = -(-args.batch // qt) * info.bytes_per_pass / launches_per_step / avg_launch_s / 1e9
         traffic = None
         pmc = os.path.join(REPO, "profiles", "pmc_summary.json")
         if os.path.exists(pmc):
             try:
-                # PMC counters cannot be read in-process: per-query HBM bytes of this kernel come from the committed
-                # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the same 21 M-doc index (profiles/pmc_summary.json)
-                per_pass = json.load(open(pmc)).get("csr_scan_topk", {}).get("hbm_bytes_per_pass_21m")
-                traffic = per_pass * passes_per_launch * (n_local / N_DOCS) if per_pass else None
+                # PMC counters cannot be read in-process: HBM bytes of this kernel come from the committed rocprofv3 --pmc
+                # FETCH_SIZE / WRITE_SIZE passes over the same 21 M-doc index and batch size (profiles/pmc_summary.json)
+                rec = json.load(open(pmc)).get("bp_scan_topk" if info.last_path == 2 else "csr_scan_topk_mq", {})
+                if rec.get("hbm_bytes_per_launch"):
+                    traffic = rec["hbm_bytes_per_launch"] * (args.batch / rec["queries_per_launch"]) * (n_local / rec["docs"])
             except Exception:
                 traffic = None
         line = {
@@ -192,14 +203,14 @@ def main():
                                    f"row-sharded over {world} GPU(s); {args.batch} queries/step ({NNZ_Q} nnz), k={args.k}",
                        "docs": args.docs, "docs_per_gpu": n_local, "batch": args.batch, "k": args.k, "queries_per_pass": qt,
                        "lanes_per_row": info.lanes_per_row, "index_bytes_per_gpu": info.device_bytes,
-                       "index_build_s": round(build_s, 2)},
+                       "postings_copy_bytes_per_gpu": info.aux_bytes, "scan_path": path, "index_build_s": round(build_s, 2)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "csr_scan_topk", "launches": scan_launches,
+                         "traffic": traffic, "kernel": "bp_scan_topk" if info.last_path == 2 else "csr_scan_topk_mq", "launches": scan_launches,
                          "avg_launch_ms": avg_launch_s * 1e3, "algorithmic_bytes_per_launch": algo_bytes_per_launch,
-                         "bytes_per_pass": info.bytes_per_pass, "merge_ms_total": merge_ms,
-                         "note": "achieved = algorithmic bytes (bytes_per_pass x passes, SURVEY 8(d)) / measured kernel time; traffic = "
-                                 "PMC-measured HBM bytes of the launch. achieved can exceed the HBM peak because concurrent query tiles "
-                                 "sweep the same rows and share the stream through L2 / Infinity Cache (traffic << algorithmic)"},
+                         "csr_scan_equivalent_GBps": csr_equiv, "bytes_per_csr_pass": info.bytes_per_pass, "merge_ms_total": merge_ms,
+                         "note": "achieved = bytes the scan kernel has to read for the batch (vs_index_info.last_scan_bytes) / measured "
+                                 "kernel time; traffic = PMC-measured HBM bytes of the same launch (profiles/); csr_scan_equivalent = "
+                                 "what a whole-index CSR pass per 8 queries (SURVEY 8(d)) would have to stream in that time"},
         }
         if world == 1:
             line["parity"] = parity_check(local_rank)

@@ -69,6 +69,12 @@ typedef struct vs_index_info_t {
     int64_t bytes_per_pass;  /* algorithmic HBM bytes one scoring pass streams      */
     int32_t lanes_per_row;   /* CSR scan geometry                                                     */
     int32_t queries_per_pass;/* Qt of the most recent search() (the planned default before any search)   */
+    int64_t last_scan_bytes; /* bytes the scan kernels of the most recent search() had to read: passes x
+                              * bytes_per_pass on the CSR paths; on the blocked-postings path the posting lists of
+                              * the queries' columns (document ids + values) + their directory entries            */
+    int64_t aux_bytes;       /* bytes of the blocked-postings copy (0 when absent)                      */
+    int32_t last_path;       /* most recent search(): 0 = one query per pass, 1 = 8-query CSR scan, 2 = blocked postings */
+    int32_t reserved;
 } vs_index_info_t;
 
 /* ---- library ------------------------------------------------------------------------------- */

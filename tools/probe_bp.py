@@ -23,6 +23,8 @@ for mode in (0, 1):
     torch.cuda.synchronize(); dt = time.time() - t
     ms, n = Profile.read("csr_scan_topk"); Profile.enable(False)
     res[mode] = (ids.cpu().numpy(), sc.cpu().numpy())
+    inf = idx.info()
+    print(f"   path={inf.last_path} scan bytes {inf.last_scan_bytes/1e9:.2f} GB -> {inf.last_scan_bytes/ms/1e6:.0f} GB/s; aux copy {inf.aux_bytes/1e9:.2f} GB")
     print(f"blocked_postings={mode}: first call {first*1e3:.1f} ms, steady {dt*1e3:.2f} ms = {B/dt:.0f} q/s (scan kernel {ms:.2f} ms)", flush=True)
 same_ids = (res[0][0] == res[1][0]).mean(); same_sc = (res[0][1] == res[1][1]).mean()
 print(f"ids equal: {same_ids:.6f}  scores bit-equal: {same_sc:.6f}")

@@ -36,8 +36,9 @@ def main():
     ap.add_argument("--write")
     ap.add_argument("--tag", required=True)
     ap.add_argument("--note", default="")
-    ap.add_argument("--passes", type=float, default=0.0, help="index passes in the bench-sized scan launch (batch / queries_per_pass): "
-                    "with --fetch and --write, rewrites profiles/pmc_summary.json (read by bench.py for roofline.traffic)")
+    ap.add_argument("--queries", type=int, default=0, help="queries in the bench-sized scan launch: with --fetch and --write, updates "
+                    "profiles/pmc_summary.json (read by bench.py for roofline.traffic)")
+    ap.add_argument("--docs", type=int, default=21015324)
     ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles"))
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
@@ -70,18 +71,21 @@ def main():
                 f.write(f"# rocprofv3 --pmc {counter}   ({a.note})\n# value = sum over XCDs/instances, KiB; per dispatch in launch order\n")
                 for name, grid, val, n in rows:
                     f.write(f"{name[:100]:100s} grid={grid:<10d} {val:18.1f}\n")
-    if a.passes > 0 and "FETCH_SIZE" in summary and "WRITE_SIZE" in summary:
-        scan = lambda rows: max((r["KiB"] for r in rows if "csr_scan_topk" in r["kernel"]), default=0.0)     # the bench-sized launch
-        fetch, write = scan(summary["FETCH_SIZE"]), scan(summary["WRITE_SIZE"])
-        pmc = {"csr_scan_topk": {
-            "hbm_bytes_per_pass_21m": (2 * fetch + write) * 1024 / a.passes, "fetch_KiB": fetch, "write_KiB": write,
-            "passes_in_pmc_launch": a.passes,
-            "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 / passes  (gfx950: FETCH_SIZE counts 1/2 of a 16 B/lane coalesced stream); "
-                       "a pass = one sweep of the 21 015 324-doc index by a tile of 8 queries",
-            "note": "below the algorithmic 96.9 GB/pass: 128 query tiles sweep the same two row chunks concurrently and share lines "
-                    "through L2 / Infinity Cache",
-            "source": f"profiles/{a.tag}_fetch_size.txt, profiles/{a.tag}_write_size.txt (rocprofv3 --pmc, separate passes, {a.note})"}}
-        with open(os.path.join(a.out, "pmc_summary.json"), "w") as f:
+    if a.queries > 0 and "FETCH_SIZE" in summary and "WRITE_SIZE" in summary:
+        # bench-sized launch (largest) of each scan kernel present -> profiles/pmc_summary.json, read by bench.py for roofline.traffic
+        pmc_path = os.path.join(a.out, "pmc_summary.json")
+        pmc = json.load(open(pmc_path)) if os.path.exists(pmc_path) else {}
+        pmc = {k: v for k, v in pmc.items() if k in ("bp_scan_topk", "csr_scan_topk_mq")}
+        for key in ("bp_scan_topk", "csr_scan_topk_mq"):
+            scan = lambda rows: max((r["KiB"] for r in rows if key in r["kernel"]), default=0.0)
+            fetch, write = scan(summary["FETCH_SIZE"]), scan(summary["WRITE_SIZE"])
+            if fetch <= 0:
+                continue
+            pmc[key] = {"hbm_bytes_per_launch": (2 * fetch + write) * 1024, "fetch_KiB": fetch, "write_KiB": write,
+                        "queries_per_launch": a.queries, "docs": a.docs,
+                        "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024  (gfx950: FETCH_SIZE counts 1/2 of a 16 B/lane coalesced stream)",
+                        "source": f"profiles/{a.tag}_fetch_size.txt, profiles/{a.tag}_write_size.txt (rocprofv3 --pmc, separate passes, {a.note})"}
+        with open(pmc_path, "w") as f:
             json.dump(pmc, f, indent=1)
     with open(os.path.join(a.out, f"{a.tag}_summary.json"), "w") as f:
         json.dump(summary, f, indent=1)

@@ -111,6 +111,34 @@ __global__ __launch_bounds__(kScanThreads) void bp_build_kernel(const uint32_t* 
     }
 }
 
+// df[c] = postings of column c over all blocks, pad postings included (what one query entry on column c streams)
+template <int UNUSED>
+__global__ void bp_df_kernel(const uint32_t* dir, int64_t n_blocks, int32_t n_cols, uint32_t* df) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_cols) return;
+    uint32_t acc = 0;
+    for (int64_t b = 0; b < n_blocks; ++b) {
+        const uint32_t* d = dir + (size_t)b * ((size_t)n_cols + 1);
+        acc += d[c + 1] - d[c];
+    }
+    df[c] = acc;
+}
+// out[0] = sum over columns of (queries of the batch using the column) x df: the postings this batch's search walks
+template <int UNUSED>
+__global__ __launch_bounds__(kScanThreads) void bp_walk_kernel(const uint32_t* colfreq, const uint32_t* df, int32_t n_cols, int64_t* out) {
+    __shared__ unsigned long long red[kScanThreads / 64];
+    unsigned long long v = 0;
+    for (int c = threadIdx.x; c < n_cols; c += kScanThreads) v += (unsigned long long)colfreq[c] * df[c];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int i = 0; i < kScanThreads / 64; ++i) t += red[i];
+        out[0] = (int64_t)t;
+    }
+}
+
 struct BpArgs {
     const uint32_t* pk_ptr;   // [n_rows + 1] (block b's postings start at 8 * pk_ptr[b * kBpRows])
     const uint32_t* dir;      // [n_blocks, n_cols + 1]
@@ -167,11 +195,27 @@ __global__ __launch_bounds__(kScanThreads) void bp_scan_topk(BpArgs a) {
         __syncthreads();
         const int64_t e0 = a.qptr[q0], e1 = a.qptr[q0 + nq];
         const int n_ent = (int)(e1 - e0);
-        for (int i = tid; i < n_ent; i += kScanThreads) {
-            const int64_t e = e0 + i;
-            int qs = 0;
-            while (e >= a.qptr[q0 + qs + 1]) ++qs;
-            ent[i] = make_uint2((uint32_t)a.qcols[e] | ((uint32_t)qs << 16), __float_as_uint(a.qvals[e]));
+        // Entries sorted by column (the accumulator area doubles as the sort buffer): neighbouring quads then read neighbouring
+        // directory words and neighbouring posting lists -- the directory is fetched once per block instead of one 64-byte
+        // sector per entry, and the walk over the block's postings becomes a forward sweep with gaps.
+        {
+            uint64_t* skey = reinterpret_cast<uint64_t*>(acc);              // kBpRows * QT = 8192 slots
+            for (int i = tid; i < kBpRows * QT; i += kScanThreads) {
+                uint64_t key = 0;
+                if (i < n_ent) {
+                    const int64_t e = e0 + i;
+                    int qs = 0;
+                    while (e >= a.qptr[q0 + qs + 1]) ++qs;
+                    key = ((uint64_t)(uint32_t)a.qcols[e] << 40) | ((uint64_t)qs << 32) | (uint64_t)__float_as_uint(a.qvals[e]);
+                }
+                skey[i] = key;
+            }
+            wg_sort_desc<kScanThreads>(skey, kBpRows * QT, tid);
+            for (int i = tid; i < n_ent; i += kScanThreads) {
+                const uint64_t key = skey[i];
+                ent[i] = make_uint2((uint32_t)(key >> 40) | ((uint32_t)((key >> 32) & 0xFFu) << 16), (uint32_t)key);
+            }
+            __syncthreads();
         }
         for (int i = tid; i < kBpRows * QT; i += kScanThreads) acc[i] = 0.0;
         if (tid < QT) { tau[tid] = 0ull; ccnt[tid] = 0u; }

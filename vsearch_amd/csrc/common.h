@@ -193,7 +193,10 @@ struct vs_index {
     vs::DevBuf bp_dir;   // uint32 [n_blocks, n_cols + 1]
     vs::DevBuf bp_doc;   // uint16 [n_packets * 8]
     vs::DevBuf bp_val;   // fp32 / fp16 [n_packets * 8]
+    vs::DevBuf bp_df;    // uint32 [n_cols]: postings per column over all blocks (incl. pad postings) -- what a query entry streams
     bool bp_ready = false, bp_tried = false;
+    int64_t last_scan_bytes = 0;   // bytes the scan kernels of the most recent search had to read (algorithmic, per path)
+    int last_path = 0;             // 0 = one query per pass, 1 = 8-query CSR scan, 2 = blocked postings
     int bp_pref = -1;    // option "blocked_postings": -1 auto, 0 never, 1 always
     int mq_variant = -1; // option "mq_variant": -1 auto (from the batch's query overlap), 0 plain, 1 shared columns
     // dense

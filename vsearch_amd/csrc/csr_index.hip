@@ -458,6 +458,9 @@ extern "C" int vs_index_info(const vs_index* idx, vs_index_info_t* o) {
     o->device = idx->device;
     o->nnz = idx->nnz;
     o->n_packets = idx->n_packets;
+    o->last_scan_bytes = idx->last_scan_bytes;
+    o->last_path = idx->last_path;
+    o->aux_bytes = idx->bp_ready ? (int64_t)(idx->bp_dir.bytes + idx->bp_doc.bytes + idx->bp_val.bytes) : 0;
     if (idx->kind == VS_KIND_CSR) {
         o->bytes_per_pass = csr_bytes_per_pass(idx);
         o->device_bytes = (int64_t)(idx->pk_ptr.bytes + idx->cols.bytes + idx->vals.bytes);
@@ -731,6 +734,11 @@ int bp_build(vs_index* idx, hipStream_t s) {
                            (const void*)idx->vals.p, idx->n_rows, idx->n_cols, idx->bp_dir.as<uint32_t>(), idx->bp_doc.as<uint16_t>(), idx->bp_val.p);
     }
     VS_HIP(hipGetLastError());
+    if (idx->bp_df.alloc((size_t)idx->n_cols * 4) == VS_OK) {
+        hipLaunchKernelGGL(bp_df_kernel<0>, dim3((unsigned)ceil_div(idx->n_cols, 256)), dim3(256), 0, s, idx->bp_dir.as<uint32_t>(), n_blocks, idx->n_cols,
+                           idx->bp_df.as<uint32_t>());
+        VS_HIP(hipGetLastError());
+    }
     idx->bp_ready = true;
     return VS_OK;
 }
@@ -761,7 +769,8 @@ int mq_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64_t id_o
     hipLaunchKernelGGL(mq_colfreq_kernel<0>, dim3(std::min(B, 2048)), dim3(kSpThreads), 0, s, dq, (int64_t)V, B, V, colfreq);
     hipLaunchKernelGGL(mq_plan_kernel<0>, dim3(1), dim3(64), 0, s, counts, B, kQT, vals_cap, qptr, tiles, dplan, colfreq, V);
     VS_HIP(hipGetLastError());
-    int64_t hplan[4] = {0, 0, 0, 0};
+    if (use_bp && idx->bp_df.p) hipLaunchKernelGGL(bp_walk_kernel<0>, dim3(1), dim3(kScanThreads), 0, s, colfreq, idx->bp_df.as<uint32_t>(), V, dplan + 4);
+    int64_t hplan[5] = {0, 0, 0, 0, 0};
     VS_HIP(hipMemcpyAsync(hplan, dplan, sizeof(hplan), hipMemcpyDeviceToHost, s));
     VS_HIP(hipStreamSynchronize(s));
     if (hplan[1] > vals_cap) return VS_OK;                       // some query is too dense for the tile tables
@@ -803,6 +812,9 @@ int mq_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64_t id_o
         a.gcand = idx->ws_mq_cand.as<uint64_t>();
         a.upper = col0 > 0 ? upper : nullptr;
         const size_t lds = bp_lds_bytes<kQT>(vals_cap);
+        // what this launch has to read: the posting lists of the batch's (query, column) entries + one directory pair per entry and block
+        idx->last_scan_bytes += hplan[4] * (2 + (idx->store_dtype == VS_F32 ? 4 : 2)) + qnnz * n_blocks * 8;
+        idx->last_path = 2;
         ProfScope prof("csr_scan_topk", s);
         if (idx->store_dtype == VS_F32) {
             VS_HIP(hipFuncSetAttribute((const void*)bp_scan_topk<VM_F32, kQT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -837,6 +849,8 @@ int mq_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64_t id_o
     a.gcand = idx->ws_mq_cand.as<uint64_t>();
     a.upper = col0 > 0 ? upper : nullptr;
     const size_t lds = mq_fixed_lds_bytes<kQT>(V, mq_acc_rows(idx)) + (size_t)vals_cap * 4;
+    idx->last_scan_bytes += (int64_t)n_tiles * csr_bytes_per_pass(idx);
+    idx->last_path = 1;
     {
         ProfScope prof("csr_scan_topk", s);
         // packets per lane per trip: enough to cover an average row in one trip, at most 3
@@ -891,6 +905,8 @@ int vs_csr_search(vs_index* idx, const void* q, int q_dtype, int64_t ldq, int32_
         d_scores = idx->ws_out_scores.as<float>();
     }
     idx->last_qt = 1;
+    idx->last_scan_bytes = 0;
+    idx->last_path = 0;
     if (idx->qt_pref != 1) {
         if (!idx->bp_ready && !idx->bp_tried && bp_wanted(idx)) VS_TRY(bp_build(idx, s));
         bool done = false;
@@ -924,6 +940,8 @@ int vs_csr_search(vs_index* idx, const void* q, int q_dtype, int64_t ldq, int32_
             return VS_OK;
         }
     }
+    idx->last_scan_bytes = 0;                                   // one query per pass from here on
+    idx->last_path = 0;
     const int passes = ceil_div(k, kMaxKShared);
     DevBuf upper;                                              // [B] exclusive upper-bound keys (multi-pass only)
     if (passes > 1) {
@@ -957,6 +975,7 @@ int vs_csr_search(vs_index* idx, const void* q, int q_dtype, int64_t ldq, int32_
             a.cand = idx->ws_cand.as<uint64_t>();
             a.upper = passes > 1 ? upper.as<uint64_t>() + b0 : nullptr;
             const int grid = (int)std::min<int64_t>((int64_t)bs * nchunk1, idx->cu_count);
+            idx->last_scan_bytes += (int64_t)bs * csr_bytes_per_pass(idx);
             VS_TRY(launch_scan(idx, kk <= kMaxKWave ? 1 : 2, a, grid, s));
             MergeArgs m{};
             m.cand = a.cand;
