@@ -347,7 +347,8 @@ __global__ __launch_bounds__(kScanThreads) void bp_scan_topk(BpArgs a) {
                     __syncthreads();
                 }
             }
-            __syncthreads();
+            // (no barrier here: without a prune nothing was written, and the next block's epilogue -- the next writer of
+            // ccnt / the candidate buffers -- sits behind the barrier that follows its walk)
             if (last) break;
         }
     }
