@@ -53,7 +53,7 @@ def sparse_like(name, n, nnz, kind, store, batch, q_law):
     info = idx.info()
     qt = max(1, info.queries_per_pass)
     passes = -(-batch // qt)
-    achieved = passes * info.bytes_per_pass / (scan_ms / 1e3 / launches) / 1e9
+    achieved = info.last_scan_bytes / (scan_ms / 1e3 / launches) / 1e9      # bytes the scan kernel had to read for the batch
     # exactness / validity on a sample of queries against the independent scores-only kernel
     sample = q[:4].cpu().numpy()
     allsc = idx.scores(sample)
@@ -61,7 +61,8 @@ def sparse_like(name, n, nnz, kind, store, batch, q_law):
     return {"config": name, "metric": "queries/sec", "value": batch / dt, "ms_per_batch": dt * 1e3, "docs": n, "batch": batch, "k": K,
             "queries_per_pass": qt, "lanes_per_row": info.lanes_per_row, "index_bytes": info.device_bytes,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK, "unit": "GB/s", "frac": achieved / HBM_PEAK,
-                         "kernel": "csr_scan_topk", "avg_launch_ms": scan_ms / launches, "bytes_per_pass": info.bytes_per_pass, "passes": passes},
+                         "kernel": "bp_scan_topk" if info.last_path == 2 else "csr_scan_topk_mq", "avg_launch_ms": scan_ms / launches,
+                         "scan_bytes": info.last_scan_bytes, "csr_bytes_per_pass": info.bytes_per_pass, "csr_passes": passes},
             "check": "top-k valid vs csr_scan_scores on 4 queries" + (" (bit-exact, canonical ids)" if kind == 1 else " (1e-4)")}
 
 
