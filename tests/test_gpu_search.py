@@ -517,3 +517,24 @@ def test_blocked_postings_auto_policy_and_append():
     bot.set_option("blocked_postings", 1)
     bot.search(q, 10)
     assert bot.info().last_path == 1 and bot.info().aux_bytes == 0
+
+
+@pytest.mark.parametrize("n_cols,qnnz", [(5000, 2000), (257, 200), (31000, 900)])
+def test_blocked_postings_other_vocabulary_sizes(n_cols, qnnz):
+    """Small / large column counts and dense-ish queries: tiles are planned within the postings kernel's entry capacity."""
+    rng = np.random.default_rng(n_cols)
+    n, nnz = 3000, min(300, n_cols // 2)
+    ix = np.concatenate([np.sort(rng.choice(n_cols, size=nnz, replace=False)) for _ in range(n)]).astype(np.int32)
+    ip = np.arange(0, (n + 1) * nnz, nnz, dtype=np.int64)
+    d = (0.01 + 3 * rng.random(len(ix))).astype(np.float32)
+    q = np.zeros((9, n_cols), dtype=np.float32)
+    for b in range(9):
+        c = rng.choice(n_cols, size=min(qnnz, n_cols), replace=False)
+        q[b, c] = 0.01 + 3 * rng.random(len(c))
+    idx = DeviceIndex.from_csr(ip, ix, d, n_cols)
+    idx.set_option("blocked_postings", 1)
+    ids, sc = idx.search(q, 50)
+    o_ids, o_sc, allsc = oracle.csr_search(ip, ix, d, n_cols, q, 50, acc64=True, return_all=True)
+    compare.check_topk_valid(allsc, ids, sc, rtol=RTOL)
+    compare.compare_topk(o_ids, o_sc, ids, sc, rtol=RTOL)
+    assert idx.info().last_path == 2

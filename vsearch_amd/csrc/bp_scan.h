@@ -23,6 +23,7 @@ namespace vs {
 constexpr int kBpRows = 1024;         // documents per block (= threads per workgroup: one document per thread at block end)
 constexpr int kBpCap = 2048;          // candidate slots per (workgroup, query slot)
 constexpr int kBpMaxK = kBpCap - kBpRows;
+constexpr int kBpEntCap = 7168;       // (query, column) entries per tile: 56 KB of LDS, and the 8192-slot entry sort must hold them
 constexpr int kBpGroup = 4;           // lanes walking one posting list, 8 consecutive postings (16-byte loads) per lane and round
 constexpr int kBpBatch = 4;           // posting lists whose loads are in flight together per group (the walk is latency-bound otherwise)
 

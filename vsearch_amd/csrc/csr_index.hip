@@ -750,8 +750,8 @@ int bp_build(vs_index* idx, hipStream_t s) {
 int mq_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64_t id_offset, int64_t* d_ids, float* d_scores,
               const ScanPlan& plan, hipStream_t s, bool* done, int32_t out_ld, int32_t col0, uint64_t* upper) {
     *done = false;
-    const int vals_cap = mq_vals_cap(idx);
     const bool use_bp = idx->bp_ready;
+    const int vals_cap = use_bp ? std::min(mq_vals_cap(idx), kBpEntCap) : mq_vals_cap(idx);     // entries (non-zeros) one tile may hold
     if (vals_cap <= 0 || k > (use_bp ? kBpMaxK : kMaxKMq)) return VS_OK;     // (callers split larger k into passes)
     const int V = idx->n_cols;
     // 1. sparsify the batch: counts -> (qptr, tiles, plan) -> (qcols, qvals)
