@@ -269,7 +269,8 @@ __global__ __launch_bounds__(kScanThreads) void bp_scan_topk(BpArgs a) {
                     // rounds of 32 postings per list; lists longer than one round (popular columns) simply take more rounds
                     while (__builtin_amdgcn_ballot_w64(more)) {
                         uint4 dd[kBpBatch];
-                        float vv[kBpBatch][8];
+                        // values stay as loaded (fp32: 8 registers, fp16: 4 packed) until their list is consumed
+                        uint4 rv[kBpBatch][VM == VM_F32 ? 2 : 1];
 #pragma unroll
                         for (int u = 0; u < kBpBatch; ++u) {
                             if (pp[u] < o1[u]) {
@@ -277,13 +278,10 @@ __global__ __launch_bounds__(kScanThreads) void bp_scan_topk(BpArgs a) {
                                 if constexpr (VM == VM_F32) {
                                     const float4* vp = reinterpret_cast<const float4*>(bval + pp[u] * 4u);
                                     const float4 v0 = vp[0], v1 = vp[1];
-                                    vv[u][0] = v0.x; vv[u][1] = v0.y; vv[u][2] = v0.z; vv[u][3] = v0.w;
-                                    vv[u][4] = v1.x; vv[u][5] = v1.y; vv[u][6] = v1.z; vv[u][7] = v1.w;
+                                    rv[u][0] = make_uint4(__float_as_uint(v0.x), __float_as_uint(v0.y), __float_as_uint(v0.z), __float_as_uint(v0.w));
+                                    rv[u][1] = make_uint4(__float_as_uint(v1.x), __float_as_uint(v1.y), __float_as_uint(v1.z), __float_as_uint(v1.w));
                                 } else {
-                                    const uint4 hv = *reinterpret_cast<const uint4*>(bval + pp[u] * 2u);
-                                    const __half2* h = reinterpret_cast<const __half2*>(&hv);
-#pragma unroll
-                                    for (int t = 0; t < 4; ++t) { const float2 f = __half22float2(h[t]); vv[u][2 * t] = f.x; vv[u][2 * t + 1] = f.y; }
+                                    rv[u][0] = *reinterpret_cast<const uint4*>(bval + pp[u] * 2u);
                                 }
                             }
                         }
@@ -293,12 +291,22 @@ __global__ __launch_bounds__(kScanThreads) void bp_scan_topk(BpArgs a) {
                             if (pp[u] < o1[u]) {
                                 const uint32_t nv = min(8u, o1[u] - pp[u]);
                                 const uint32_t dw[4] = {dd[u].x, dd[u].y, dd[u].z, dd[u].w};
+                                float vv[8];
+                                if constexpr (VM == VM_F32) {
+                                    vv[0] = __uint_as_float(rv[u][0].x); vv[1] = __uint_as_float(rv[u][0].y); vv[2] = __uint_as_float(rv[u][0].z);
+                                    vv[3] = __uint_as_float(rv[u][0].w); vv[4] = __uint_as_float(rv[u][1].x); vv[5] = __uint_as_float(rv[u][1].y);
+                                    vv[6] = __uint_as_float(rv[u][1].z); vv[7] = __uint_as_float(rv[u][1].w);
+                                } else {
+                                    const __half2* h = reinterpret_cast<const __half2*>(&rv[u][0]);
+#pragma unroll
+                                    for (int t = 0; t < 4; ++t) { const float2 f = __half22float2(h[t]); vv[2 * t] = f.x; vv[2 * t + 1] = f.y; }
+                                }
 #pragma unroll
                                 for (int t = 0; t < 8; ++t) {
                                     const uint32_t d = (t & 1) ? (dw[t >> 1] >> 16) : (dw[t >> 1] & 0xFFFFu);
                                     // past the list's end the 16-byte loads picked up the next list's postings (valid documents of this
                                     // block) or zero padding: those lanes add 0.0 -- no branch per posting
-                                    const float prod = (uint32_t)t < nv ? ww[u] * vv[u][t] : 0.f;
+                                    const float prod = (uint32_t)t < nv ? ww[u] * vv[t] : 0.f;
                                     atomicAdd(&acc[d * QT + (qoff[u] ^ (d & 7u))], (double)prod);
                                 }
                             }
