@@ -189,6 +189,7 @@ __global__ __launch_bounds__(kScanThreads) void bp_scan_topk(BpArgs a) {
     const int64_t items = (int64_t)a.n_tiles * a.nchunk;
     const size_t dir_ld = (size_t)a.n_cols + 1;
 
+    // Work items = (tile, chunk), taken round-robin (the host picks nchunk so that an XCD keeps to few chunks, see bp launch)
     for (int64_t item = blockIdx.x; item < items; item += gridDim.x) {
         const int tile = (int)(item / a.nchunk), c = (int)(item % a.nchunk);
         const int q0 = a.tiles[tile].x, nq = a.tiles[tile].y;

@@ -787,6 +787,21 @@ int mq_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64_t id_o
         // blocked postings: chunks are runs of 1024-document blocks
         const int64_t n_blocks = ceil_div64(idx->n_rows, kBpRows);
         nchunk = (int)std::min<int64_t>(nchunk, n_blocks);
+        // Big index: a multiple of 8 chunks, 16 or more.  Workgroup b runs on XCD b % 8 and takes items b, b + grid, ...; with
+        // nchunk % 8 == 0 the 32 CUs behind one L2 only ever touch nchunk / 8 chunks and walk the same block runs for different
+        // tiles at the same time -- tiles share directory and posting lines, and locality decides the speed of this kernel
+        // (21 M docs, 1024 queries: 0.61 s with 16 chunks, 0.69 s with 2, 0.99 s when items are drawn from one global counter).
+        if (n_blocks >= 4096 && (int64_t)n_tiles * 16 >= idx->cu_count) {
+            int best = 16;
+            double best_eff = 0.0;
+            for (int c = 16; c <= 40; c += 8) {
+                const int64_t it = (int64_t)n_tiles * c;
+                const double eff = (double)it / (double)(ceil_div64(it, idx->cu_count) * idx->cu_count);
+                if (eff > best_eff + 1e-9) { best_eff = eff; best = c; }
+                if (eff >= 0.92) break;
+            }
+            nchunk = best;
+        }
         const int64_t blocks_per_chunk = ceil_div64(n_blocks, nchunk);
         const int64_t items = (int64_t)n_tiles * nchunk;
         const int grid = (int)std::min<int64_t>(items, idx->cu_count);
