@@ -79,6 +79,11 @@ extern "C" int vs_index_set_option(vs_index* idx, const char* name, int value) {
         idx->bp_tried = false;
         return VS_OK;
     }
+    if (n == "postings_chunks") {
+        if (value < 0 || value > 4096) return fail(VS_EINVAL, "postings_chunks: 0 = auto, else 1..4096");
+        idx->bp_chunks = value;
+        return VS_OK;
+    }
     if (n == "mq_variant") {
         if (value < -1 || value > 1) return fail(VS_EINVAL, "mq_variant: -1 = auto, 0 = plain, 1 = shared columns");
         idx->mq_variant = value;

@@ -198,6 +198,7 @@ struct vs_index {
     int64_t last_scan_bytes = 0;   // bytes the scan kernels of the most recent search had to read (algorithmic, per path)
     int last_path = 0;             // 0 = one query per pass, 1 = 8-query CSR scan, 2 = blocked postings
     int bp_pref = -1;    // option "blocked_postings": -1 auto, 0 never, 1 always
+    int bp_chunks = 0;   // option "postings_chunks": 0 = auto, else block runs per tile on the postings path
     int mq_variant = -1; // option "mq_variant": -1 auto (from the batch's query overlap), 0 plain, 1 shared columns
     // dense
     vs::DevBuf mat;      // [n_rows, n_cols] store_dtype

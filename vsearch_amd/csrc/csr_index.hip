@@ -791,10 +791,12 @@ int mq_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64_t id_o
         // nchunk % 8 == 0 the 32 CUs behind one L2 only ever touch nchunk / 8 chunks and walk the same block runs for different
         // tiles at the same time -- tiles share directory and posting lines, and locality decides the speed of this kernel
         // (21 M docs, 1024 queries: 0.61 s with 16 chunks, 0.69 s with 2, 0.99 s when items are drawn from one global counter).
-        if (n_blocks >= 4096 && (int64_t)n_tiles * 16 >= idx->cu_count) {
-            int best = 16;
+        // (measured: 8 chunks are best from 2.6 M to 10.5 M docs, 16 at 21 M; below ~2 M docs the fewest chunks that fill the CUs)
+        const int base_chunks = n_blocks >= 16384 ? 16 : 8;
+        if (n_blocks >= 2048 && (int64_t)n_tiles * base_chunks >= idx->cu_count) {
+            int best = base_chunks;
             double best_eff = 0.0;
-            for (int c = 16; c <= 40; c += 8) {
+            for (int c = base_chunks; c <= base_chunks + 24; c += 8) {
                 const int64_t it = (int64_t)n_tiles * c;
                 const double eff = (double)it / (double)(ceil_div64(it, idx->cu_count) * idx->cu_count);
                 if (eff > best_eff + 1e-9) { best_eff = eff; best = c; }
@@ -802,6 +804,7 @@ int mq_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64_t id_o
             }
             nchunk = best;
         }
+        if (idx->bp_chunks > 0) nchunk = (int)std::min<int64_t>(idx->bp_chunks, n_blocks);
         const int64_t blocks_per_chunk = ceil_div64(n_blocks, nchunk);
         const int64_t items = (int64_t)n_tiles * nchunk;
         const int grid = (int)std::min<int64_t>(items, idx->cu_count);
