@@ -325,9 +325,9 @@ __global__ __launch_bounds__(kScanThreads) void bp_scan_topk(BpArgs a) {
                 if (row < a.n_rows) {
 #pragma unroll
                     for (int q = 0; q < QT; ++q) {
-                        const double sum = pa[q ^ (tid & 7)];            // slot swizzled by document: a document's 64-byte row would
-                        pa[q ^ (tid & 7)] = 0.0;                         // otherwise put every add of a wave on two bank groups
-                        if (q < nq) {
+                        if (q < nq) {                                     // (slots >= nq are never written: a ragged tile skips them)
+                            const double sum = pa[q ^ (tid & 7)];        // slot swizzled by document: a document's 64-byte row would
+                            pa[q ^ (tid & 7)] = 0.0;                     // otherwise put every add of a wave on two bank groups
                             const uint64_t key = make_key((float)sum, (uint32_t)row);
                             if (key > tau[q] && key < upper_sh[q]) {
                                 const uint32_t pos = atomicAdd(&ccnt[q], 1u);
