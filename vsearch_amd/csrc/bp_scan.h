@@ -235,45 +235,47 @@ __global__ __launch_bounds__(kScanThreads) void bp_scan_topk(BpArgs a) {
                 // fetches the next slot's pair while the current one is walked.  A lane takes 8 consecutive postings of a list per
                 // round (one 16-byte load of document ids, two of values); the kBpBatch lists of a slot are loaded before any
                 // multiply-add, so ~32 postings per lane are in flight.
-                uint32_t nlo = 0, nhi = 0;
-                {
-                    const int e = gid + NG * gl;
+                constexpr int SL = 1;                             // slots per trip (2 for the fp16 copy spills in the walk: measured 2.6x slower),
+                constexpr int NB = kBpBatch * SL;                 // lists in flight per quad
+                uint32_t nlo[SL], nhi[SL];
+#pragma unroll
+                for (int sl = 0; sl < SL; ++sl) {
+                    const int e = gid + NG * (gl + kBpGroup * sl);
+                    nlo[sl] = 0; nhi[sl] = 0;
                     if (e < n_ent) {
                         const uint32_t cc = ent[e].x & 0xFFFFu;
-                        nlo = dirb[cc];
-                        nhi = dirb[cc + 1];
+                        nlo[sl] = dirb[cc];
+                        nhi[sl] = dirb[cc + 1];
                     }
                 }
-                for (int j = 0; gid + NG * (kBpGroup * j) < n_ent; ++j) {
-                    const uint32_t clo = nlo, chi = nhi;
-                    nlo = 0; nhi = 0;
-                    {
-                        const int e = gid + NG * (gl + kBpGroup * (j + 1));
+                for (int j = 0; gid + NG * (kBpGroup * j) < n_ent; j += SL) {
+                    uint32_t clo[SL], chi[SL];
+#pragma unroll
+                    for (int sl = 0; sl < SL; ++sl) {
+                        clo[sl] = nlo[sl]; chi[sl] = nhi[sl];
+                        nlo[sl] = 0; nhi[sl] = 0;
+                        const int e = gid + NG * (gl + kBpGroup * (j + SL + sl));
                         if (e < n_ent) {
                             const uint32_t cc = ent[e].x & 0xFFFFu;
-                            nlo = dirb[cc];
-                            nhi = dirb[cc + 1];
+                            nlo[sl] = dirb[cc];
+                            nhi[sl] = dirb[cc + 1];
                         }
                     }
-                    uint32_t pp[kBpBatch], o1[kBpBatch], qoff[kBpBatch];
-                    float ww[kBpBatch];
+                    uint32_t pp[NB], o1[NB];
                     bool more = false;
 #pragma unroll
-                    for (int u = 0; u < kBpBatch; ++u) {                                 // kBpBatch == kBpGroup: owner lane u holds entry u of this slot
-                        const uint32_t lo = __shfl(clo, u, kBpGroup), hi = __shfl(chi, u, kBpGroup);
-                        const int e = gid + NG * (u + kBpGroup * j);
-                        const uint2 en = ent[e < n_ent ? e : 0];
-                        qoff[u] = en.x >> 16; ww[u] = __uint_as_float(en.y);
+                    for (int u = 0; u < NB; ++u) {                                       // owner lane u % 4 holds the pair of entry u % 4 of slot j + u / 4
+                        const uint32_t lo = __shfl(clo[u / kBpGroup], u % kBpGroup, kBpGroup), hi = __shfl(chi[u / kBpGroup], u % kBpGroup, kBpGroup);
                         pp[u] = lo + 8u * gl; o1[u] = hi;
                         more = more || (pp[u] < o1[u]);
                     }
                     // rounds of 32 postings per list; lists longer than one round (popular columns) simply take more rounds
                     while (__builtin_amdgcn_ballot_w64(more)) {
-                        uint4 dd[kBpBatch];
+                        uint4 dd[NB];
                         // values stay as loaded (fp32: 8 registers, fp16: 4 packed) until their list is consumed
-                        uint4 rv[kBpBatch][VM == VM_F32 ? 2 : 1];
+                        uint4 rv[NB][VM == VM_F32 ? 2 : 1];
 #pragma unroll
-                        for (int u = 0; u < kBpBatch; ++u) {
+                        for (int u = 0; u < NB; ++u) {
                             if (pp[u] < o1[u]) {
                                 dd[u] = *reinterpret_cast<const uint4*>(bdoc + pp[u] * 2u);
                                 if constexpr (VM == VM_F32) {
@@ -288,8 +290,11 @@ __global__ __launch_bounds__(kScanThreads) void bp_scan_topk(BpArgs a) {
                         }
                         more = false;
 #pragma unroll
-                        for (int u = 0; u < kBpBatch; ++u) {
+                        for (int u = 0; u < NB; ++u) {
                             if (pp[u] < o1[u]) {
+                                const uint2 en = ent[gid + NG * (u + kBpGroup * j)];     // (column | slot << 16, weight): one LDS broadcast per quad
+                                const uint32_t qo = en.x >> 16;
+                                const float wq = __uint_as_float(en.y);
                                 const uint32_t nv = min(8u, o1[u] - pp[u]);
                                 const uint32_t dw[4] = {dd[u].x, dd[u].y, dd[u].z, dd[u].w};
                                 float vv[8];
@@ -307,8 +312,8 @@ __global__ __launch_bounds__(kScanThreads) void bp_scan_topk(BpArgs a) {
                                     const uint32_t d = (t & 1) ? (dw[t >> 1] >> 16) : (dw[t >> 1] & 0xFFFFu);
                                     // past the list's end the 16-byte loads picked up the next list's postings (valid documents of this
                                     // block) or zero padding: those lanes add 0.0 -- no branch per posting
-                                    const float prod = (uint32_t)t < nv ? ww[u] * vv[t] : 0.f;
-                                    atomicAdd(&acc[d * QT + (qoff[u] ^ (d & 7u))], (double)prod);
+                                    const float prod = (uint32_t)t < nv ? wq * vv[t] : 0.f;
+                                    atomicAdd(&acc[d * QT + (qo ^ (d & 7u))], (double)prod);
                                 }
                             }
                             pp[u] += 8u * kBpGroup;
