@@ -328,9 +328,9 @@ __global__ __launch_bounds__(kScanThreads) void bp_scan_topk(BpArgs a) {
                 const int64_t row = b * kBpRows + tid;
                 double* pa = acc + (size_t)tid * QT;
                 if (row < a.n_rows) {
-#pragma unroll
-                    for (int q = 0; q < QT; ++q) {
-                        if (q < nq) {                                     // (slots >= nq are never written: a ragged tile skips them)
+#pragma unroll 1
+                    for (int q = 0; q < nq; ++q) {                        // (slots >= nq are never written: a ragged tile skips them;
+                        {                                                 //  not unrolled: 8 hoisted candidate-buffer addresses spill into the walk)
                             const double sum = pa[q ^ (tid & 7)];        // slot swizzled by document: a document's 64-byte row would
                             pa[q ^ (tid & 7)] = 0.0;                     // otherwise put every add of a wave on two bank groups
                             const uint64_t key = make_key((float)sum, (uint32_t)row);
