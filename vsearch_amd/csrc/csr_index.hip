@@ -930,16 +930,17 @@ int vs_csr_search(vs_index* idx, const void* q, int q_dtype, int64_t ldq, int32_
         bool done = false;
         // k > kMaxKMq: "search after" passes of kMaxKMq ranks each (the k-th key of a pass is the next pass's exclusive
         // upper bound); large batches are cut so that the candidate scratch stays bounded
-        const int mq_passes = ceil_div(k, kMaxKMq);
-        const int kk_mq = std::min<int>(k, kMaxKMq);
+        const int max_k = idx->bp_ready ? kBpMaxK : kMaxKMq;      // ranks one pass delivers (1024 on the postings path, 512 on the CSR scan)
+        const int mq_passes = ceil_div(k, max_k);
+        const int kk_mq = std::min<int>(k, max_k);
         DevBuf mq_upper;
         if (mq_passes > 1) VS_TRY(mq_upper.alloc((size_t)B * 8));
         const size_t per_q_mq = (size_t)plan.nchunk * kk_mq * 8;
         const int bs_mq = (int)std::max<size_t>(1, std::min<size_t>((size_t)B, ((size_t)1 << 30) / per_q_mq));
         bool all = true;
         for (int pass = 0; pass < mq_passes && all; ++pass) {
-            const int col0 = pass * kMaxKMq;
-            const int kk = std::min(k - col0, kMaxKMq);
+            const int col0 = pass * max_k;
+            const int kk = std::min(k - col0, max_k);
             for (int b0 = 0; b0 < B && all; b0 += bs_mq) {
                 const int bs = std::min(bs_mq, B - b0);
                 VS_TRY(mq_search(idx, dq + (size_t)b0 * idx->n_cols, bs, kk, id_offset, d_ids + (size_t)b0 * k, d_scores + (size_t)b0 * k, plan, s,
