@@ -3,14 +3,16 @@
 
 Metric (BASELINE.json): queries/sec over a 21 M-doc sparse CSR index (V = 29 523, 768 nnz/doc, fp32),
 k = 100.  One "step" = one batch of B = 1024 synthetic queries (768 + 8 nnz each) searched against
-the whole index: CSR scoring pass + fused top-k + merge (+ one all-gather and a final merge when the
-index is row-sharded over N GPUs).  Index and queries are resident in HBM when the timed region
+the whole index: scoring scan + fused top-k + merge (+ one all-gather and a final merge when the
+index is row-sharded over N GPUs).  The scan is the blocked-postings kernel when HBM has room for the
+column-grouped copy of the shard (default; it is built as part of the index build), else the 8-query CSR
+scan (`--scan csr` forces it).  Index and queries are resident in HBM when the timed region
 starts.  Strong scaling: the 21 015 324-row index is re-partitioned over the N ranks.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line (rank 0) with `roofline` (dominant kernel: the CSR scan, HBM-bound) and
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel: the scan, HBM roofline) and
 `cpu_baseline` (the reference's three torch calls, oracle/torch_ref.py, timed on this host).
 """
 import argparse
