@@ -23,6 +23,8 @@ namespace vs {
 constexpr int kBpRows = 1024;         // documents per block (= threads per workgroup: one document per thread at block end)
 constexpr int kBpCap = 2048;          // candidate slots per (workgroup, query slot)
 constexpr int kBpMaxK = kBpCap - kBpRows;
+constexpr int kBpPitch = 9;           // accumulator row pitch in doubles (8 slots + 1): a document's row starts 72 B after its neighbour's, so
+                                      // the adds of a wave spread over all LDS banks and the address is ONE mad (document * 72 + slot * 8)
 constexpr int kBpEntCap = 7168;       // (query, column) entries per tile: 56 KB of LDS, and the 8192-slot entry sort must hold them
 constexpr int kBpGroup = 4;           // lanes walking one posting list, 8 consecutive postings (16-byte loads) per lane and round
 constexpr int kBpBatch = 4;           // posting lists whose loads are in flight together per group (the walk is latency-bound otherwise)
@@ -163,17 +165,17 @@ struct BpArgs {
 
 template <int QT>
 __host__ __device__ inline size_t bp_lds_bytes(int ent_cap) {
-    return (size_t)kBpRows * QT * 8 + (size_t)kBpCap * 8 + (size_t)QT * 16 + 64 * 4 + (size_t)ent_cap * 8;
+    return (size_t)kBpRows * kBpPitch * 8 + (size_t)kBpCap * 8 + (size_t)QT * 16 + 64 * 4 + (size_t)ent_cap * 8;
 }
 
 template <int VM, int QT>
 __global__ __launch_bounds__(kScanThreads) void bp_scan_topk(BpArgs a) {
     static_assert(kBpRows == kScanThreads, "one document per thread at block end");
     static_assert(kBpBatch == kBpGroup, "one directory-owning lane per list of a batch");
-    static_assert(QT == 8, "the accumulator swizzle assumes 8 slots per document");
+    static_assert(QT < kBpPitch && QT * kBpRows >= 8192, "row pitch covers the slots; the accumulator area holds the 8192-slot entry sort");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    double* acc = reinterpret_cast<double*>(smem);                                  // [kBpRows][QT]
-    uint64_t* sortbuf = reinterpret_cast<uint64_t*>(acc + kBpRows * QT);            // [kBpCap]
+    double* acc = reinterpret_cast<double*>(smem);                                  // [kBpRows][kBpPitch]
+    uint64_t* sortbuf = reinterpret_cast<uint64_t*>(acc + kBpRows * kBpPitch);      // [kBpCap]
     unsigned long long* tau = reinterpret_cast<unsigned long long*>(sortbuf + kBpCap);   // [QT]
     unsigned long long* upper_sh = tau + QT;                                        // [QT] exclusive upper bounds ("search after")
     int* scratch = reinterpret_cast<int*>(upper_sh + QT);                           // [48]
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(kScanThreads) void bp_scan_topk(BpArgs a) {
             }
             __syncthreads();
         }
-        for (int i = tid; i < kBpRows * QT; i += kScanThreads) acc[i] = 0.0;
+        for (int i = tid; i < kBpRows * kBpPitch; i += kScanThreads) acc[i] = 0.0;
         if (tid < QT) { tau[tid] = 0ull; ccnt[tid] = 0u; }
         if (tid < QT) upper_sh[tid] = (a.upper && tid < nq) ? a.upper[q0 + tid] : ~0ull;
         __syncthreads();
@@ -313,7 +315,7 @@ __global__ __launch_bounds__(kScanThreads) void bp_scan_topk(BpArgs a) {
                                     // past the list's end the 16-byte loads picked up the next list's postings (valid documents of this
                                     // block) or zero padding: those lanes add 0.0 -- no branch per posting
                                     const float prod = (uint32_t)t < nv ? wq * vv[t] : 0.f;
-                                    atomicAdd(&acc[d * QT + (qo ^ (d & 7u))], (double)prod);
+                                    atomicAdd(&acc[d * kBpPitch + qo], (double)prod);
                                 }
                             }
                             pp[u] += 8u * kBpGroup;
@@ -326,13 +328,13 @@ __global__ __launch_bounds__(kScanThreads) void bp_scan_topk(BpArgs a) {
             __syncthreads();
             if (b < b1) {       // one document per thread: its QT sums -> order keys -> candidates
                 const int64_t row = b * kBpRows + tid;
-                double* pa = acc + (size_t)tid * QT;
+                double* pa = acc + (size_t)tid * kBpPitch;
                 if (row < a.n_rows) {
 #pragma unroll 1
                     for (int q = 0; q < nq; ++q) {                        // (slots >= nq are never written: a ragged tile skips them;
                         {                                                 //  not unrolled: 8 hoisted candidate-buffer addresses spill into the walk)
-                            const double sum = pa[q ^ (tid & 7)];        // slot swizzled by document: a document's 64-byte row would
-                            pa[q ^ (tid & 7)] = 0.0;                     // otherwise put every add of a wave on two bank groups
+                            const double sum = pa[q];
+                            pa[q] = 0.0;
                             const uint64_t key = make_key((float)sum, (uint32_t)row);
                             if (key > tau[q] && key < upper_sh[q]) {
                                 const uint32_t pos = atomicAdd(&ccnt[q], 1u);
