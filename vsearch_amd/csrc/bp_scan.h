@@ -314,7 +314,8 @@ __global__ __launch_bounds__(kScanThreads) void bp_scan_topk(BpArgs a) {
                                     const uint32_t d = (t & 1) ? (dw[t >> 1] >> 16) : (dw[t >> 1] & 0xFFFFu);
                                     // past the list's end the 16-byte loads picked up the next list's postings (valid documents of this
                                     // block) or zero padding: those lanes add 0.0 -- no branch per posting
-                                    const float prod = (uint32_t)t < nv ? wq * vv[t] : 0.f;
+                                    const float vsel = (uint32_t)t < nv ? vv[t] : 0.f;     // select on the fp32 value (one cndmask), not on the double
+                                    const float prod = wq * vsel;
                                     atomicAdd(&acc[d * kBpPitch + qo], (double)prod);
                                 }
                             }
