@@ -152,6 +152,7 @@ VS_API int  vs_index_set_queries_per_pass(vs_index* index, int qt);
  *   "blocked_postings"  -1 = auto (long-row valued indexes, when HBM has room for the second copy), 0 = off, 1 = on:
  *                       sparse queries are scored from a row-blocked, column-grouped copy of the index that is built on
  *                       first use -- a query tile reads only the posting lists of its own columns
+ *   "postings_rows"     0 = auto (a column's list in a block averages ~20 postings), else documents per block of the copy
  *   "postings_chunks"   0 = auto, else the number of block runs the postings scan cuts the index into (work items = tiles x runs)
  *   "mq_variant"        -1 = auto (from the batch's query overlap), 0 = plain, 1 = shared-column variant of the 8-query scan */
 VS_API int  vs_index_set_option(vs_index* index, const char* name, int value);

@@ -79,6 +79,12 @@ extern "C" int vs_index_set_option(vs_index* idx, const char* name, int value) {
         idx->bp_tried = false;
         return VS_OK;
     }
+    if (n == "postings_rows") {
+        if (value != 0 && (value < 256 || value > 1024 || value % 64)) return fail(VS_EINVAL, "postings_rows: 0 = auto, else a multiple of 64 in 256..1024");
+        idx->bp_rows_pref = value;
+        idx->bp_dir.release(); idx->bp_doc.release(); idx->bp_val.release(); idx->bp_ready = false; idx->bp_tried = false;
+        return VS_OK;
+    }
     if (n == "postings_chunks") {
         if (value < 0 || value > 4096) return fail(VS_EINVAL, "postings_chunks: 0 = auto, else 1..4096");
         idx->bp_chunks = value;

@@ -20,7 +20,9 @@
 
 namespace vs {
 
-constexpr int kBpRows = 1024;         // documents per block (= threads per workgroup: one document per thread at block end)
+constexpr int kBpRows = 1024;         // most documents per block (= threads per workgroup: one document per thread at block end); the actual
+                                      // count is picked at build time so that a column's list in a block averages ~20 postings: lists beyond
+                                      // the 32 a quad takes per round cost the whole wave a second, mostly idle round
 constexpr int kBpCap = 2048;          // candidate slots per (workgroup, query slot)
 constexpr int kBpMaxK = kBpCap - kBpRows;
 constexpr int kBpPitch = 9;           // accumulator row pitch in doubles (8 slots + 1): a document's row starts 72 B after its neighbour's, so
@@ -40,15 +42,15 @@ __host__ __device__ inline size_t bp_postings_capacity(int64_t n_packets, int64_
 // ---- builder: one workgroup per block; counts per column -> directory -> scatter ----------------------
 template <int VM>
 __global__ __launch_bounds__(kScanThreads) void bp_build_kernel(const uint32_t* pk_ptr, const uint4* cols, const void* vals, int64_t n_rows,
-                                                                int32_t n_cols, uint32_t* dir, uint16_t* pdoc, void* pval) {
+                                                                int32_t n_cols, int32_t rows, uint32_t* dir, uint16_t* pdoc, void* pval) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint32_t* cnt = reinterpret_cast<uint32_t*>(smem);                  // [n_cols + 1]
     __shared__ int scratch[32];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int64_t n_blocks = (n_rows + kBpRows - 1) / kBpRows;
+    const int64_t n_blocks = (n_rows + rows - 1) / rows;
     const int seg = (n_cols + 1 + kScanThreads - 1) / kScanThreads;
     for (int64_t b = blockIdx.x; b < n_blocks; b += gridDim.x) {
-        const int64_t r0 = b * kBpRows, r1 = min(n_rows, r0 + kBpRows);
+        const int64_t r0 = b * rows, r1 = min(n_rows, r0 + rows);
         const uint32_t P0 = pk_ptr[r0], P1 = pk_ptr[r1];
         __syncthreads();
         for (int i = tid; i <= n_cols; i += kScanThreads) cnt[i] = 0;
@@ -143,7 +145,8 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_kernel(const uint32_t* c
 }
 
 struct BpArgs {
-    const uint32_t* pk_ptr;   // [n_rows + 1] (block b's postings start at 8 * pk_ptr[b * kBpRows])
+    const uint32_t* pk_ptr;   // [n_rows + 1] (block b's postings start at bp_block_base(pk_ptr[b * rows], b))
+    int32_t rows;             // documents per block (<= kBpRows)
     const uint32_t* dir;      // [n_blocks, n_cols + 1]
     const uint16_t* pdoc;
     const void* pval;
@@ -187,7 +190,7 @@ __global__ __launch_bounds__(kScanThreads) void bp_scan_topk(BpArgs a) {
     constexpr int NG = kScanThreads / kBpGroup;                                     // 64 groups
     const int K = a.k;
     uint64_t* my_gcand = a.gcand + (size_t)blockIdx.x * QT * kBpCap;
-    const int64_t n_blocks = (a.n_rows + kBpRows - 1) / kBpRows;
+    const int64_t n_blocks = (a.n_rows + a.rows - 1) / a.rows;
     const int64_t items = (int64_t)a.n_tiles * a.nchunk;
     const size_t dir_ld = (size_t)a.n_cols + 1;
 
@@ -229,7 +232,7 @@ __global__ __launch_bounds__(kScanThreads) void bp_scan_topk(BpArgs a) {
         for (int64_t b = b0; b < b1 || b == b0; ++b) {
             if (b < b1) {
                 const uint32_t* dirb = a.dir + (size_t)b * dir_ld;
-                const size_t base = bp_block_base(a.pk_ptr[b * kBpRows], b, a.n_cols);
+                const size_t base = bp_block_base(a.pk_ptr[b * a.rows], b, a.n_cols);
                 // block-uniform base pointers + 32-bit byte offsets: the loads take the scalar-base form, no 64-bit address per lane
                 const char* bdoc = reinterpret_cast<const char*>(a.pdoc + base);
                 const char* bval = reinterpret_cast<const char*>(a.pval) + base * (VM == VM_F32 ? 4 : 2);
@@ -328,9 +331,9 @@ __global__ __launch_bounds__(kScanThreads) void bp_scan_topk(BpArgs a) {
             }
             __syncthreads();
             if (b < b1) {       // one document per thread: its QT sums -> order keys -> candidates
-                const int64_t row = b * kBpRows + tid;
+                const int64_t row = b * a.rows + tid;
                 double* pa = acc + (size_t)tid * kBpPitch;
-                if (row < a.n_rows) {
+                if (tid < a.rows && row < a.n_rows) {
 #pragma unroll 1
                     for (int q = 0; q < nq; ++q) {                        // (slots >= nq are never written: a ragged tile skips them;
                         {                                                 //  not unrolled: 8 hoisted candidate-buffer addresses spill into the walk)
@@ -349,7 +352,7 @@ __global__ __launch_bounds__(kScanThreads) void bp_scan_topk(BpArgs a) {
             const bool last = b + 1 >= b1;
             for (int qs = 0; qs < nq; ++qs) {
                 const uint32_t cnt = ccnt[qs];
-                if (last || cnt > (uint32_t)(kBpCap - kBpRows)) {
+                if (last || cnt > (uint32_t)(kBpCap - a.rows)) {
                     for (int i = tid; i < kBpCap; i += kScanThreads) sortbuf[i] = (uint32_t)i < cnt ? my_gcand[(size_t)qs * kBpCap + i] : 0ull;
                     wg_sort_desc<kScanThreads>(sortbuf, kBpCap, tid);
                     if (last) {

@@ -194,10 +194,12 @@ struct vs_index {
     vs::DevBuf bp_doc;   // uint16 [n_packets * 8]
     vs::DevBuf bp_val;   // fp32 / fp16 [n_packets * 8]
     vs::DevBuf bp_df;    // uint32 [n_cols]: postings per column over all blocks (incl. pad postings) -- what a query entry streams
+    int bp_rows = 1024;  // documents per block of the copy (picked at build time)
     bool bp_ready = false, bp_tried = false;
     int64_t last_scan_bytes = 0;   // bytes the scan kernels of the most recent search had to read (algorithmic, per path)
     int last_path = 0;             // 0 = one query per pass, 1 = 8-query CSR scan, 2 = blocked postings
     int bp_pref = -1;    // option "blocked_postings": -1 auto, 0 never, 1 always
+    int bp_rows_pref = 0;// option "postings_rows": 0 = auto, else documents per block (multiple of 64, 256..1024); applies at the next build
     int bp_chunks = 0;   // option "postings_chunks": 0 = auto, else block runs per tile on the postings path
     int mq_variant = -1; // option "mq_variant": -1 auto (from the batch's query overlap), 0 plain, 1 shared columns
     // dense

@@ -707,7 +707,14 @@ bool bp_wanted(const vs_index* idx) {
 int bp_build(vs_index* idx, hipStream_t s) {
     idx->bp_tried = true;
     idx->bp_ready = false;
-    const int64_t n_blocks = ceil_div64(idx->n_rows, kBpRows);
+    // documents per block: a column's list in a block should average ~22 postings (rows x nnz-per-row / columns)
+    {
+        const double per_row = (double)idx->nnz / (double)idx->n_rows / (double)idx->n_cols;      // P(a document has a given column)
+        int rows = (int)(22.0 / std::max(per_row, 1e-9));                                       // (measured flat optimum: 20-24)
+        rows = std::max(256, std::min(kBpRows, rows / 64 * 64));
+        idx->bp_rows = idx->bp_rows_pref > 0 ? idx->bp_rows_pref : rows;
+    }
+    const int64_t n_blocks = ceil_div64(idx->n_rows, idx->bp_rows);
     const size_t cap = bp_postings_capacity(idx->n_packets, n_blocks, idx->n_cols);
     const size_t b_dir = (size_t)n_blocks * ((size_t)idx->n_cols + 1) * 4, b_doc = cap * 2, b_val = cap * (idx->store_dtype == VS_F32 ? 4 : 2);
     size_t free_b = 0, total_b = 0;
@@ -727,11 +734,11 @@ int bp_build(vs_index* idx, hipStream_t s) {
     if (idx->store_dtype == VS_F32) {
         VS_HIP(hipFuncSetAttribute((const void*)bp_build_kernel<VM_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((bp_build_kernel<VM_F32>), dim3(grid), dim3(kScanThreads), lds, s, idx->pk_ptr.as<uint32_t>(), idx->cols.as<uint4>(),
-                           (const void*)idx->vals.p, idx->n_rows, idx->n_cols, idx->bp_dir.as<uint32_t>(), idx->bp_doc.as<uint16_t>(), idx->bp_val.p);
+                           (const void*)idx->vals.p, idx->n_rows, idx->n_cols, idx->bp_rows, idx->bp_dir.as<uint32_t>(), idx->bp_doc.as<uint16_t>(), idx->bp_val.p);
     } else {
         VS_HIP(hipFuncSetAttribute((const void*)bp_build_kernel<VM_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((bp_build_kernel<VM_F16>), dim3(grid), dim3(kScanThreads), lds, s, idx->pk_ptr.as<uint32_t>(), idx->cols.as<uint4>(),
-                           (const void*)idx->vals.p, idx->n_rows, idx->n_cols, idx->bp_dir.as<uint32_t>(), idx->bp_doc.as<uint16_t>(), idx->bp_val.p);
+                           (const void*)idx->vals.p, idx->n_rows, idx->n_cols, idx->bp_rows, idx->bp_dir.as<uint32_t>(), idx->bp_doc.as<uint16_t>(), idx->bp_val.p);
     }
     VS_HIP(hipGetLastError());
     if (idx->bp_df.alloc((size_t)idx->n_cols * 4) == VS_OK) {
@@ -785,15 +792,15 @@ int mq_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64_t id_o
     int nchunk = choose_chunks(idx, n_tiles, plan.nchunk);
     if (use_bp) {
         // blocked postings: chunks are runs of 1024-document blocks
-        const int64_t n_blocks = ceil_div64(idx->n_rows, kBpRows);
+        const int64_t n_blocks = ceil_div64(idx->n_rows, idx->bp_rows);
         nchunk = (int)std::min<int64_t>(nchunk, n_blocks);
         // Big index: a multiple of 8 chunks, 16 or more.  Workgroup b runs on XCD b % 8 and takes items b, b + grid, ...; with
         // nchunk % 8 == 0 the 32 CUs behind one L2 only ever touch nchunk / 8 chunks and walk the same block runs for different
         // tiles at the same time -- tiles share directory and posting lines, and locality decides the speed of this kernel
         // (21 M docs, 1024 queries: 0.61 s with 16 chunks, 0.69 s with 2, 0.99 s when items are drawn from one global counter).
         // (measured: 8 chunks are best from 2.6 M to 10.5 M docs, 16 at 21 M; below ~2 M docs the fewest chunks that fill the CUs)
-        const int base_chunks = n_blocks >= 16384 ? 16 : 8;
-        if (n_blocks >= 2048 && (int64_t)n_tiles * base_chunks >= idx->cu_count) {
+        const int base_chunks = idx->n_rows >= (16 << 20) ? 16 : 8;
+        if (idx->n_rows >= (2 << 20) && (int64_t)n_tiles * base_chunks >= idx->cu_count) {
             int best = base_chunks;
             double best_eff = 0.0;
             for (int c = base_chunks; c <= base_chunks + 24; c += 8) {
@@ -812,6 +819,7 @@ int mq_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64_t id_o
         VS_TRY(idx->ws_cand.reserve((size_t)B * nchunk * k * 8));
         BpArgs a{};
         a.pk_ptr = idx->pk_ptr.as<uint32_t>();
+        a.rows = idx->bp_rows;
         a.dir = idx->bp_dir.as<uint32_t>();
         a.pdoc = idx->bp_doc.as<uint16_t>();
         a.pval = idx->bp_val.p;
