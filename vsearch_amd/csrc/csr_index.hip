@@ -794,16 +794,15 @@ int mq_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64_t id_o
         // blocked postings: chunks are runs of 1024-document blocks
         const int64_t n_blocks = ceil_div64(idx->n_rows, idx->bp_rows);
         nchunk = (int)std::min<int64_t>(nchunk, n_blocks);
-        // Big index: a multiple of 8 chunks, 16 or more.  Workgroup b runs on XCD b % 8 and takes items b, b + grid, ...; with
-        // nchunk % 8 == 0 the 32 CUs behind one L2 only ever touch nchunk / 8 chunks and walk the same block runs for different
-        // tiles at the same time -- tiles share directory and posting lines, and locality decides the speed of this kernel
-        // (21 M docs, 1024 queries: 0.61 s with 16 chunks, 0.69 s with 2, 0.99 s when items are drawn from one global counter).
-        // (measured: 8 chunks are best from 2.6 M to 10.5 M docs, 16 at 21 M; below ~2 M docs the fewest chunks that fill the CUs)
-        const int base_chunks = idx->n_rows >= (16 << 20) ? 16 : 8;
-        if (idx->n_rows >= (2 << 20) && (int64_t)n_tiles * base_chunks >= idx->cu_count) {
-            int best = base_chunks;
+        // Big index: 12 chunks (or 16 / 24 when that fills the CUs better).  Workgroup b runs on XCD b % 8 and takes items
+        // b, b + grid, ...; what matters is how many chunks the 32 CUs behind one L2 work on at a time: tiles share directory
+        // and posting lines, so few chunks per XCD is good -- but exactly one (8 chunks) makes 32 workgroups hammer the same
+        // lines and is as slow as no affinity at all.  Measured, 1024 queries: 21 M docs 505 ms (12) / 508 (16) / 607 (8) /
+        // 592 (2) / 625 (20), 0.99 s with items drawn from a global counter; 10.5 M docs 255 (12) / 301 (8); 2.6 M 67 / 73.
+        if (idx->n_rows >= (2 << 20) && (int64_t)n_tiles * 12 >= idx->cu_count) {
+            int best = 12;
             double best_eff = 0.0;
-            for (int c = base_chunks; c <= base_chunks + 24; c += 8) {
+            for (int c : {12, 16, 24}) {
                 const int64_t it = (int64_t)n_tiles * c;
                 const double eff = (double)it / (double)(ceil_div64(it, idx->cu_count) * idx->cu_count);
                 if (eff > best_eff + 1e-9) { best_eff = eff; best = c; }
