@@ -794,15 +794,16 @@ int mq_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64_t id_o
         // blocked postings: chunks are runs of 1024-document blocks
         const int64_t n_blocks = ceil_div64(idx->n_rows, idx->bp_rows);
         nchunk = (int)std::min<int64_t>(nchunk, n_blocks);
-        // Big index: 12 chunks (or 16 / 24 when that fills the CUs better).  Workgroup b runs on XCD b % 8 and takes items
+        // Big index: 16 chunks (or 12 / 24 when that fills the CUs better).  Workgroup b runs on XCD b % 8 and takes items
         // b, b + grid, ...; what matters is how many chunks the 32 CUs behind one L2 work on at a time: tiles share directory
         // and posting lines, so few chunks per XCD is good -- but exactly one (8 chunks) makes 32 workgroups hammer the same
         // lines and is as slow as no affinity at all.  Measured, 1024 queries: 21 M docs 505 ms (12) / 508 (16) / 607 (8) /
         // 592 (2) / 625 (20), 0.99 s with items drawn from a global counter; 10.5 M docs 255 (12) / 301 (8); 2.6 M 67 / 73.
+        // (12 and 16 tie on time; 16 leaves 40 % less HBM traffic: 1.09 vs 1.81 TB per 1024 queries at 21 M docs)
         if (idx->n_rows >= (2 << 20) && (int64_t)n_tiles * 12 >= idx->cu_count) {
-            int best = 12;
+            int best = 16;
             double best_eff = 0.0;
-            for (int c : {12, 16, 24}) {
+            for (int c : {16, 12, 24}) {
                 const int64_t it = (int64_t)n_tiles * c;
                 const double eff = (double)it / (double)(ceil_div64(it, idx->cu_count) * idx->cu_count);
                 if (eff > best_eff + 1e-9) { best_eff = eff; best = c; }
