@@ -2,14 +2,14 @@
 //
 // The CSR scan (csr_scan_mq.h) looks every index non-zero up in the tile table, although only ~2.6 % x Qt of
 // them carry a query weight -- and at Qt = 8 that lookup + hit handling (VALU issue), not HBM, bounds the pass.
-// Here the rows are cut into blocks of kBpRows documents; inside a block the non-zeros are grouped by column
-// (dir[b][c] .. dir[b][c+1] = the postings (document-in-block uint16, value) of column c).  A query tile then
-// walks ONLY the posting lists of its own columns: every visited non-zero is a hit, the lanes of a 16-lane group
-// read one list with contiguous loads, and the products go to fp64 accumulators [document][query slot] in LDS
-// (same numerics as the CSR pass: fp32 product, fp64 sum, order-independent).  One block = 1024 documents x 8
-// queries of accumulators (64 KB); after each block a thread finishes one document (8 sums -> order keys ->
-// candidate buffers), exactly like the per-row epilogue of the CSR pass.  Bytes read per tile = the tile's
-// share of the postings (~21 % of the index at 8 x 776 query non-zeros) + the directory entries.
+// Here the rows are cut into blocks of up to kBpRows documents (sized at build time); inside a block the non-zeros
+// are grouped by column (dir[b][c] .. dir[b][c+1] = the postings (document-in-block uint16, value) of column c).  A
+// query tile then walks ONLY the posting lists of its own columns: every visited non-zero is a hit, a quad of lanes
+// reads one list with 16-byte loads, and the products go to fp64 accumulators [document][query slot] in LDS (same
+// numerics as the CSR pass: fp32 product, fp64 sum, order-independent).  One block = up to 1024 documents x 8 queries
+// of accumulators (72 KB with the row pitch); after each block a thread finishes one document (8 sums -> order keys
+// -> candidate buffers), exactly like the per-row epilogue of the CSR pass.  Bytes read per tile = the tile's share
+// of the postings (~21 % of the index at 8 x 776 query non-zeros) + the directory entries.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
@@ -21,7 +21,7 @@
 namespace vs {
 
 constexpr int kBpRows = 1024;         // most documents per block (= threads per workgroup: one document per thread at block end); the actual
-                                      // count is picked at build time so that a column's list in a block averages ~20 postings: lists beyond
+                                      // count is picked at build time so that a column's list in a block averages ~22 postings: lists beyond
                                       // the 32 a quad takes per round cost the whole wave a second, mostly idle round
 constexpr int kBpCap = 2048;          // candidate slots per (workgroup, query slot)
 constexpr int kBpMaxK = kBpCap - kBpRows;
