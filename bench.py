@@ -116,13 +116,20 @@ def cpu_baseline(sample_docs, device):
 
 def main():
     args = parse()
+    # `python bench.py --gpus N` from a plain shell: this process has not touched the GPU yet; it becomes the parent of N
+    # fresh rank processes (vsearch_amd/launch.py) and exits with their code.  Under torch.distributed.run we already are a rank.
+    from vsearch_amd.launch import relaunch_as_ranks
+    relaunch_as_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:])
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
+    # VS_BENCH_SHARE_GPU=1 (tests on a 1-GPU box): every rank uses cuda:0 and the exchange runs over gloo -- RCCL refuses two
+    # ranks on one device.  Never set for a measurement.
+    share_gpu = os.environ.get("VS_BENCH_SHARE_GPU", "0") == "1"
+    if share_gpu:
+        local_rank = 0
     import torch.distributed as dist
     from vsearch_amd import _native as nat
     from vsearch_amd.device_index import DeviceIndex, Profile
@@ -130,8 +137,12 @@ def main():
     nat.require_device()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    backend = "gloo" if share_gpu else "nccl"
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     row0, n_local = shard_rows(args.docs, world, rank)
     t0 = time.perf_counter()
@@ -167,7 +178,7 @@ def main():
     scan_ms, scan_launches = Profile.read("csr_scan_topk")
     merge_ms, _ = Profile.read("merge_topk")
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -206,6 +217,9 @@ def main():
                        "docs": args.docs, "docs_per_gpu": n_local, "batch": args.batch, "k": args.k, "queries_per_pass": qt,
                        "lanes_per_row": info.lanes_per_row, "index_bytes_per_gpu": info.device_bytes,
                        "postings_copy_bytes_per_gpu": info.aux_bytes, "scan_path": path, "index_build_s": round(build_s, 2)},
+            "exchange": {"backend": ("rccl (torch.distributed nccl)" if backend == "nccl" else backend) if world > 1 else None,
+                         "world_size": dist.get_world_size() if world > 1 else 1,
+                         "collective": "one all_gather_into_tensor of B*k packed (score, global id) int64 per rank + vs_merge_topk" if world > 1 else None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "bp_scan_topk" if info.last_path == 2 else "csr_scan_topk_mq", "launches": scan_launches,
                          "avg_launch_ms": avg_launch_s * 1e3, "algorithmic_bytes_per_launch": algo_bytes_per_launch,

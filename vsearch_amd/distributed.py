@@ -52,6 +52,9 @@ class ShardedSearcher:
                  group: Optional[torch.distributed.ProcessGroup] = None):
         self.local_search, self.merge = local_search, merge
         self.n_local, self.row0, self.n_total, self.group = int(n_local), int(row0), int(n_total), group
+        if self.n_total >= _PAD_ID:
+            # candidates travel as (score bits << 32 | global id): ids are 32-bit on the wire and 2^32 - 1 is the pad sentinel
+            raise ValueError(f"row-sharded search addresses at most {_PAD_ID - 1} documents (n_total = {self.n_total})")
         self.force_exchange = False     # tests: run the all-gather + merge even in a 1-rank group
 
     @classmethod
@@ -80,7 +83,11 @@ class ShardedSearcher:
             ids = torch.cat([ids, torch.full((B, pad), _PAD_ID, dtype=torch.int64, device=ids.device)], 1)
             scores = torch.cat([scores, torch.full((B, pad), float("-inf"), dtype=torch.float32, device=scores.device)], 1)
         packed = pack_candidates(ids, scores).contiguous()
+        dev = packed.device
+        if dev.type == "cuda" and dist.is_initialized() and dist.get_backend(self.group) == "gloo":
+            packed = packed.cpu()            # test rigs only (ranks sharing one GPU): gloo moves host memory
         gathered = torch.empty((world * B, k), dtype=torch.int64, device=packed.device)   # rank-major concatenation
         dist.all_gather_into_tensor(gathered, packed, group=self.group)        # the one exchange step
+        gathered = gathered.to(dev)
         cand_ids, cand_scores = unpack_candidates(gathered.view(world, B, k).permute(1, 0, 2).reshape(B, world * k).contiguous())
         return self.merge(cand_ids.contiguous(), cand_scores.contiguous(), k)
