@@ -73,8 +73,11 @@ typedef struct vs_index_info_t {
                               * bytes_per_pass on the CSR paths; on the blocked-postings path the posting lists of
                               * the queries' columns (document ids + values) + their directory entries            */
     int64_t aux_bytes;       /* bytes of the blocked-postings copy (0 when absent)                      */
-    int32_t last_path;       /* most recent search(): 0 = one query per pass, 1 = 8-query CSR scan, 2 = blocked postings */
-    int32_t reserved;
+    int32_t last_path;       /* most recent search(): 0 = one query per pass, 1 = 8-query CSR scan, 2 = blocked postings
+                              * (fp64 walk), 3 = blocked postings, fixed-point filter walk + exact refine               */
+    int32_t last_fallbacks;  /* path 3: queries of the most recent search() whose top k the refine step could not prove from
+                              * the filter's candidates and that were re-run on the exact walk (reading it synchronises)  */
+    int64_t last_walk_postings; /* postings (multiply-adds into the accumulators) the most recent walk visited          */
 } vs_index_info_t;
 
 /* ---- library ------------------------------------------------------------------------------- */
@@ -154,6 +157,10 @@ VS_API int  vs_index_set_queries_per_pass(vs_index* index, int qt);
  *                       first use -- a query tile reads only the posting lists of its own columns
  *   "postings_rows"     0 = auto (a column's list in a block averages ~20 postings), else documents per block of the copy
  *   "postings_chunks"   0 = auto, else the number of block runs the postings scan cuts the index into (work items = tiles x runs)
+ *   "postings_filter"   1 (default) = the postings walk accumulates int32 fixed-point sums (3.4x the LDS atomic rate of fp64 on
+ *                       MI355X) and returns k + max(28, k/4) candidates per query, which are re-scored with the exact numerics
+ *                       and PROVEN to contain the top k; unproven queries re-run on the fp64 walk.  Results are identical to
+ *                       0 = fp64 walk only
  *   "mq_variant"        -1 = auto (from the batch's query overlap), 0 = plain, 1 = shared-column variant of the 8-query scan */
 VS_API int  vs_index_set_option(vs_index* index, const char* name, int value);
 

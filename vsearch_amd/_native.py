@@ -27,7 +27,8 @@ class IndexInfo(C.Structure):
     _fields_ = [("kind", C.c_int32), ("store_dtype", C.c_int32), ("n_rows", C.c_int64), ("n_cols", C.c_int32),
                 ("device", C.c_int32), ("nnz", C.c_int64), ("n_packets", C.c_int64), ("device_bytes", C.c_int64),
                 ("bytes_per_pass", C.c_int64), ("lanes_per_row", C.c_int32), ("queries_per_pass", C.c_int32),
-                ("last_scan_bytes", C.c_int64), ("aux_bytes", C.c_int64), ("last_path", C.c_int32), ("reserved", C.c_int32)]
+                ("last_scan_bytes", C.c_int64), ("aux_bytes", C.c_int64), ("last_path", C.c_int32), ("last_fallbacks", C.c_int32),
+                ("last_walk_postings", C.c_int64)]
 
 
 _vp, _i32, _i64, _int = C.c_void_p, C.c_int32, C.c_int64, C.c_int

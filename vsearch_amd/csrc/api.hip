@@ -75,19 +75,24 @@ extern "C" int vs_index_set_option(vs_index* idx, const char* name, int value) {
     if (n == "blocked_postings") {
         if (value < -1 || value > 1) return fail(VS_EINVAL, "blocked_postings: -1 = auto, 0 = off, 1 = on");
         idx->bp_pref = value;
-        if (value == 0) { idx->bp_dir.release(); idx->bp_doc.release(); idx->bp_val.release(); idx->bp_ready = false; }
+        if (value == 0) { idx->bp_dir.release(); idx->bp_base.release(); idx->bp_rec.release(); idx->bp_ready = false; }
         idx->bp_tried = false;
         return VS_OK;
     }
     if (n == "postings_rows") {
-        if (value != 0 && (value < 256 || value > 1024 || value % 64)) return fail(VS_EINVAL, "postings_rows: 0 = auto, else a multiple of 64 in 256..1024");
+        if (value != 0 && (value < 256 || value > 2048 || value % 64)) return fail(VS_EINVAL, "postings_rows: 0 = auto, else a multiple of 64 in 256..2048");
         idx->bp_rows_pref = value;
-        idx->bp_dir.release(); idx->bp_doc.release(); idx->bp_val.release(); idx->bp_ready = false; idx->bp_tried = false;
+        idx->bp_dir.release(); idx->bp_base.release(); idx->bp_rec.release(); idx->bp_ready = false; idx->bp_tried = false;
         return VS_OK;
     }
     if (n == "postings_chunks") {
         if (value < 0 || value > 4096) return fail(VS_EINVAL, "postings_chunks: 0 = auto, else 1..4096");
         idx->bp_chunks = value;
+        return VS_OK;
+    }
+    if (n == "postings_filter") {
+        if (value < 0 || value > 1) return fail(VS_EINVAL, "postings_filter: 1 = fixed-point walk + exact refine, 0 = fp64 walk only");
+        idx->bp_filter = value;
         return VS_OK;
     }
     if (n == "mq_variant") {

@@ -1,0 +1,178 @@
+// bp_refine.h -- the "refine" half of the filter-and-refine postings search (see AM_FIX in bp_walk.h).
+//
+// The fixed-point walk returns, per query, the K' > k documents with the largest APPROXIMATE scores.  Here those K'
+// documents are re-scored from their CSR rows with the library's exact numerics (fp32 product, fp64 sum -- what the CSR
+// pass and the fp64 walk compute), the exact top k is written out, and the kernel PROVES per query that no document
+// outside the K' can belong to it:  a document the walk did not return has an approximate sum A <= A_cut (the K'-th best),
+// hence an exact sum below (A_cut + n) / S, n = the query's non-zeros (one unit of truncation per matched term).  If the
+// exact k-th score is above that bound the query is done; otherwise its flag is set and the exact walk re-runs it.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+#include "bp_walk.h"
+
+namespace vs {
+
+// max |value| of a valued index (one float, device) -- bounds every product of the walk
+template <int VM>
+__global__ __launch_bounds__(256) void bp_vmax_kernel(const void* vals, int64_t n, uint32_t* out_bits) {
+    float m = 0.f;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        float v;
+        if constexpr (VM == VM_F32) v = reinterpret_cast<const float*>(vals)[i];
+        else v = __half2float(reinterpret_cast<const __half*>(vals)[i]);
+        m = fmaxf(m, fabsf(v));
+    }
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(out_bits, __float_as_uint(m));       // non-negative floats order like their bits
+}
+
+// Per query: S = 2^e with (sum |w|) * vmax * S < 2^30 (no int32 sum can wrap), and the slack n = non-zeros + 1 in fixed-point
+// units.  n = 0 marks a query whose walk is EXACT (binary index and every w * S an integer): its approximate order is the
+// exact order, nothing to prove.  One wave per query, fixed reduction order.
+template <int UNUSED>
+__global__ __launch_bounds__(256) void bp_qscale_kernel(const int64_t* qptr, const float* qvals, int32_t B, const uint32_t* vmax_bits, int binary,
+                                                        float* qscale, int32_t* qslack) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= B) return;
+    const int64_t e0 = qptr[q], e1 = qptr[q + 1];
+    float sum = 0.f;
+    for (int64_t e = e0 + lane; e < e1; e += 64) sum += fabsf(qvals[e]);
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    const float vmax = binary ? 1.f : __uint_as_float(vmax_bits[0]);
+    const float bound = sum * vmax * 1.0001f;                        // the reduction above is not the walk's order: a hair of slack
+    int e = 0;
+    if (bound > 0.f && isfinite(bound)) {
+        int be;
+        (void)frexpf(bound, &be);                                    // bound < 2^be
+        e = 30 - be;
+    }
+    e = max(-60, min(60, e));
+    const float S = ldexpf(1.f, e);
+    bool exact = binary != 0;
+    if (exact) {
+        for (int64_t x = e0 + lane; x < e1; x += 64) {
+            const float w = qvals[x] * S;
+            exact = exact && (w == truncf(w));
+        }
+        exact = __builtin_amdgcn_ballot_w64(!exact) == 0ull;
+    }
+    if (lane == 0) {
+        qscale[q] = S;
+        qslack[q] = (exact || e1 == e0) ? 0 : (int32_t)min((int64_t)1 << 20, e1 - e0 + 1);
+    }
+}
+
+struct RefineArgs {
+    const uint64_t* cand;     // [B, n_cand] approximate keys (make_key_fix), runs of run_len sorted descending
+    int64_t n_cand;
+    int32_t run_len;
+    int32_t B, k, kp;         // kp = K' documents re-scored per query (k <= kp <= kBpMaxK)
+    const uint32_t* pk_ptr;   // the CSR packets of the same index
+    const uint4* cols;
+    const void* vals;
+    int32_t n_cols;
+    int64_t n_rows;
+    const float* q;           // [B, n_cols] dense fp32 queries (already rounded to the index dtype)
+    const float* qscale;      // [B]
+    const int32_t* qslack;    // [B]
+    int64_t id_offset;
+    int64_t* out_ids;         // [B, out_ld]
+    float* out_scores;
+    int64_t out_ld;
+    uint32_t* flags;          // [B]: 1 = the top k could not be proven from K' candidates -> exact walk
+};
+
+template <int VM>
+__global__ __launch_bounds__(kScanThreads) void refine_topk_kernel(RefineArgs a) {
+    __shared__ uint64_t buf[kWgCap];
+    __shared__ uint64_t ex[kBpMaxK];
+    __shared__ int cnt_sh;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int K = a.k, KP = a.kp;
+    for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+        merge_select(a.cand + (size_t)b * a.n_cand, a.n_cand, a.run_len, KP, nullptr, buf, &cnt_sh, tid);
+        __syncthreads();
+        const uint64_t cut_key = buf[KP - 1];                         // 0: fewer than K' documents exist -> every document is a candidate
+        const float* qrow = a.q + (size_t)b * a.n_cols;
+        int pow2 = 64;
+        while (pow2 < KP) pow2 <<= 1;
+        for (int i = KP + tid; i < pow2; i += kScanThreads) ex[i] = 0ull;
+        // exact scores: one wave per candidate, a lane takes whole packets (8 non-zeros), fp32 products summed in fp64
+        for (int i = w; i < KP; i += kScanWaves) {
+            const uint64_t key = buf[i];
+            uint64_t out = 0ull;
+            if (key != 0ull) {
+                const uint32_t row = key_row(key);
+                const uint32_t p0 = a.pk_ptr[row], p1 = a.pk_ptr[row + 1];
+                double sum = 0.0;
+                for (uint32_t p = p0 + lane; p < p1; p += 64) {
+                    const uint4 cw = a.cols[p];
+                    const uint32_t cwv[4] = {cw.x, cw.y, cw.z, cw.w};
+                    float v[8];
+                    if constexpr (VM == VM_F32) {
+                        const float4* vp = reinterpret_cast<const float4*>(a.vals);
+                        const float4 v0 = vp[2 * (size_t)p], v1 = vp[2 * (size_t)p + 1];
+                        v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
+                    } else if constexpr (VM == VM_F16) {
+                        const uint4 hv = reinterpret_cast<const uint4*>(a.vals)[p];
+                        const __half2* h = reinterpret_cast<const __half2*>(&hv);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) { const float2 f = __half22float2(h[t]); v[2 * t] = f.x; v[2 * t + 1] = f.y; }
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) v[t] = 1.f;
+                    }
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        const uint32_t c = (t & 1) ? (cwv[t >> 1] >> 16) : (cwv[t >> 1] & 0xFFFFu);
+                        const float wq = c < (uint32_t)a.n_cols ? qrow[c] : 0.f;       // pad columns (id n_cols) carry no weight
+                        sum += (double)(wq * v[t]);
+                    }
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+                out = make_key((float)sum, row);
+            }
+            if (lane == 0) ex[i] = out;
+        }
+        wg_sort_desc<kScanThreads>(ex, pow2, tid);
+        for (int i = tid; i < K; i += kScanThreads) {
+            const uint64_t key = ex[i];
+            a.out_ids[(size_t)b * a.out_ld + i] = (int64_t)key_row(key) + a.id_offset;
+            a.out_scores[(size_t)b * a.out_ld + i] = key_score(key);
+        }
+        if (tid == 0) {
+            const int32_t slack = a.qslack[b];
+            bool ok = slack == 0 || cut_key == 0ull;
+            if (!ok) {
+                const double bound = ((double)key_fix(cut_key) + (double)slack) / (double)a.qscale[b];    // exact sums outside the K' stay below
+                float bf = (float)bound;
+                if ((double)bf < bound) bf = nextafterf(bf, INFINITY);
+                ok = ex[K - 1] != 0ull && key_score(ex[K - 1]) > bf;
+            }
+            a.flags[b] = ok ? 0u : 1u;
+        }
+        __syncthreads();
+    }
+}
+
+// flagged queries -> one-query tiles for the exact walk (and the query list of the merge behind it)
+template <int UNUSED>
+__global__ __launch_bounds__(kScanThreads) void fb_plan_kernel(const uint32_t* flags, int32_t B, int2* tiles, int32_t* n_tiles) {
+    __shared__ int cnt;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < B; b0 += kScanThreads) {                      // ascending query order within a sweep is not needed: tiles are independent
+        const int b = b0 + threadIdx.x;
+        if (b < B && flags[b]) tiles[atomicAdd(&cnt, 1)] = make_int2(b, 1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) n_tiles[0] = cnt;
+}
+
+}  // namespace vs

@@ -1,0 +1,496 @@
+// bp_walk.h -- "blocked postings": a second, column-grouped copy of a CSR index for SPARSE queries, and the walk over it.
+//
+// The CSR scan (csr_scan_mq.h) looks every index non-zero up in the tile table although only ~2.6 % x Qt of them carry a
+// query weight.  Here the rows are cut into blocks of R documents (R <= 2048, picked at build time); inside a block the
+// non-zeros are grouped by column into posting lists, and a query tile walks ONLY the lists of its own columns: every visited
+// non-zero is a hit.  The products go to accumulators [document][query slot] in LDS; after each block a thread finishes its
+// documents (sums -> order keys -> candidate buffers), like the per-row epilogue of the CSR pass.
+//
+// Layout ("records", all 16-byte aligned): a list is a run of RECORDS of 8 postings -- 8 uint16 document-in-block ids (16 B)
+// followed by their 8 values (fp32: 32 B, fp16: 16 B, binary index: none) -- the last record zero-padded (document 0, value 0:
+// adds nothing).  dir[b][c] = first record of column c in block b (record units, relative to the block), base[b] = first
+// record of block b.  A lane takes whole records (one 16-byte load of ids + one/two of values, no per-posting bounds), a group
+// of LG lanes takes consecutive records of one list, so a list of n postings is ~6 n contiguous bytes: with 128-byte cache
+// lines that is what decides how many of the fetched bytes are used (rocprofv3, 21 M docs: the round-1 layout -- ids and values
+// in separate arrays, 832-document blocks, 22-posting lists -- moved 6.7 TB through L2->L1 for 2.8 TB of postings and held the
+// walk at the ~64 outstanding lines a CU can keep in flight).
+//
+// Accumulator modes:
+//   AM_F64: fp32 product, fp64 sum (ds_add_f64) -- the library's exact numerics, same as the CSR pass.
+//   AM_FIX: fp32 product of the PRE-SCALED weight (w * 2^e, e per query so that no sum can reach 2^31), truncated to int32 and
+//           summed with ds_add_u32 -- 3.4x the ds_add_f64 rate on MI355X (tools/microbench/lds_scatter.hip: 5.0 vs 1.5 Tadd/s) and
+//           half the LDS, hence twice the documents per block.  Integer sums are order-independent, and every truncation loses
+//           less than one unit, so  |S * exact - A| < n  (n = matched terms) bounds the exact fp64 sum by the approximate one.
+//           The walk then FILTERS: it returns the K' > k best documents by approximate score; refine_topk_kernel (bp_refine.h)
+//           re-scores exactly those with the exact numerics and proves, per query, that no other document can reach the top k;
+//           queries it cannot prove are re-run on the AM_F64 walk.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <type_traits>
+
+#include "csr_scan.h"
+#include "dense_csr.h"
+
+namespace vs {
+
+enum : int { AM_F64 = 0, AM_FIX = 1 };
+
+constexpr int kBpRowsMax = 2048;      // most documents per block (the epilogue takes them 1024 = one per thread at a time)
+constexpr int kBpCap = 2048;          // candidate slots per (workgroup, query slot): K' kept + 1024 new per epilogue round
+constexpr int kBpMaxK = kBpCap - kScanThreads;
+constexpr int kBpEntCap = 7168;       // (query, column) entries per tile: 56 KB of LDS, and the 8192-slot entry sort must hold them
+constexpr int kBpNB = 4;              // posting lists whose loads are in flight together per lane group
+constexpr size_t kBpSortBytes = (size_t)8192 * 8;   // the entry sort of a tile (8192 slots) borrows the accumulator area
+
+__host__ __device__ constexpr int bp_rec_bytes(int vm) { return vm == VM_F32 ? 48 : (vm == VM_F16 ? 32 : 16); }
+
+// ---- builder ------------------------------------------------------------------------------------------------------
+// pass 1: one workgroup per block: postings per column -> records per column -> directory (record offsets) + block total;
+//         also the per-column totals over all blocks (records and non-zeros: what a query entry on that column walks)
+template <int UNUSED>
+__global__ __launch_bounds__(kScanThreads) void bp_count_kernel(const uint32_t* pk_ptr, const uint4* cols, int64_t n_rows, int32_t n_cols, int32_t rows,
+                                                                uint32_t* dir, uint32_t* block_recs, unsigned long long* df_rec,
+                                                                unsigned long long* df_nnz) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(smem);                  // [n_cols + 1]
+    __shared__ int scratch[32];
+    const int tid = threadIdx.x;
+    const int64_t n_blocks = (n_rows + rows - 1) / rows;
+    const int seg = (n_cols + 1 + kScanThreads - 1) / kScanThreads;
+    for (int64_t b = blockIdx.x; b < n_blocks; b += gridDim.x) {
+        const int64_t r0 = b * rows, r1 = min(n_rows, r0 + rows);
+        const uint32_t P0 = pk_ptr[r0], P1 = pk_ptr[r1];
+        __syncthreads();
+        for (int i = tid; i <= n_cols; i += kScanThreads) cnt[i] = 0;
+        __syncthreads();
+        for (uint32_t p = P0 + tid; p < P1; p += kScanThreads) {
+            const uint4 cw = cols[p];
+            const uint32_t cwv[4] = {cw.x, cw.y, cw.z, cw.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                atomicAdd(&cnt[cwv[i] & 0xFFFFu], 1u);                  // row padding lands in cnt[n_cols], dropped below
+                atomicAdd(&cnt[cwv[i] >> 16], 1u);
+            }
+        }
+        __syncthreads();
+        if (tid == 0) cnt[n_cols] = 0;
+        __syncthreads();
+        const int i0 = tid * seg, i1 = min(n_cols + 1, i0 + seg);
+        int mine = 0;
+        for (int i = i0; i < i1; ++i) mine += ((int)cnt[i] + 7) >> 3;
+        int tot = 0;
+        int off = block_excl_scan(mine, scratch, tid, &tot);
+        uint32_t* d = dir + (size_t)b * (n_cols + 1);
+        for (int i = i0; i < i1; ++i) {
+            const uint32_t c = cnt[i], r = (c + 7) >> 3;
+            d[i] = (uint32_t)off;
+            off += (int)r;
+            if (i < n_cols && c) {
+                atomicAdd(&df_rec[i], (unsigned long long)r);
+                atomicAdd(&df_nnz[i], (unsigned long long)c);
+            }
+        }
+        if (tid == 0) block_recs[b] = (uint32_t)tot;
+    }
+}
+
+// pass 2: exclusive scan of the block totals -> base[b] (records), base[n_blocks] = all records.  One workgroup.
+template <int UNUSED>
+__global__ __launch_bounds__(kScanThreads) void bp_base_kernel(const uint32_t* block_recs, int64_t n_blocks, unsigned long long* base) {
+    __shared__ unsigned long long part[kScanThreads];
+    const int tid = threadIdx.x;
+    const int64_t per = (n_blocks + kScanThreads - 1) / kScanThreads;
+    const int64_t i0 = min(n_blocks, (int64_t)tid * per), i1 = min(n_blocks, i0 + per);
+    unsigned long long s = 0;
+    for (int64_t i = i0; i < i1; ++i) s += block_recs[i];
+    part[tid] = s;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long run = 0;
+        for (int i = 0; i < kScanThreads; ++i) { const unsigned long long v = part[i]; part[i] = run; run += v; }
+        base[n_blocks] = run;
+    }
+    __syncthreads();
+    unsigned long long run = part[tid];
+    for (int64_t i = i0; i < i1; ++i) { base[i] = run; run += block_recs[i]; }
+}
+
+// pass 3: scatter the non-zeros into their records (the array is zero-filled first: pad postings are document 0, value 0)
+template <int VM>
+__global__ __launch_bounds__(kScanThreads) void bp_fill_kernel(const uint32_t* pk_ptr, const uint4* cols, const void* vals, int64_t n_rows,
+                                                               int32_t n_cols, int32_t rows, const uint32_t* dir, const unsigned long long* base,
+                                                               char* rec) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint32_t* cur = reinterpret_cast<uint32_t*>(smem);                  // [n_cols + 1] write cursors in postings
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    constexpr int RS = bp_rec_bytes(VM);
+    const int64_t n_blocks = (n_rows + rows - 1) / rows;
+    for (int64_t b = blockIdx.x; b < n_blocks; b += gridDim.x) {
+        const int64_t r0 = b * rows, r1 = min(n_rows, r0 + rows);
+        const uint32_t* d = dir + (size_t)b * (n_cols + 1);
+        __syncthreads();
+        for (int i = tid; i <= n_cols; i += kScanThreads) cur[i] = d[i] * 8u;
+        __syncthreads();
+        char* brec = rec + (size_t)base[b] * RS;
+        for (int64_t r = r0 + w; r < r1; r += kScanWaves) {
+            const uint32_t p0 = pk_ptr[r], p1 = pk_ptr[r + 1];
+            const uint16_t dl = (uint16_t)(r - r0);
+            for (uint32_t p = p0 + lane; p < p1; p += 64) {
+                const uint4 cw = cols[p];
+                const uint32_t cwv[4] = {cw.x, cw.y, cw.z, cw.w};
+                float v[8];
+                if constexpr (VM == VM_F32) {
+                    const float4* vp = reinterpret_cast<const float4*>(vals);
+                    const float4 v0 = vp[2 * (size_t)p], v1 = vp[2 * (size_t)p + 1];
+                    v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
+                } else if constexpr (VM == VM_F16) {
+                    const uint4 hv = reinterpret_cast<const uint4*>(vals)[p];
+                    const __half2* h = reinterpret_cast<const __half2*>(&hv);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { const float2 f = __half22float2(h[i]); v[2 * i] = f.x; v[2 * i + 1] = f.y; }
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const uint32_t c = (i & 1) ? (cwv[i >> 1] >> 16) : (cwv[i >> 1] & 0xFFFFu);
+                    if (c < (uint32_t)n_cols) {
+                        const uint32_t pos = atomicAdd(&cur[c], 1u);
+                        char* rp = brec + (size_t)(pos >> 3) * RS;
+                        reinterpret_cast<uint16_t*>(rp)[pos & 7u] = dl;
+                        if constexpr (VM == VM_F32) reinterpret_cast<float*>(rp + 16)[pos & 7u] = v[i];
+                        if constexpr (VM == VM_F16) reinterpret_cast<__half*>(rp + 16)[pos & 7u] = __float2half(v[i]);
+                    }
+                }
+            }
+        }
+        if constexpr (VM == VM_BIN) {
+            // a binary posting has no value to zero: the pad postings of a list's last record point at the scratch row behind
+            // the accumulators (document id kBpRowsMax), whatever they add is never read
+            __syncthreads();
+            for (int i = tid; i < n_cols; i += kScanThreads) {
+                const uint32_t lim = d[i + 1] * 8u;
+                for (uint32_t pos = cur[i]; pos < lim; ++pos) reinterpret_cast<uint16_t*>(brec + (size_t)(pos >> 3) * RS)[pos & 7u] = (uint16_t)kBpRowsMax;
+            }
+        }
+    }
+}
+
+// out[0] = records, out[1] = non-zeros this batch's walk visits: sum over columns of (queries of the batch using the column) x df
+template <int UNUSED>
+__global__ __launch_bounds__(kScanThreads) void bp_walk_kernel(const uint32_t* colfreq, const unsigned long long* df_rec, const unsigned long long* df_nnz,
+                                                               int32_t n_cols, int64_t* out) {
+    __shared__ unsigned long long red[2][kScanThreads / 64];
+    unsigned long long v = 0, z = 0;
+    for (int c = threadIdx.x; c < n_cols; c += kScanThreads) { v += (unsigned long long)colfreq[c] * df_rec[c]; z += (unsigned long long)colfreq[c] * df_nnz[c]; }
+    for (int o = 32; o > 0; o >>= 1) { v += __shfl_xor(v, o, 64); z += __shfl_xor(z, o, 64); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = v; red[1][threadIdx.x >> 6] = z; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0, u = 0;
+        for (int i = 0; i < kScanThreads / 64; ++i) { t += red[0][i]; u += red[1][i]; }
+        out[0] = (int64_t)t;
+        out[1] = (int64_t)u;
+    }
+}
+
+// ---- walk ---------------------------------------------------------------------------------------------------------
+struct BpArgs {
+    int32_t rows;             // documents per block (<= kBpRowsMax)
+    const uint32_t* dir;      // [n_blocks, n_cols + 1] record offsets inside the block
+    const unsigned long long* base;   // [n_blocks + 1] first record of a block
+    const char* rec;          // records
+    int64_t n_rows;
+    int32_t n_cols;
+    int32_t k;
+    int32_t nchunk;
+    int64_t blocks_per_chunk;
+    const int64_t* qptr;      // sparse queries (CSR over the batch) and the tile plan -- as MqArgs
+    const int32_t* qcols;
+    const float* qvals;
+    const int2* tiles;
+    int32_t n_tiles;
+    const int32_t* n_tiles_dev; // optional: the tile count lives on the device (fallback plan built by a kernel); overrides n_tiles
+    int32_t ent_cap;          // LDS capacity for tile entries
+    uint64_t* cand;           // [B, nchunk, k] output keys, sorted descending
+    uint64_t* gcand;          // [grid, QT, kBpCap] scratch
+    const uint64_t* upper;    // optional [B] exclusive upper bounds ("search after")
+    const float* qscale;      // AM_FIX: [B] per-query power-of-two scale of the fixed-point sums
+};
+
+// accumulators [kBpRowsMax + 1][QT + 1]: the extra row absorbs the pad postings of a binary list (document id kBpRowsMax)
+template <int QT, int AM>
+__host__ __device__ constexpr size_t bp_acc_bytes() { return (((size_t)(kBpRowsMax + 1) * (QT + 1) * (AM == AM_F64 ? 8 : 4)) + 15) & ~(size_t)15; }
+template <int QT, int AM>
+__host__ __device__ inline size_t bp_lds_bytes(int ent_cap) {
+    return bp_acc_bytes<QT, AM>() + (size_t)kBpCap * 8 + (size_t)QT * 16 + 64 * 4 + (size_t)ent_cap * 8;
+}
+
+__device__ __forceinline__ uint64_t make_key_fix(int32_t a, uint32_t row) {
+    return ((uint64_t)((uint32_t)a ^ 0x80000000u) << 32) | (uint32_t)(~row);
+}
+__device__ __forceinline__ int32_t key_fix(uint64_t k) { return (int32_t)((uint32_t)(k >> 32) ^ 0x80000000u); }
+
+// LDS byte offset of accumulator [document][slot]: document (one half of a packed id word) * pitch + slot offset, ONE instruction
+__device__ __forceinline__ uint32_t acc_off_lo(uint32_t idw, uint32_t pitch, uint32_t so) {
+    uint32_t r;
+    asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(r) : "v"(idw), "v"(pitch), "v"(so));
+    return r;
+}
+__device__ __forceinline__ uint32_t acc_off_hi(uint32_t idw, uint32_t pitch, uint32_t so) {
+    uint32_t r;
+    asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(r) : "v"(idw), "v"(pitch), "v"(so));
+    return r;
+}
+
+// A record's loads as ONE asm statement each (global_load, block base in SGPRs + 32-bit byte offset); wait_loads<N> lets all but
+// the N youngest loads land and ties the loaded registers to the wait, so that no use can be scheduled above it.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void load_rec48(u32x4& a, u32x4& b, u32x4& c, uint32_t off, unsigned long long base) {
+    asm volatile("global_load_dwordx4 %0, %3, %4\n\tglobal_load_dwordx4 %1, %3, %4 offset:16\n\tglobal_load_dwordx4 %2, %3, %4 offset:32"
+                 : "=&v"(a), "=&v"(b), "=&v"(c) : "v"(off), "s"(base));
+}
+__device__ __forceinline__ void load_rec32(u32x4& a, u32x4& b, uint32_t off, unsigned long long base) {
+    asm volatile("global_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:16" : "=&v"(a), "=&v"(b) : "v"(off), "s"(base));
+}
+__device__ __forceinline__ void load_rec16(u32x4& a, uint32_t off, unsigned long long base) {
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(a) : "v"(off), "s"(base));
+}
+#define VS_WAIT_CASE(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(a), "+v"(b), "+v"(c)); break;
+__device__ __forceinline__ void wait_loads(int n, u32x4& a, u32x4& b, u32x4& c) {       // n is a constant after unrolling
+    switch (n) {
+        VS_WAIT_CASE(1) VS_WAIT_CASE(2) VS_WAIT_CASE(3) VS_WAIT_CASE(4) VS_WAIT_CASE(6) VS_WAIT_CASE(9)
+        default: asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c)); break;
+    }
+}
+#undef VS_WAIT_CASE
+// accumulate into LDS at a byte address (ds_add_u32 / ds_add_f64, no return)
+__device__ __forceinline__ void lds_add(uint32_t addr, int32_t v) {
+    __hip_atomic_fetch_add(reinterpret_cast<__attribute__((address_space(3))) int32_t*>(addr), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_add(uint32_t addr, double v) {
+    __hip_atomic_fetch_add(reinterpret_cast<__attribute__((address_space(3))) double*>(addr), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// LG = lanes per posting list (4 for the long lists of a valued index, 1 for the short lists of the bag-of-token index)
+template <int VM, int QT, int AM, int LG>
+__global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
+    static_assert(bp_acc_bytes<QT, AM>() >= kBpSortBytes, "the accumulator area holds the 8192-slot entry sort");
+    static_assert(kBpNB % LG == 0, "a lane owns NB / LG directory pairs of a slot");
+    using acc_t = typename std::conditional<AM == AM_F64, double, int32_t>::type;
+    constexpr int PITCH = QT + 1;                 // accumulator row pitch in elements: a document's row starts an odd number of words
+                                                  // after its neighbour's, so the adds of a wave spread over all LDS banks
+    constexpr uint32_t PITCHB = PITCH * sizeof(acc_t);
+    constexpr int RS = bp_rec_bytes(VM);
+    constexpr int NB = kBpNB;
+    constexpr int OWN = NB / LG;                  // directory pairs a lane owns per slot
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    acc_t* acc = reinterpret_cast<acc_t*>(smem);                                            // [kBpRowsMax][PITCH]
+    uint64_t* sortbuf = reinterpret_cast<uint64_t*>(smem + bp_acc_bytes<QT, AM>());         // [kBpCap]
+    unsigned long long* tau = reinterpret_cast<unsigned long long*>(sortbuf + kBpCap);      // [QT]
+    unsigned long long* upper_sh = tau + QT;                                                // [QT] exclusive upper bounds ("search after")
+    int* scratch = reinterpret_cast<int*>(upper_sh + QT);                                   // [48]
+    unsigned int* ccnt = reinterpret_cast<unsigned int*>(scratch + 48);                     // [QT]
+    uint2* ent = reinterpret_cast<uint2*>(scratch + 64);                                    // [ent_cap]: x = column | slot byte offset << 16, y = weight bits
+
+    const int tid = threadIdx.x;
+    const int gid = tid / LG, gl = tid % LG;
+    constexpr int NG = kScanThreads / LG;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;     // LDS address of the accumulators
+    const int K = a.k;
+    uint64_t* my_gcand = a.gcand + (size_t)blockIdx.x * QT * kBpCap;
+    const int64_t n_blocks = (a.n_rows + a.rows - 1) / a.rows;
+    const int64_t items = (int64_t)(a.n_tiles_dev ? a.n_tiles_dev[0] : a.n_tiles) * a.nchunk;
+    const size_t dir_ld = (size_t)a.n_cols + 1;
+
+    // Work items = (tile, chunk), taken round-robin (the host picks nchunk so that an XCD keeps to few chunks, see the launch)
+    for (int64_t item = blockIdx.x; item < items; item += gridDim.x) {
+        const int tile = (int)(item / a.nchunk), c = (int)(item % a.nchunk);
+        const int q0 = a.tiles[tile].x, nq = a.tiles[tile].y;
+        const int64_t b0 = (int64_t)c * a.blocks_per_chunk, b1 = min(n_blocks, b0 + a.blocks_per_chunk);
+        __syncthreads();
+        const int64_t e0 = a.qptr[q0], e1 = a.qptr[q0 + nq];
+        const int n_ent = (int)(e1 - e0);
+        // Entries sorted by column (the accumulator area doubles as the sort buffer): neighbouring groups then read neighbouring
+        // directory words and neighbouring posting lists -- the walk over the block's records is a forward sweep with gaps.
+        {
+            uint64_t* skey = reinterpret_cast<uint64_t*>(acc);
+            for (int i = tid; i < 8192; i += kScanThreads) {
+                uint64_t key = 0;
+                if (i < n_ent) {
+                    const int64_t e = e0 + i;
+                    int qs = 0;
+                    while (e >= a.qptr[q0 + qs + 1]) ++qs;
+                    float w = a.qvals[e];
+                    if constexpr (AM == AM_FIX) w *= a.qscale[q0 + qs];          // power of two: exact
+                    key = ((uint64_t)(uint32_t)a.qcols[e] << 40) | ((uint64_t)qs << 32) | (uint64_t)__float_as_uint(w);
+                }
+                skey[i] = key;
+            }
+            wg_sort_desc<kScanThreads>(skey, 8192, tid);
+            for (int i = tid; i < n_ent; i += kScanThreads) {
+                const uint64_t key = skey[i];
+                ent[i] = make_uint2((uint32_t)(key >> 40) | ((uint32_t)((key >> 32) & 0xFFu) * (uint32_t)sizeof(acc_t) << 16), (uint32_t)key);
+            }
+            __syncthreads();
+        }
+        for (int i = tid; i < kBpRowsMax * PITCH; i += kScanThreads) acc[i] = (acc_t)0;
+        if (tid < QT) { tau[tid] = 0ull; ccnt[tid] = 0u; }
+        if (tid < QT) upper_sh[tid] = (a.upper && tid < nq) ? a.upper[q0 + tid] : ~0ull;
+        __syncthreads();
+
+        for (int64_t b = b0; b < b1 || b == b0; ++b) {
+            const bool have = b < b1;
+            const int rows_b = have ? (int)min((int64_t)a.rows, a.n_rows - b * a.rows) : 0;
+            if (have) {
+                const uint32_t* dirb = a.dir + (size_t)b * dir_ld;
+                // block-uniform base pointer in SGPRs + 32-bit record offsets per lane
+                // block-uniform base pointer in SGPRs + 32-bit byte offsets per lane
+                const unsigned long long pb = (unsigned long long)(a.rec + (size_t)a.base[b] * RS);
+                const unsigned long long brec = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(pb >> 32)) << 32) |
+                                                (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)pb);   // (the builtin returns int)
+                // A slot = the group's next NB entries; lane l owns the directory pairs (first, end) of entries l, l + LG, ... of the
+                // slot and fetches the next slot's pairs while the current one is walked.  A lane takes one record (8 postings) of a
+                // list per round; the NB lists of a slot are loaded before any multiply-add.  Loads are unconditional (a lane past
+                // its list's end re-reads the record at the end: always inside the array) so that no loaded register is merged with
+                // an older value; only the adds are predicated.
+                uint32_t nlo[OWN], nhi[OWN];
+#pragma unroll
+                for (int o = 0; o < OWN; ++o) {
+                    const int e = gid + NG * (gl + LG * o);
+                    nlo[o] = 0; nhi[o] = 0;
+                    if (e < n_ent) {
+                        const uint32_t cc = ent[e].x & 0xFFFFu;
+                        nlo[o] = dirb[cc];
+                        nhi[o] = dirb[cc + 1];
+                    }
+                }
+                for (int j = 0; gid + NG * (NB * j) < n_ent; ++j) {
+                    uint32_t clo[OWN], chi[OWN];
+#pragma unroll
+                    for (int o = 0; o < OWN; ++o) {
+                        clo[o] = nlo[o]; chi[o] = nhi[o];
+                        nlo[o] = 0; nhi[o] = 0;
+                        const int e = gid + NG * (gl + LG * o + NB * (j + 1));
+                        if (e < n_ent) {
+                            const uint32_t cc = ent[e].x & 0xFFFFu;
+                            nlo[o] = dirb[cc];
+                            nhi[o] = dirb[cc + 1];
+                        }
+                    }
+                    uint32_t rec[NB], end[NB];
+                    uint2 en[NB];
+                    bool more = false;
+#pragma unroll
+                    for (int u = 0; u < NB; ++u) {                  // list u of the slot: its pair sits in lane u % LG, register u / LG
+                        const uint32_t lo = LG == 1 ? clo[u] : (uint32_t)__shfl((int)clo[u / LG], u % LG, LG);
+                        const uint32_t hi = LG == 1 ? chi[u] : (uint32_t)__shfl((int)chi[u / LG], u % LG, LG);
+                        rec[u] = lo + gl; end[u] = hi;
+                        more = more || (rec[u] < end[u]);
+                        en[u] = ent[min(gid + NG * (u + NB * j), n_ent - 1)];       // (column | slot offset << 16, weight): LDS broadcast per group
+                    }
+                    while (__builtin_amdgcn_ballot_w64(more)) {
+                        // 12 loads per lane (fp32 records) are issued back to back -- hand-written: the compiler sinks plain loads into
+                        // the predicated blocks below and then waits for each list separately -- and each list waits only for its own.
+                        u32x4 ids[NB], va[NB], vb[NB];
+#pragma unroll
+                        for (int u = 0; u < NB; ++u) {
+                            const uint32_t off = __umul24(min(rec[u], end[u]), (uint32_t)RS);
+                            if constexpr (VM == VM_F32) load_rec48(ids[u], va[u], vb[u], off, brec);
+                            else if constexpr (VM == VM_F16) load_rec32(ids[u], va[u], off, brec);
+                            else load_rec16(ids[u], off, brec);
+                        }
+                        more = false;
+#pragma unroll
+                        for (int u = 0; u < NB; ++u) {
+                            if constexpr (VM == VM_F32) wait_loads((NB - 1 - u) * 3, ids[u], va[u], vb[u]);
+                            else if constexpr (VM == VM_F16) wait_loads((NB - 1 - u) * 2, ids[u], va[u], va[u]);
+                            else wait_loads(NB - 1 - u, ids[u], ids[u], ids[u]);
+                            if (rec[u] < end[u]) {
+                                const float wq = __uint_as_float(en[u].y);
+                                const uint32_t so = (en[u].x >> 16) + lds0;         // LDS byte address of [document 0][slot]
+                                const uint32_t dw[4] = {ids[u].x, ids[u].y, ids[u].z, ids[u].w};
+                                float vv[8];
+                                if constexpr (VM == VM_F32) {
+                                    vv[0] = __uint_as_float(va[u].x); vv[1] = __uint_as_float(va[u].y); vv[2] = __uint_as_float(va[u].z);
+                                    vv[3] = __uint_as_float(va[u].w); vv[4] = __uint_as_float(vb[u].x); vv[5] = __uint_as_float(vb[u].y);
+                                    vv[6] = __uint_as_float(vb[u].z); vv[7] = __uint_as_float(vb[u].w);
+                                } else if constexpr (VM == VM_F16) {
+                                    const uint32_t hw[4] = {va[u].x, va[u].y, va[u].z, va[u].w};
+#pragma unroll
+                                    for (int t = 0; t < 4; ++t) {
+                                        const float2 f = __half22float2(*reinterpret_cast<const __half2*>(&hw[t]));
+                                        vv[2 * t] = f.x; vv[2 * t + 1] = f.y;
+                                    }
+                                }
+                                [[maybe_unused]] int32_t wi = 0;
+                                [[maybe_unused]] double wd = 0.0;
+                                if constexpr (VM == VM_BIN && AM == AM_FIX) wi = (int32_t)wq;
+                                if constexpr (VM == VM_BIN && AM == AM_F64) wd = (double)wq;
+#pragma unroll
+                                for (int t = 0; t < 8; ++t) {
+                                    const uint32_t off = (t & 1) ? acc_off_hi(dw[t >> 1], PITCHB, so) : acc_off_lo(dw[t >> 1], PITCHB, so);
+                                    if constexpr (VM == VM_BIN) {
+                                        // (pad postings of a binary list carry document id kBpRowsMax: the scratch row behind the accumulators)
+                                        if constexpr (AM == AM_FIX) lds_add(off, wi);
+                                        else lds_add(off, wd);
+                                    } else {
+                                        const float prod = wq * vv[t];
+                                        if constexpr (AM == AM_FIX) lds_add(off, (int32_t)prod);
+                                        else lds_add(off, (double)prod);
+                                    }
+                                }
+                            }
+                            rec[u] += LG;
+                            more = more || (rec[u] < end[u]);
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            // epilogue: 1024 documents at a time, one per thread: its QT sums -> order keys -> candidates; prune when a buffer could overflow
+            for (int d0 = 0; d0 < rows_b || d0 == 0; d0 += kScanThreads) {
+                const int d = d0 + tid;
+                if (d < rows_b) {
+                    const int64_t row = b * a.rows + d;
+                    acc_t* pa = acc + (size_t)d * PITCH;
+#pragma unroll 1
+                    for (int q = 0; q < nq; ++q) {                        // (slots >= nq are never written: a ragged tile skips them;
+                        const acc_t sum = pa[q];                          //  not unrolled: hoisted candidate-buffer addresses spill into the walk)
+                        pa[q] = (acc_t)0;
+                        uint64_t key;
+                        if constexpr (AM == AM_F64) key = make_key((float)sum, (uint32_t)row);
+                        else key = make_key_fix(sum, (uint32_t)row);
+                        if (key > tau[q] && key < upper_sh[q]) {
+                            const uint32_t pos = atomicAdd(&ccnt[q], 1u);
+                            my_gcand[(size_t)q * kBpCap + pos] = key;
+                        }
+                    }
+                }
+                __syncthreads();
+                const bool last = b + 1 >= b1 && d0 + kScanThreads >= rows_b;
+                for (int qs = 0; qs < nq; ++qs) {
+                    const uint32_t cnt = ccnt[qs];
+                    if (last || cnt > (uint32_t)(kBpCap - kScanThreads)) {
+                        for (int i = tid; i < kBpCap; i += kScanThreads) sortbuf[i] = (uint32_t)i < cnt ? my_gcand[(size_t)qs * kBpCap + i] : 0ull;
+                        wg_sort_desc<kScanThreads>(sortbuf, kBpCap, tid);
+                        if (last) {
+                            uint64_t* out = a.cand + ((size_t)(q0 + qs) * a.nchunk + c) * (size_t)K;
+                            for (int i = tid; i < K; i += kScanThreads) out[i] = sortbuf[i];
+                        } else if (cnt > (uint32_t)K) {
+                            for (int i = tid; i < K; i += kScanThreads) my_gcand[(size_t)qs * kBpCap + i] = sortbuf[i];
+                            if (tid == 0) {
+                                tau[qs] = sortbuf[K - 1];
+                                ccnt[qs] = (uint32_t)K;
+                            }
+                        }
+                        __syncthreads();
+                    }
+                }
+            }
+            if (b + 1 >= b1) break;
+        }
+    }
+}
+
+}  // namespace vs

@@ -164,6 +164,20 @@ struct ProfScope {
     ~ProfScope() { Profiler::get().end(s); }
 };
 
+// VS_DEBUG_SYNC=1: synchronise and report after each stage (finding the kernel behind a device fault)
+inline bool debug_sync_on() {
+    static const bool on = getenv("VS_DEBUG_SYNC") != nullptr;
+    return on;
+}
+#define VS_STAGE(name, stream)                                                                        \
+    do {                                                                                              \
+        if (vs::debug_sync_on()) {                                                                    \
+            hipError_t e__ = hipStreamSynchronize(stream);                                            \
+            fprintf(stderr, "[vsearch_hip] stage %s: %s\n", name, hipGetErrorString(e__));            \
+            fflush(stderr);                                                                           \
+        }                                                                                             \
+    } while (0)
+
 inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 inline uint32_t pow2_ceil(uint32_t x) {
@@ -189,23 +203,29 @@ struct vs_index {
     vs::DevBuf pk_ptr;   // uint32 [n_rows + 1]
     vs::DevBuf cols;     // uint16 [n_packets * 8]
     vs::DevBuf vals;     // fp32 / fp16 [n_packets * 8] (absent for binary)
-    // blocked postings (bp_scan.h): column-grouped copy for sparse queries, built on first use when HBM allows
-    vs::DevBuf bp_dir;   // uint32 [n_blocks, n_cols + 1]
-    vs::DevBuf bp_doc;   // uint16 [n_packets * 8]
-    vs::DevBuf bp_val;   // fp32 / fp16 [n_packets * 8]
-    vs::DevBuf bp_df;    // uint32 [n_cols]: postings per column over all blocks (incl. pad postings) -- what a query entry streams
-    int bp_rows = 1024;  // documents per block of the copy (picked at build time)
+    // blocked postings (bp_walk.h): column-grouped copy for sparse queries, built on first use when HBM allows
+    vs::DevBuf bp_dir;   // uint32 [n_blocks, n_cols + 1]: first record of a column inside its block
+    vs::DevBuf bp_base;  // uint64 [n_blocks + 1]: first record of a block
+    vs::DevBuf bp_rec;   // records: 8 x uint16 document-in-block + 8 values (fp32 | fp16 | none)
+    vs::DevBuf bp_df;    // uint64 [2][n_cols]: records / non-zeros per column over all blocks -- what a query entry walks
+    int64_t bp_records = 0;
+    vs::DevBuf bp_vmax;  // float bits: max |value| of the index (bounds the fixed-point walk's products)
+    int bp_filter = 1;   // option "postings_filter": 1 = int32 fixed-point walk + exact refine (default), 0 = fp64 walk only
+    int64_t last_walk_postings = 0;      // postings (multiply-adds) the most recent search's walk visited
+    const uint32_t* last_flags = nullptr; // device [last_flags_n]: queries of the most recent filter search that took the exact walk
+    int last_flags_n = 0;
+    int bp_rows = 2048;  // documents per block of the copy (picked at build time)
     bool bp_ready = false, bp_tried = false;
     int64_t last_scan_bytes = 0;   // bytes the scan kernels of the most recent search had to read (algorithmic, per path)
     int last_path = 0;             // 0 = one query per pass, 1 = 8-query CSR scan, 2 = blocked postings
     int bp_pref = -1;    // option "blocked_postings": -1 auto, 0 never, 1 always
-    int bp_rows_pref = 0;// option "postings_rows": 0 = auto, else documents per block (multiple of 64, 256..1024); applies at the next build
+    int bp_rows_pref = 0;// option "postings_rows": 0 = auto, else documents per block (multiple of 64, 256..2048); applies at the next build
     int bp_chunks = 0;   // option "postings_chunks": 0 = auto, else block runs per tile on the postings path
     int mq_variant = -1; // option "mq_variant": -1 auto (from the batch's query overlap), 0 plain, 1 shared columns
     // dense
     vs::DevBuf mat;      // [n_rows, n_cols] store_dtype
     // scratch owned by the handle (grow-only)
-    vs::DevBuf ws_q, ws_cand, ws_out_ids, ws_out_scores, ws_misc, ws_mq_meta, ws_mq_q, ws_mq_cand;
+    vs::DevBuf ws_q, ws_cand, ws_out_ids, ws_out_scores, ws_misc, ws_mq_meta, ws_mq_q, ws_mq_cand, ws_fb;
     bool logical_dense = false;   // dense Index stored as CSR packets (sparsity-aware dense index)
     int qt_pref = 0;     // 0 = auto (multi-query pass when the batch qualifies), 1 = force the dense-image pass
     int last_qt = 0;     // queries per pass of the most recent search

@@ -3,7 +3,8 @@
 #include "common.h"
 #include "csr_scan.h"
 #include "csr_scan_mq.h"
-#include "bp_scan.h"
+#include "bp_walk.h"
+#include "bp_refine.h"
 #include "synth_device.h"
 
 #include <algorithm>
@@ -460,7 +461,15 @@ extern "C" int vs_index_info(const vs_index* idx, vs_index_info_t* o) {
     o->n_packets = idx->n_packets;
     o->last_scan_bytes = idx->last_scan_bytes;
     o->last_path = idx->last_path;
-    o->aux_bytes = idx->bp_ready ? (int64_t)(idx->bp_dir.bytes + idx->bp_doc.bytes + idx->bp_val.bytes) : 0;
+    o->last_walk_postings = idx->last_walk_postings;
+    if (idx->last_path == 3 && idx->last_flags && idx->last_flags_n > 0) {
+        std::vector<uint32_t> h((size_t)idx->last_flags_n);
+        VS_HIP(hipSetDevice(idx->device));
+        VS_HIP(hipDeviceSynchronize());
+        VS_HIP(hipMemcpy(h.data(), idx->last_flags, h.size() * 4, hipMemcpyDeviceToHost));
+        for (uint32_t f : h) o->last_fallbacks += f ? 1 : 0;
+    }
+    o->aux_bytes = idx->bp_ready ? (int64_t)(idx->bp_dir.bytes + idx->bp_base.bytes + idx->bp_rec.bytes) : 0;
     if (idx->kind == VS_KIND_CSR) {
         o->bytes_per_pass = csr_bytes_per_pass(idx);
         o->device_bytes = (int64_t)(idx->pk_ptr.bytes + idx->cols.bytes + idx->vals.bytes);
@@ -695,56 +704,119 @@ int mq_vals_cap(const vs_index* idx) {
     return (int)((total - fixed) / 4);
 }
 
-// ---- blocked postings (bp_scan.h): second, column-grouped copy of a long-row valued index ------------------------
+// ---- blocked postings (bp_walk.h): second, column-grouped copy of the index for sparse queries ---------------------
+constexpr int kBpExactQT = 4;     // queries per tile of the fp64 walk (its accumulators are twice as wide as the filter walk's)
+
 bool bp_wanted(const vs_index* idx) {
-    if (idx->bp_pref == 0 || idx->store_dtype == VS_NONE || idx->n_rows <= 0 || idx->n_packets <= 0) return false;
+    if (idx->bp_pref == 0 || idx->n_rows <= 0 || idx->n_packets <= 0) return false;
     if (((size_t)idx->n_cols + 1) * 4 + 4096 > 160 * 1024) return false;            // the builder keeps one counter per column in LDS
     if (idx->bp_pref == 1) return true;
-    // pays off when rows are long (the directory costs 4 (V + 1) bytes per 1024 documents) and the index is big enough
+    // pays off when the index is big enough for the per-block directory (4 (V + 1) bytes per block) to disappear
+    if (idx->store_dtype == VS_NONE) return idx->n_rows >= 65536;
     return idx->n_rows >= 16384 && (double)idx->nnz / (double)idx->n_rows >= 256.0;
+}
+
+void bp_release(vs_index* idx) {
+    idx->bp_dir.release(); idx->bp_base.release(); idx->bp_rec.release(); idx->bp_df.release(); idx->bp_vmax.release();
+    idx->bp_ready = false;
+}
+
+template <int QT, int AM>
+int launch_bp_walk(const vs_index* idx, const BpArgs& a, int grid, int ent_cap, hipStream_t s) {
+    const size_t lds = bp_lds_bytes<QT, AM>(ent_cap);
+    if (lds > 160 * 1024) return fail(VS_EUNSUPPORTED, "postings walk needs %zu B of LDS", lds);
+    void (*kern)(BpArgs) = idx->store_dtype == VS_F32 ? bp_walk_topk<VM_F32, QT, AM, 4>
+                         : idx->store_dtype == VS_F16 ? bp_walk_topk<VM_F16, QT, AM, 4> : bp_walk_topk<VM_BIN, QT, AM, 1>;
+    VS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kScanThreads), lds, s, a);
+    VS_HIP(hipGetLastError());
+    return VS_OK;
 }
 
 int bp_build(vs_index* idx, hipStream_t s) {
     idx->bp_tried = true;
-    idx->bp_ready = false;
-    // documents per block: a column's list in a block should average ~22 postings (rows x nnz-per-row / columns)
-    {
-        const double per_row = (double)idx->nnz / (double)idx->n_rows / (double)idx->n_cols;      // P(a document has a given column)
-        int rows = (int)(22.0 / std::max(per_row, 1e-9));                                       // (measured flat optimum: 20-24)
-        rows = std::max(256, std::min(kBpRows, rows / 64 * 64));
-        idx->bp_rows = idx->bp_rows_pref > 0 ? idx->bp_rows_pref : rows;
-    }
+    bp_release(idx);
+    // documents per block: as many as the filter walk's accumulators hold -- the longer a column's list in a block, the more of
+    // every 128-byte line the walk fetches is used (768-nnz documents, V = 29 523: 53 postings = 6.7 records per list)
+    idx->bp_rows = idx->bp_rows_pref > 0 ? idx->bp_rows_pref : kBpRowsMax;
     const int64_t n_blocks = ceil_div64(idx->n_rows, idx->bp_rows);
-    const size_t cap = bp_postings_capacity(idx->n_packets, n_blocks, idx->n_cols);
-    const size_t b_dir = (size_t)n_blocks * ((size_t)idx->n_cols + 1) * 4, b_doc = cap * 2, b_val = cap * (idx->store_dtype == VS_F32 ? 4 : 2);
+    const int V = idx->n_cols;
+    const int RS = bp_rec_bytes(idx->store_dtype == VS_F32 ? VM_F32 : idx->store_dtype == VS_F16 ? VM_F16 : VM_BIN);
+    const size_t b_dir = (size_t)n_blocks * ((size_t)V + 1) * 4;
     size_t free_b = 0, total_b = 0;
     VS_HIP(hipMemGetInfo(&free_b, &total_b));
     const size_t margin = idx->bp_pref == 1 ? ((size_t)256 << 20) : ((size_t)4 << 30);  // leave room for scratch / other tensors
-    if (free_b < b_dir + b_doc + b_val + margin) return VS_OK;                          // no room: the CSR scan serves every query
-    if (idx->bp_dir.alloc(b_dir) != VS_OK || idx->bp_doc.alloc(b_doc) != VS_OK || idx->bp_val.alloc(b_val) != VS_OK) {
-        idx->bp_dir.release(); idx->bp_doc.release(); idx->bp_val.release();
+    auto no_room = [&](size_t need) {
+        fprintf(stderr, "[vsearch_hip] blocked-postings copy not built: needs %.1f GB, %.1f GB of HBM free -- sparse queries use the CSR scan (3x slower)\n",
+                (double)need / 1e9, (double)free_b / 1e9);
+        bp_release(idx);
         (void)hipGetLastError();
         return VS_OK;
-    }
-    VS_HIP(hipMemsetAsync(idx->bp_doc.p, 0, b_doc, s));          // pad postings: document 0, value 0
-    VS_HIP(hipMemsetAsync(idx->bp_val.p, 0, b_val, s));
-    const size_t lds = ((size_t)idx->n_cols + 1) * 4;
+    };
+    // lower bound of the records: one per 8 non-zeros
+    if (free_b < b_dir + (size_t)idx->n_packets * RS + margin) return no_room(b_dir + (size_t)idx->n_packets * RS);
+    DevBuf block_recs;
+    if (idx->bp_dir.alloc(b_dir) != VS_OK || idx->bp_base.alloc((size_t)(n_blocks + 1) * 8) != VS_OK || idx->bp_df.alloc((size_t)V * 16) != VS_OK ||
+        block_recs.alloc((size_t)n_blocks * 4) != VS_OK)
+        return no_room(b_dir);
+    VS_HIP(hipMemsetAsync(idx->bp_df.p, 0, (size_t)V * 16, s));
+    unsigned long long* df_rec = idx->bp_df.as<unsigned long long>();
+    unsigned long long* df_nnz = df_rec + V;
+    const size_t lds = ((size_t)V + 1) * 4;
     const int grid = (int)std::min<int64_t>(n_blocks, (int64_t)idx->cu_count * 8);
     ProfScope prof("bp_build", s);
+    VS_HIP(hipFuncSetAttribute((const void*)bp_count_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(bp_count_kernel<0>, dim3(grid), dim3(kScanThreads), lds, s, idx->pk_ptr.as<uint32_t>(), idx->cols.as<uint4>(), idx->n_rows, V, idx->bp_rows,
+                       idx->bp_dir.as<uint32_t>(), block_recs.as<uint32_t>(), df_rec, df_nnz);
+    VS_STAGE("bp_count", s);
+    hipLaunchKernelGGL(bp_base_kernel<0>, dim3(1), dim3(kScanThreads), 0, s, block_recs.as<uint32_t>(), n_blocks, idx->bp_base.as<unsigned long long>());
+    VS_HIP(hipGetLastError());
+    VS_STAGE("bp_base", s);
+    unsigned long long n_rec = 0;
+    VS_HIP(hipMemcpyAsync(&n_rec, idx->bp_base.as<unsigned long long>() + n_blocks, 8, hipMemcpyDeviceToHost, s));
+    VS_HIP(hipStreamSynchronize(s));
+    const size_t b_rec = ((size_t)n_rec + 1) * RS;                       // + one record: a lane past the last list's end re-reads "the record at the end"
+    VS_HIP(hipMemGetInfo(&free_b, &total_b));
+    if (free_b < b_rec + margin || idx->bp_rec.alloc(b_rec) != VS_OK) return no_room(b_rec);
+    idx->bp_records = (int64_t)n_rec;
+    VS_HIP(hipMemsetAsync(idx->bp_rec.p, 0, b_rec, s));                  // pad postings: document 0, value 0
     if (idx->store_dtype == VS_F32) {
-        VS_HIP(hipFuncSetAttribute((const void*)bp_build_kernel<VM_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((bp_build_kernel<VM_F32>), dim3(grid), dim3(kScanThreads), lds, s, idx->pk_ptr.as<uint32_t>(), idx->cols.as<uint4>(),
-                           (const void*)idx->vals.p, idx->n_rows, idx->n_cols, idx->bp_rows, idx->bp_dir.as<uint32_t>(), idx->bp_doc.as<uint16_t>(), idx->bp_val.p);
+        VS_HIP(hipFuncSetAttribute((const void*)bp_fill_kernel<VM_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(bp_fill_kernel<VM_F32>, dim3(grid), dim3(kScanThreads), lds, s, idx->pk_ptr.as<uint32_t>(), idx->cols.as<uint4>(), (const void*)idx->vals.p,
+                           idx->n_rows, V, idx->bp_rows, idx->bp_dir.as<uint32_t>(), idx->bp_base.as<unsigned long long>(), idx->bp_rec.as<char>());
+    } else if (idx->store_dtype == VS_F16) {
+        VS_HIP(hipFuncSetAttribute((const void*)bp_fill_kernel<VM_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(bp_fill_kernel<VM_F16>, dim3(grid), dim3(kScanThreads), lds, s, idx->pk_ptr.as<uint32_t>(), idx->cols.as<uint4>(), (const void*)idx->vals.p,
+                           idx->n_rows, V, idx->bp_rows, idx->bp_dir.as<uint32_t>(), idx->bp_base.as<unsigned long long>(), idx->bp_rec.as<char>());
     } else {
-        VS_HIP(hipFuncSetAttribute((const void*)bp_build_kernel<VM_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((bp_build_kernel<VM_F16>), dim3(grid), dim3(kScanThreads), lds, s, idx->pk_ptr.as<uint32_t>(), idx->cols.as<uint4>(),
-                           (const void*)idx->vals.p, idx->n_rows, idx->n_cols, idx->bp_rows, idx->bp_dir.as<uint32_t>(), idx->bp_doc.as<uint16_t>(), idx->bp_val.p);
+        VS_HIP(hipFuncSetAttribute((const void*)bp_fill_kernel<VM_BIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(bp_fill_kernel<VM_BIN>, dim3(grid), dim3(kScanThreads), lds, s, idx->pk_ptr.as<uint32_t>(), idx->cols.as<uint4>(), (const void*)nullptr,
+                           idx->n_rows, V, idx->bp_rows, idx->bp_dir.as<uint32_t>(), idx->bp_base.as<unsigned long long>(), idx->bp_rec.as<char>());
     }
     VS_HIP(hipGetLastError());
-    if (idx->bp_df.alloc((size_t)idx->n_cols * 4) == VS_OK) {
-        hipLaunchKernelGGL(bp_df_kernel<0>, dim3((unsigned)ceil_div(idx->n_cols, 256)), dim3(256), 0, s, idx->bp_dir.as<uint32_t>(), n_blocks, idx->n_cols,
-                           idx->bp_df.as<uint32_t>());
+    VS_STAGE("bp_fill", s);
+    // max |value|: bounds the products of the fixed-point walk (bp_refine.h); a binary index has none (every value is 1)
+    if (idx->store_dtype != VS_NONE && idx->bp_vmax.alloc(4) == VS_OK) {
+        VS_HIP(hipMemsetAsync(idx->bp_vmax.p, 0, 4, s));
+        const int64_t nv = idx->n_packets * 8;
+        const unsigned g = (unsigned)std::min<int64_t>(ceil_div64(nv, 256 * 16), (int64_t)idx->cu_count * 16);
+        if (idx->store_dtype == VS_F32) hipLaunchKernelGGL(bp_vmax_kernel<VM_F32>, dim3(g), dim3(256), 0, s, (const void*)idx->vals.p, nv, idx->bp_vmax.as<uint32_t>());
+        else hipLaunchKernelGGL(bp_vmax_kernel<VM_F16>, dim3(g), dim3(256), 0, s, (const void*)idx->vals.p, nv, idx->bp_vmax.as<uint32_t>());
         VS_HIP(hipGetLastError());
+    }
+    VS_HIP(hipStreamSynchronize(s));                                     // `block_recs` is freed on return
+    VS_STAGE("bp_vmax", s);
+    if (debug_sync_on()) {
+        std::vector<unsigned long long> hb((size_t)n_blocks + 1);
+        std::vector<uint32_t> hd((size_t)V + 1);
+        (void)hipMemcpy(hb.data(), idx->bp_base.p, hb.size() * 8, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(hd.data(), idx->bp_dir.as<uint32_t>() + (size_t)(n_blocks - 1) * (V + 1), hd.size() * 4, hipMemcpyDeviceToHost);
+        bool mono = true;
+        for (size_t i = 0; i + 1 < hb.size(); ++i) mono = mono && hb[i] <= hb[i + 1];
+        bool dmono = true;
+        for (size_t i = 0; i + 1 < hd.size(); ++i) dmono = dmono && hd[i] <= hd[i + 1];
+        fprintf(stderr, "[vsearch_hip] bp: rows %d blocks %lld records %llu base[1] %llu base[last] %llu monotone %d; last block dir end %u (block holds %llu) monotone %d\n",
+                idx->bp_rows, (long long)n_blocks, n_rec, hb.size() > 1 ? hb[1] : 0ull, hb[n_blocks], (int)mono, hd[V], hb[n_blocks] - hb[n_blocks - 1], (int)dmono);
     }
     idx->bp_ready = true;
     return VS_OK;
@@ -758,7 +830,14 @@ int mq_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64_t id_o
               const ScanPlan& plan, hipStream_t s, bool* done, int32_t out_ld, int32_t col0, uint64_t* upper) {
     *done = false;
     const bool use_bp = idx->bp_ready;
-    const int vals_cap = use_bp ? std::min(mq_vals_cap(idx), kBpEntCap) : mq_vals_cap(idx);     // entries (non-zeros) one tile may hold
+    // Filter and refine (bp_refine.h): the walk runs on int32 fixed-point sums and returns K' > k documents per query, the refine
+    // kernel re-scores them exactly and proves the top k; unproven queries go through the fp64 walk.  Without it (option
+    // "postings_filter" = 0, "search after" passes, k beyond the candidate buffers) every tile takes the fp64 walk.
+    const int kp = k + std::max(28, k / 4);
+    const bool filter = use_bp && idx->bp_filter != 0 && col0 == 0 && !upper && kp <= kBpMaxK && (idx->store_dtype == VS_NONE || idx->bp_vmax.p);
+    const int qt_plan = use_bp && !filter ? kBpExactQT : kQT;
+    const int bp_cap = filter ? kBpEntCap : kBpEntCap / 2;
+    const int vals_cap = use_bp ? std::min(mq_vals_cap(idx), bp_cap) : mq_vals_cap(idx);     // entries (non-zeros) one tile may hold
     if (vals_cap <= 0 || k > (use_bp ? kBpMaxK : kMaxKMq)) return VS_OK;     // (callers split larger k into passes)
     const int V = idx->n_cols;
     // 1. sparsify the batch: counts -> (qptr, tiles, plan) -> (qcols, qvals)
@@ -774,10 +853,12 @@ int mq_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64_t id_o
     VS_HIP(hipMemsetAsync(colfreq, 0, (size_t)(V + 4) * 4 + 8, s));          // counts + the 64-bit overlap sum behind them
     hipLaunchKernelGGL(count_nz_kernel<0>, dim3(std::min(B, 2048)), dim3(kSpThreads), 0, s, dq, (int64_t)V, B, V, counts);
     hipLaunchKernelGGL(mq_colfreq_kernel<0>, dim3(std::min(B, 2048)), dim3(kSpThreads), 0, s, dq, (int64_t)V, B, V, colfreq);
-    hipLaunchKernelGGL(mq_plan_kernel<0>, dim3(1), dim3(64), 0, s, counts, B, kQT, vals_cap, qptr, tiles, dplan, colfreq, V);
+    hipLaunchKernelGGL(mq_plan_kernel<0>, dim3(1), dim3(64), 0, s, counts, B, qt_plan, vals_cap, qptr, tiles, dplan, colfreq, V);
     VS_HIP(hipGetLastError());
-    if (use_bp && idx->bp_df.p) hipLaunchKernelGGL(bp_walk_kernel<0>, dim3(1), dim3(kScanThreads), 0, s, colfreq, idx->bp_df.as<uint32_t>(), V, dplan + 4);
-    int64_t hplan[5] = {0, 0, 0, 0, 0};
+    if (use_bp && idx->bp_df.p)
+        hipLaunchKernelGGL(bp_walk_kernel<0>, dim3(1), dim3(kScanThreads), 0, s, colfreq, idx->bp_df.as<unsigned long long>(),
+                           idx->bp_df.as<unsigned long long>() + V, V, dplan + 4);
+    int64_t hplan[6] = {0, 0, 0, 0, 0, 0};
     VS_HIP(hipMemcpyAsync(hplan, dplan, sizeof(hplan), hipMemcpyDeviceToHost, s));
     VS_HIP(hipStreamSynchronize(s));
     if (hplan[1] > vals_cap) return VS_OK;                       // some query is too dense for the tile tables
@@ -788,18 +869,18 @@ int mq_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64_t id_o
     float* qvals = reinterpret_cast<float*>(qcols + qnnz);
     hipLaunchKernelGGL(fill_csr_kernel<0>, dim3(std::min(B, 2048)), dim3(kSpThreads), 0, s, dq, (int64_t)V, B, V, qptr, qcols, qvals, qnnz);
     VS_HIP(hipGetLastError());
+    VS_STAGE("sparsify", s);
+    if (debug_sync_on()) fprintf(stderr, "[vsearch_hip] plan: tiles %d qnnz %lld max %lld filter %d cap %d\n", n_tiles, (long long)qnnz, (long long)hplan[1], (int)filter, vals_cap);
     // 2. scan.  Work items = (tile, row chunk)
     int nchunk = choose_chunks(idx, n_tiles, plan.nchunk);
     if (use_bp) {
-        // blocked postings: chunks are runs of 1024-document blocks
+        // blocked postings: chunks are runs of blocks
         const int64_t n_blocks = ceil_div64(idx->n_rows, idx->bp_rows);
         nchunk = (int)std::min<int64_t>(nchunk, n_blocks);
         // Big index: 16 chunks (or 12 / 24 when that fills the CUs better).  Workgroup b runs on XCD b % 8 and takes items
         // b, b + grid, ...; what matters is how many chunks the 32 CUs behind one L2 work on at a time: tiles share directory
         // and posting lines, so few chunks per XCD is good -- but exactly one (8 chunks) makes 32 workgroups hammer the same
-        // lines and is as slow as no affinity at all.  Measured, 1024 queries: 21 M docs 505 ms (12) / 508 (16) / 607 (8) /
-        // 592 (2) / 625 (20), 0.99 s with items drawn from a global counter; 10.5 M docs 255 (12) / 301 (8); 2.6 M 67 / 73.
-        // (12 and 16 tie on time; 16 leaves 40 % less HBM traffic: 1.09 vs 1.81 TB per 1024 queries at 21 M docs)
+        // lines and is as slow as no affinity at all.
         if (idx->n_rows >= (2 << 20) && (int64_t)n_tiles * 12 >= idx->cu_count) {
             int best = 16;
             double best_eff = 0.0;
@@ -815,14 +896,15 @@ int mq_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64_t id_o
         const int64_t blocks_per_chunk = ceil_div64(n_blocks, nchunk);
         const int64_t items = (int64_t)n_tiles * nchunk;
         const int grid = (int)std::min<int64_t>(items, idx->cu_count);
-        VS_TRY(idx->ws_mq_cand.reserve((size_t)grid * kQT * kBpCap * 8));
-        VS_TRY(idx->ws_cand.reserve((size_t)B * nchunk * k * 8));
+        const int nchunk_fb = (int)std::min<int64_t>(n_blocks, 64);
+        VS_TRY(idx->ws_mq_cand.reserve((size_t)idx->cu_count * kQT * kBpCap * 8));
+        VS_TRY(idx->ws_cand.reserve(std::max((size_t)B * nchunk * (filter ? kp : k), filter ? (size_t)B * nchunk_fb * k : (size_t)0) * 8));
+        const int RS = bp_rec_bytes(idx->store_dtype == VS_F32 ? VM_F32 : idx->store_dtype == VS_F16 ? VM_F16 : VM_BIN);
         BpArgs a{};
-        a.pk_ptr = idx->pk_ptr.as<uint32_t>();
         a.rows = idx->bp_rows;
         a.dir = idx->bp_dir.as<uint32_t>();
-        a.pdoc = idx->bp_doc.as<uint16_t>();
-        a.pval = idx->bp_val.p;
+        a.base = idx->bp_base.as<unsigned long long>();
+        a.rec = idx->bp_rec.as<char>();
         a.n_rows = idx->n_rows;
         a.n_cols = V;
         a.k = k;
@@ -837,19 +919,94 @@ int mq_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64_t id_o
         a.cand = idx->ws_cand.as<uint64_t>();
         a.gcand = idx->ws_mq_cand.as<uint64_t>();
         a.upper = col0 > 0 ? upper : nullptr;
-        const size_t lds = bp_lds_bytes<kQT>(vals_cap);
-        // what this launch has to read: the posting lists of the batch's (query, column) entries + one directory pair per entry and block
-        idx->last_scan_bytes += hplan[4] * (2 + (idx->store_dtype == VS_F32 ? 4 : 2)) + qnnz * n_blocks * 8;
+        if (debug_sync_on()) fprintf(stderr, "[vsearch_hip] walk: blocks %lld nchunk %d bpc %lld grid %d kp %d\n", (long long)n_blocks, nchunk, (long long)blocks_per_chunk, grid, kp);
+        // what this launch has to read: the records of the batch's (query, column) entries + one directory pair per entry and block
+        idx->last_scan_bytes += hplan[4] * RS + qnnz * n_blocks * 8;
+        idx->last_walk_postings += hplan[5];
+        if (filter) {
+            VS_TRY(idx->ws_fb.reserve((size_t)B * sizeof(int2) + (size_t)B * 12 + 64));
+            int2* fb_tiles = idx->ws_fb.as<int2>();
+            float* qscale = reinterpret_cast<float*>(fb_tiles + B);
+            int32_t* qslack = reinterpret_cast<int32_t*>(qscale + B);
+            uint32_t* flags = reinterpret_cast<uint32_t*>(qslack + B);
+            int32_t* fb_n = reinterpret_cast<int32_t*>(flags + B);
+            hipLaunchKernelGGL(bp_qscale_kernel<0>, dim3((unsigned)ceil_div(B, 4)), dim3(256), 0, s, qptr, qvals, B, idx->bp_vmax.as<uint32_t>(),
+                               idx->store_dtype == VS_NONE ? 1 : 0, qscale, qslack);
+            VS_HIP(hipGetLastError());
+            a.k = kp;
+            a.qscale = qscale;
+            idx->last_path = 3;
+            {
+                ProfScope prof("csr_scan_topk", s);
+                VS_TRY((launch_bp_walk<kQT, AM_FIX>(idx, a, grid, vals_cap, s)));
+            }
+            VS_STAGE("filter walk", s);
+            RefineArgs r{};
+            r.cand = a.cand;
+            r.n_cand = (int64_t)nchunk * kp;
+            r.run_len = kp;
+            r.B = B; r.k = k; r.kp = kp;
+            r.pk_ptr = idx->pk_ptr.as<uint32_t>();
+            r.cols = idx->cols.as<uint4>();
+            r.vals = idx->vals.p;
+            r.n_cols = V;
+            r.n_rows = idx->n_rows;
+            r.q = dq;
+            r.qscale = qscale;
+            r.qslack = qslack;
+            r.id_offset = id_offset;
+            r.out_ids = d_ids;
+            r.out_scores = d_scores;
+            r.out_ld = out_ld;
+            r.flags = flags;
+            {
+                ProfScope prof("refine_topk", s);
+                const int rgrid = std::min(B, idx->cu_count * 2);
+                if (idx->store_dtype == VS_F32) hipLaunchKernelGGL(refine_topk_kernel<VM_F32>, dim3(rgrid), dim3(kScanThreads), 0, s, r);
+                else if (idx->store_dtype == VS_F16) hipLaunchKernelGGL(refine_topk_kernel<VM_F16>, dim3(rgrid), dim3(kScanThreads), 0, s, r);
+                else hipLaunchKernelGGL(refine_topk_kernel<VM_BIN>, dim3(rgrid), dim3(kScanThreads), 0, s, r);
+                VS_HIP(hipGetLastError());
+            }
+            VS_STAGE("refine", s);
+            // unproven queries (normally none): one-query tiles, planned on the device, through the exact walk + merge
+            hipLaunchKernelGGL(fb_plan_kernel<0>, dim3(1), dim3(kScanThreads), 0, s, flags, B, fb_tiles, fb_n);
+            VS_HIP(hipGetLastError());
+            a.k = k;
+            a.qscale = nullptr;
+            a.tiles = fb_tiles;
+            a.n_tiles_dev = fb_n;
+            a.nchunk = nchunk_fb;
+            a.blocks_per_chunk = ceil_div64(n_blocks, nchunk_fb);
+            a.ent_cap = std::min(vals_cap, kBpEntCap / 2);
+            {
+                ProfScope prof("exact_fallback", s);
+                VS_TRY((launch_bp_walk<kBpExactQT, AM_F64>(idx, a, idx->cu_count, a.ent_cap, s)));
+                MergeArgs m{};
+                m.cand = a.cand;
+                m.n_cand = (int64_t)nchunk_fb * k;
+                m.B = B;
+                m.k = k;
+                m.id_offset = id_offset;
+                m.out_ids = d_ids;
+                m.out_scores = d_scores;
+                m.out_ld = out_ld;
+                m.col0 = 0;
+                m.run_len = k;
+                m.sel = fb_tiles;
+                m.sel_n = fb_n;
+                hipLaunchKernelGGL(merge_topk_kernel<0>, dim3(std::min(B, idx->cu_count)), dim3(kScanThreads), 0, s, m);
+                VS_HIP(hipGetLastError());
+            }
+            VS_STAGE("fallback", s);
+            idx->last_flags = flags;
+            idx->last_flags_n = B;
+            *done = true;
+            return VS_OK;
+        }
         idx->last_path = 2;
         ProfScope prof("csr_scan_topk", s);
-        if (idx->store_dtype == VS_F32) {
-            VS_HIP(hipFuncSetAttribute((const void*)bp_scan_topk<VM_F32, kQT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL((bp_scan_topk<VM_F32, kQT>), dim3(grid), dim3(kScanThreads), lds, s, a);
-        } else {
-            VS_HIP(hipFuncSetAttribute((const void*)bp_scan_topk<VM_F16, kQT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL((bp_scan_topk<VM_F16, kQT>), dim3(grid), dim3(kScanThreads), lds, s, a);
-        }
-        VS_HIP(hipGetLastError());
+        VS_TRY((launch_bp_walk<kBpExactQT, AM_F64>(idx, a, grid, vals_cap, s)));
+        VS_STAGE("fp64 walk", s);
     } else {
     const int64_t rows_per_chunk = ceil_div64(idx->n_rows, nchunk);
     const int64_t items = (int64_t)n_tiles * nchunk;
@@ -932,6 +1089,9 @@ int vs_csr_search(vs_index* idx, const void* q, int q_dtype, int64_t ldq, int32_
     }
     idx->last_qt = 1;
     idx->last_scan_bytes = 0;
+    idx->last_walk_postings = 0;
+    idx->last_flags = nullptr;
+    idx->last_flags_n = 0;
     idx->last_path = 0;
     if (idx->qt_pref != 1) {
         if (!idx->bp_ready && !idx->bp_tried && bp_wanted(idx)) VS_TRY(bp_build(idx, s));

@@ -306,7 +306,67 @@ struct MergeArgs {
     uint64_t* upper_out;      // optional [B]: receives the k-th key (next pass's exclusive upper bound)
     const uint64_t* upper_in; // optional [B]: only keys < upper_in[b] take part (passes after the first when k > 2048)
     int32_t run_len;          // > 0: the list is a sequence of descending-sorted runs of this length (per-chunk top-k lists)
+    const int2* sel;          // optional device list of queries (x = query) with its length in sel_n[0]: merge only those
+    const int32_t* sel_n;
 };
+
+// Leaves the K largest of src[0, n_cand) (0 = empty slot) in buf[0, K), sorted descending; buf holds kWgCap keys.
+__device__ __forceinline__ void merge_select(const uint64_t* src, int64_t n_cand, int run_len, int K, const uint64_t* upper_in, uint64_t* buf,
+                                             int* cnt_sh, int tid) {
+    int64_t consumed = 0;
+    int have = 0;                                        // buf[0..have) = best so far
+    __syncthreads();
+    // Sorted runs (many row chunks, small batch): the first p = ceil(K / runs) keys of every run hold >= K keys, so
+    // their K-th largest is a lower bound of the answer's K-th key; typically only a few hundred candidates pass
+    // it, and ONE small sort replaces n_cand / 4096 full-buffer rounds.
+    bool done = false;
+    if (run_len > 0 && !upper_in && n_cand > kWgCap && n_cand % run_len == 0) {
+        const int runs = (int)(n_cand / run_len);
+        const int p = min(run_len, (K + runs - 1) / runs);
+        const int heads = runs * p;
+        if (heads >= K && heads <= kWgCap) {
+            int n2 = 64;
+            while (n2 < heads) n2 <<= 1;
+            for (int i = tid; i < n2; i += kScanThreads) buf[i] = i < heads ? src[(size_t)(i / p) * run_len + (i % p)] : 0ull;
+            wg_sort_desc<kScanThreads>(buf, n2, tid);
+            const uint64_t bound = buf[K - 1];
+            __syncthreads();
+            if (tid == 0) *cnt_sh = 0;
+            __syncthreads();
+            for (int64_t i = tid; i < n_cand; i += kScanThreads) {
+                const uint64_t key = src[i];
+                if (key >= bound && key != 0ull) {
+                    const int pos = atomicAdd(cnt_sh, 1);
+                    if (pos < kWgCap) buf[pos] = key;
+                }
+            }
+            __syncthreads();
+            const int cnt = *cnt_sh;
+            if (cnt <= kWgCap) {
+                int n3 = 64;
+                while (n3 < cnt) n3 <<= 1;
+                n3 = max(n3, 64);
+                while (n3 < K) n3 <<= 1;
+                for (int i = cnt + tid; i < n3; i += kScanThreads) buf[i] = 0ull;
+                wg_sort_desc<kScanThreads>(buf, n3, tid);
+                done = true;
+            }
+            __syncthreads();
+        }
+    }
+    if (!done) do {
+        const int room = kWgCap - have;
+        const int64_t take = min((int64_t)room, n_cand - consumed);
+        for (int i = tid; i < room; i += kScanThreads) {
+            uint64_t key = i < take ? src[consumed + i] : 0ull;
+            if (upper_in && key >= upper_in[0]) key = 0ull;
+            buf[have + i] = key;
+        }
+        consumed += take;
+        wg_sort_desc<kScanThreads>(buf, kWgCap, tid);
+        have = K;
+    } while (consumed < n_cand);
+}
 
 template <int UNUSED>
 __global__ __launch_bounds__(kScanThreads) void merge_topk_kernel(MergeArgs a) {
@@ -314,61 +374,10 @@ __global__ __launch_bounds__(kScanThreads) void merge_topk_kernel(MergeArgs a) {
     __shared__ int cnt_sh;
     const int tid = threadIdx.x;
     const int K = a.k;                                       // K <= kMaxKShared
-    for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
-        const uint64_t* src = a.cand + (size_t)b * a.n_cand;
-        int64_t consumed = 0;
-        int have = 0;                                        // buf[0..have) = best so far
-        __syncthreads();
-        // Sorted runs (many row chunks, small batch): the first p = ceil(K / runs) keys of every run hold >= K keys, so
-        // their K-th largest is a lower bound of the answer's K-th key; typically only a few hundred candidates pass
-        // it, and ONE small sort replaces n_cand / 4096 full-buffer rounds.
-        bool done = false;
-        if (a.run_len > 0 && !a.upper_in && a.n_cand > kWgCap && a.n_cand % a.run_len == 0) {
-            const int runs = (int)(a.n_cand / a.run_len);
-            const int p = min(a.run_len, (K + runs - 1) / runs);
-            const int heads = runs * p;
-            if (heads >= K && heads <= kWgCap) {
-                int n2 = 64;
-                while (n2 < heads) n2 <<= 1;
-                for (int i = tid; i < n2; i += kScanThreads) buf[i] = i < heads ? src[(size_t)(i / p) * a.run_len + (i % p)] : 0ull;
-                wg_sort_desc<kScanThreads>(buf, n2, tid);
-                const uint64_t bound = buf[K - 1];
-                __syncthreads();
-                if (tid == 0) cnt_sh = 0;
-                __syncthreads();
-                for (int64_t i = tid; i < a.n_cand; i += kScanThreads) {
-                    const uint64_t key = src[i];
-                    if (key >= bound && key != 0ull) {
-                        const int pos = atomicAdd(&cnt_sh, 1);
-                        if (pos < kWgCap) buf[pos] = key;
-                    }
-                }
-                __syncthreads();
-                const int cnt = cnt_sh;
-                if (cnt <= kWgCap) {
-                    int n3 = 64;
-                    while (n3 < cnt) n3 <<= 1;
-                    n3 = max(n3, 64);
-                    while (n3 < K) n3 <<= 1;
-                    for (int i = cnt + tid; i < n3; i += kScanThreads) buf[i] = 0ull;
-                    wg_sort_desc<kScanThreads>(buf, n3, tid);
-                    done = true;
-                }
-                __syncthreads();
-            }
-        }
-        if (!done) do {
-            const int room = kWgCap - have;
-            const int64_t take = min((int64_t)room, a.n_cand - consumed);
-            for (int i = tid; i < room; i += kScanThreads) {
-                uint64_t key = i < take ? src[consumed + i] : 0ull;
-                if (a.upper_in && key >= a.upper_in[b]) key = 0ull;
-                buf[have + i] = key;
-            }
-            consumed += take;
-            wg_sort_desc<kScanThreads>(buf, kWgCap, tid);
-            have = K;
-        } while (consumed < a.n_cand);
+    const int n_q = a.sel_n ? a.sel_n[0] : a.B;              // optional query list (device): only those queries are merged
+    for (int bi = blockIdx.x; bi < n_q; bi += gridDim.x) {
+        const int b = a.sel ? a.sel[bi].x : bi;
+        merge_select(a.cand + (size_t)b * a.n_cand, a.n_cand, a.run_len, K, a.upper_in ? a.upper_in + b : nullptr, buf, &cnt_sh, tid);
         for (int i = tid; i < K; i += kScanThreads) {
             const uint64_t key = buf[i];
             a.out_ids[(size_t)b * a.out_ld + a.col0 + i] = (int64_t)key_row(key) + a.id_offset;
