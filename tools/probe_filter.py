@@ -12,12 +12,18 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 k = int(sys.argv[3]) if len(sys.argv) > 3 else 100
 store = nat.VS_F16 if len(sys.argv) > 4 and sys.argv[4] == "fp16" else nat.VS_F32
 modes = sys.argv[5].split(",") if len(sys.argv) > 5 else ["filter", "f64", "csr"]
+chunk_list = [int(x) for x in sys.argv[6].split(",")] if len(sys.argv) > 6 else [0]
+lanes = int(sys.argv[7]) if len(sys.argv) > 7 else 8
 idx = DeviceIndex.synthetic(0, 0, N, 29523, 768, 0, 0, store)
 q = torch.from_numpy(oracle.synth_queries(1, B)).cuda()
 res = {}
-for mode in modes:
+idx.set_option("postings_lanes", lanes)
+for mode, chunks in [(m, c) for m in modes for c in (chunk_list if m != "csr" else [0])]:
+    idx.set_option("postings_chunks", chunks)
     idx.set_option("blocked_postings", 0 if mode == "csr" else 1)
-    idx.set_option("postings_filter", 1 if mode == "filter" else 0)
+    idx.set_option("postings_filter", 1 if mode in ("filter", "filterx", "fallback", "fallbackx") else 0)
+    idx.set_option("postings_quant", 0 if mode in ("filterx", "fallbackx") else -1)        # x = exact (fp32) records
+    idx.set_option("postings_force_fallback", 1 if mode.startswith("fallback") else 0)
     torch.cuda.synchronize(); t = time.time()
     idx.search(q, k)
     torch.cuda.synchronize(); first = time.time() - t
@@ -30,10 +36,10 @@ for mode in modes:
     ms, n = Profile.read("csr_scan_topk"); rms, _ = Profile.read("refine_topk"); fms, _ = Profile.read("exact_fallback"); Profile.enable(False)
     res[mode] = (ids.cpu().numpy(), sc.cpu().numpy())
     inf = idx.info()
-    print(f"{mode:7s} path={inf.last_path} first {first*1e3:.1f} ms, steady {dt*1e3:.2f} ms = {B/dt:.0f} q/s | walk {ms/reps:.2f} ms refine {rms/reps:.3f} ms "
+    print(f"{mode:7s} chunks={chunks} path={inf.last_path} first {first*1e3:.1f} ms, steady {dt*1e3:.2f} ms = {B/dt:.0f} q/s | walk {ms/reps:.2f} ms refine {rms/reps:.3f} ms "
           f"fallback {fms/reps:.3f} ms ({inf.last_fallbacks} queries) | {inf.last_walk_postings/(ms/reps)/1e6:.0f} Gadd/s", flush=True)
 ref = modes[-1]
 for mode in modes[:-1]:
     same_ids = (res[mode][0] == res[ref][0]).mean(); same_sc = (res[mode][1] == res[ref][1]).mean()
     print(f"{mode} vs {ref}: ids equal {same_ids:.6f}  scores bit-equal {same_sc:.6f}")
-    assert same_ids == 1.0 and same_sc == 1.0
+    if not (same_ids == 1.0 and same_sc == 1.0): print("MISMATCH", mode, np.abs(res[mode][1]-res[ref][1]).max())

@@ -92,7 +92,23 @@ extern "C" int vs_index_set_option(vs_index* idx, const char* name, int value) {
     }
     if (n == "postings_filter") {
         if (value < 0 || value > 1) return fail(VS_EINVAL, "postings_filter: 1 = fixed-point walk + exact refine, 0 = fp64 walk only");
+        if (value != idx->bp_filter) { idx->bp_dir.release(); idx->bp_base.release(); idx->bp_rec.release(); idx->bp_ready = false; idx->bp_tried = false; }
         idx->bp_filter = value;
+        return VS_OK;
+    }
+    if (n == "postings_force_fallback") {          // tests: the refine step flags every query, so the exact pass decides all results
+        idx->bp_force_fb = value != 0;
+        return VS_OK;
+    }
+    if (n == "postings_quant") {
+        if (value < -1 || value > 1) return fail(VS_EINVAL, "postings_quant: -1 = auto, 0 = off, 1 = on (when the data allow it)");
+        idx->bp_quant_pref = value;
+        idx->bp_dir.release(); idx->bp_base.release(); idx->bp_rec.release(); idx->bp_ready = false; idx->bp_tried = false;
+        return VS_OK;
+    }
+    if (n == "postings_lanes") {
+        if (value != 4 && value != 8) return fail(VS_EINVAL, "postings_lanes: 4 | 8");
+        idx->bp_lanes = value;
         return VS_OK;
     }
     if (n == "mq_variant") {

@@ -5,7 +5,12 @@
 // pass and the fp64 walk compute), the exact top k is written out, and the kernel PROVES per query that no document
 // outside the K' can belong to it:  a document the walk did not return has an approximate sum A <= A_cut (the K'-th best),
 // hence an exact sum below (A_cut + n) / S, n = the query's non-zeros (one unit of truncation per matched term).  If the
-// exact k-th score is above that bound the query is done; otherwise its flag is set and the exact walk re-runs it.
+// exact k-th score is above that bound the query is done; otherwise its flag is set and an exact pass re-runs it.
+//
+// Lossy records: for an fp32 index the filter's copy stores the values ROUNDED TO fp16 (4 instead of 6 bytes per posting -- the
+// walk is bound by the bytes a CU can pull through its L1, rocprofv3: ~23 B/clk/CU).  The rounding error is relative
+// (<= 2^-11 per value, + 2^-25 absolute for fp16 subnormals), so it widens the bound by a factor, not by a constant; it
+// needs non-negative values and weights (VDR embeddings are, vdr.py:73-75 elu1p >= 0), else the copy keeps fp32 values.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
@@ -15,34 +20,40 @@
 
 namespace vs {
 
-// max |value| of a valued index (one float, device) -- bounds every product of the walk
+// out[0] = max |value| of a valued index (float bits; bounds every product of the walk), out[1] = 1 if any value is negative
 template <int VM>
 __global__ __launch_bounds__(256) void bp_vmax_kernel(const void* vals, int64_t n, uint32_t* out_bits) {
     float m = 0.f;
+    bool neg = false;
     const int64_t stride = (int64_t)gridDim.x * 256;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
         float v;
         if constexpr (VM == VM_F32) v = reinterpret_cast<const float*>(vals)[i];
         else v = __half2float(reinterpret_cast<const __half*>(vals)[i]);
         m = fmaxf(m, fabsf(v));
+        neg = neg || v < 0.f;
     }
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     if ((threadIdx.x & 63) == 0) atomicMax(out_bits, __float_as_uint(m));       // non-negative floats order like their bits
+    if (__builtin_amdgcn_ballot_w64(neg) && (threadIdx.x & 63) == 0) atomicOr(out_bits + 1, 1u);
 }
 
-// Per query: S = 2^e with (sum |w|) * vmax * S < 2^30 (no int32 sum can wrap), and the slack n = non-zeros + 1 in fixed-point
-// units.  n = 0 marks a query whose walk is EXACT (binary index and every w * S an integer): its approximate order is the
-// exact order, nothing to prove.  One wave per query, fixed reduction order.
+// Per query: S = 2^e with (sum |w|) * vmax * S < 2^30 (no int32 sum can wrap), the slack n = non-zeros + 1 in fixed-point
+// units and sum |w|.  n = 0 marks a query whose walk is EXACT (binary index and every w * S an integer): its approximate order
+// is the exact order, nothing to prove.  n = -1 marks a query the quantised records cannot bound (a negative weight): it
+// goes straight to the exact pass.  One wave per query, fixed reduction order.
 template <int UNUSED>
-__global__ __launch_bounds__(256) void bp_qscale_kernel(const int64_t* qptr, const float* qvals, int32_t B, const uint32_t* vmax_bits, int binary,
-                                                        float* qscale, int32_t* qslack) {
+__global__ __launch_bounds__(256) void bp_qscale_kernel(const int64_t* qptr, const float* qvals, int32_t B, const uint32_t* vmax_bits, int binary, int quant,
+                                                        float* qscale, int32_t* qslack, float* qwsum) {
     const int lane = threadIdx.x & 63;
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= B) return;
     const int64_t e0 = qptr[q], e1 = qptr[q + 1];
     float sum = 0.f;
-    for (int64_t e = e0 + lane; e < e1; e += 64) sum += fabsf(qvals[e]);
+    bool neg = false;
+    for (int64_t e = e0 + lane; e < e1; e += 64) { sum += fabsf(qvals[e]); neg = neg || qvals[e] < 0.f; }
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    neg = __builtin_amdgcn_ballot_w64(neg) != 0ull;
     const float vmax = binary ? 1.f : __uint_as_float(vmax_bits[0]);
     const float bound = sum * vmax * 1.0001f;                        // the reduction above is not the walk's order: a hair of slack
     int e = 0;
@@ -63,7 +74,8 @@ __global__ __launch_bounds__(256) void bp_qscale_kernel(const int64_t* qptr, con
     }
     if (lane == 0) {
         qscale[q] = S;
-        qslack[q] = (exact || e1 == e0) ? 0 : (int32_t)min((int64_t)1 << 20, e1 - e0 + 1);
+        qwsum[q] = sum * 1.0001f;
+        qslack[q] = (exact || e1 == e0) ? 0 : ((quant && neg) ? -1 : (int32_t)min((int64_t)1 << 20, e1 - e0 + 1));
     }
 }
 
@@ -80,6 +92,9 @@ struct RefineArgs {
     const float* q;           // [B, n_cols] dense fp32 queries (already rounded to the index dtype)
     const float* qscale;      // [B]
     const int32_t* qslack;    // [B]
+    const float* qwsum;       // [B] sum |w| (rounded up)
+    int32_t force_flag;       // tests: flag every query
+    int32_t quant;            // 1: the records hold fp16-rounded copies of non-negative fp32 values (lossy filter copy)
     int64_t id_offset;
     int64_t* out_ids;         // [B, out_ld]
     float* out_scores;
@@ -108,34 +123,8 @@ __global__ __launch_bounds__(kScanThreads) void refine_topk_kernel(RefineArgs a)
             uint64_t out = 0ull;
             if (key != 0ull) {
                 const uint32_t row = key_row(key);
-                const uint32_t p0 = a.pk_ptr[row], p1 = a.pk_ptr[row + 1];
-                double sum = 0.0;
-                for (uint32_t p = p0 + lane; p < p1; p += 64) {
-                    const uint4 cw = a.cols[p];
-                    const uint32_t cwv[4] = {cw.x, cw.y, cw.z, cw.w};
-                    float v[8];
-                    if constexpr (VM == VM_F32) {
-                        const float4* vp = reinterpret_cast<const float4*>(a.vals);
-                        const float4 v0 = vp[2 * (size_t)p], v1 = vp[2 * (size_t)p + 1];
-                        v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
-                    } else if constexpr (VM == VM_F16) {
-                        const uint4 hv = reinterpret_cast<const uint4*>(a.vals)[p];
-                        const __half2* h = reinterpret_cast<const __half2*>(&hv);
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) { const float2 f = __half22float2(h[t]); v[2 * t] = f.x; v[2 * t + 1] = f.y; }
-                    } else {
-#pragma unroll
-                        for (int t = 0; t < 8; ++t) v[t] = 1.f;
-                    }
-#pragma unroll
-                    for (int t = 0; t < 8; ++t) {
-                        const uint32_t c = (t & 1) ? (cwv[t >> 1] >> 16) : (cwv[t >> 1] & 0xFFFFu);
-                        const float wq = c < (uint32_t)a.n_cols ? qrow[c] : 0.f;       // pad columns (id n_cols) carry no weight
-                        sum += (double)(wq * v[t]);
-                    }
-                }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+                const double sum = row_sum_f64<VM>(a.pk_ptr, a.cols, a.vals, row, lane,
+                                                   [&](uint32_t col) { return col < (uint32_t)a.n_cols ? qrow[col] : 0.f; });   // pad columns (id n_cols) carry no weight
                 out = make_key((float)sum, row);
             }
             if (lane == 0) ex[i] = out;
@@ -148,14 +137,17 @@ __global__ __launch_bounds__(kScanThreads) void refine_topk_kernel(RefineArgs a)
         }
         if (tid == 0) {
             const int32_t slack = a.qslack[b];
-            bool ok = slack == 0 || cut_key == 0ull;
-            if (!ok) {
-                const double bound = ((double)key_fix(cut_key) + (double)slack) / (double)a.qscale[b];    // exact sums outside the K' stay below
+            bool ok = slack == 0 || (cut_key == 0ull && slack > 0);
+            if (!ok && slack > 0) {
+                double bound = ((double)key_fix(cut_key) + (double)slack) / (double)a.qscale[b];    // exact sums outside the K' stay below
+                // Quantised records (values v >= 0 stored as fp16(v), weights w >= 0): |v - fp16(v)| <= 2^-11 v + 2^-25, so the exact sum
+                // E of a document and the sum Q over its stored values satisfy E (1 - 2^-11) <= Q + 2^-25 sum |w|.
+                if (a.quant) bound = (bound + (double)a.qwsum[b] * 0x1p-25) / (1.0 - 0x1p-11);
                 float bf = (float)bound;
                 if ((double)bf < bound) bf = nextafterf(bf, INFINITY);
                 ok = ex[K - 1] != 0ull && key_score(ex[K - 1]) > bf;
             }
-            a.flags[b] = ok ? 0u : 1u;
+            a.flags[b] = (ok && !a.force_flag) ? 0u : 1u;
         }
         __syncthreads();
     }

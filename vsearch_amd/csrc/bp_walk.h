@@ -118,7 +118,8 @@ __global__ __launch_bounds__(kScanThreads) void bp_base_kernel(const uint32_t* b
 }
 
 // pass 3: scatter the non-zeros into their records (the array is zero-filled first: pad postings are document 0, value 0)
-template <int VM>
+// VS = value mode of the CSR packets, VM = value mode of the records (VS = fp32, VM = fp16: the lossy filter copy, see bp_refine.h)
+template <int VS, int VM>
 __global__ __launch_bounds__(kScanThreads) void bp_fill_kernel(const uint32_t* pk_ptr, const uint4* cols, const void* vals, int64_t n_rows,
                                                                int32_t n_cols, int32_t rows, const uint32_t* dir, const unsigned long long* base,
                                                                char* rec) {
@@ -141,11 +142,11 @@ __global__ __launch_bounds__(kScanThreads) void bp_fill_kernel(const uint32_t* p
                 const uint4 cw = cols[p];
                 const uint32_t cwv[4] = {cw.x, cw.y, cw.z, cw.w};
                 float v[8];
-                if constexpr (VM == VM_F32) {
+                if constexpr (VS == VM_F32) {
                     const float4* vp = reinterpret_cast<const float4*>(vals);
                     const float4 v0 = vp[2 * (size_t)p], v1 = vp[2 * (size_t)p + 1];
                     v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
-                } else if constexpr (VM == VM_F16) {
+                } else if constexpr (VS == VM_F16) {
                     const uint4 hv = reinterpret_cast<const uint4*>(vals)[p];
                     const __half2* h = reinterpret_cast<const __half2*>(&hv);
 #pragma unroll
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(kScanThreads) void bp_fill_kernel(const uint32_t* p
                         char* rp = brec + (size_t)(pos >> 3) * RS;
                         reinterpret_cast<uint16_t*>(rp)[pos & 7u] = dl;
                         if constexpr (VM == VM_F32) reinterpret_cast<float*>(rp + 16)[pos & 7u] = v[i];
-                        if constexpr (VM == VM_F16) reinterpret_cast<__half*>(rp + 16)[pos & 7u] = __float2half(v[i]);
+                        if constexpr (VM == VM_F16) reinterpret_cast<__half*>(rp + 16)[pos & 7u] = __float2half_rn(v[i]);
                     }
                 }
             }
@@ -256,14 +257,27 @@ __device__ __forceinline__ void load_rec32(u32x4& a, u32x4& b, uint32_t off, uns
 __device__ __forceinline__ void load_rec16(u32x4& a, uint32_t off, unsigned long long base) {
     asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(a) : "v"(off), "s"(base));
 }
-#define VS_WAIT_CASE(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(a), "+v"(b), "+v"(c)); break;
-__device__ __forceinline__ void wait_loads(int n, u32x4& a, u32x4& b, u32x4& c) {       // n is a constant after unrolling
-    switch (n) {
-        VS_WAIT_CASE(1) VS_WAIT_CASE(2) VS_WAIT_CASE(3) VS_WAIT_CASE(4) VS_WAIT_CASE(6) VS_WAIT_CASE(9)
-        default: asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c)); break;
+// (one overload per register count: naming the same variable twice in one asm makes the compiler copy it BEFORE the wait)
+#define VS_WAIT_CASES(OPS)                                                                                              \
+    switch (n) {                                                                                                        \
+        case 1: asm volatile("s_waitcnt vmcnt(1)" : OPS); break;                                                        \
+        case 2: asm volatile("s_waitcnt vmcnt(2)" : OPS); break;                                                        \
+        case 3: asm volatile("s_waitcnt vmcnt(3)" : OPS); break;                                                        \
+        case 4: asm volatile("s_waitcnt vmcnt(4)" : OPS); break;                                                        \
+        case 6: asm volatile("s_waitcnt vmcnt(6)" : OPS); break;                                                        \
+        case 9: asm volatile("s_waitcnt vmcnt(9)" : OPS); break;                                                        \
+        default: asm volatile("s_waitcnt vmcnt(0)" : OPS); break;                                                       \
     }
-}
-#undef VS_WAIT_CASE
+#define VS_OPS3 "+v"(a), "+v"(b), "+v"(c)
+#define VS_OPS2 "+v"(a), "+v"(b)
+#define VS_OPS1 "+v"(a)
+__device__ __forceinline__ void wait_loads(int n, u32x4& a, u32x4& b, u32x4& c) { VS_WAIT_CASES(VS_OPS3) }      // n is a constant after unrolling
+__device__ __forceinline__ void wait_loads(int n, u32x4& a, u32x4& b) { VS_WAIT_CASES(VS_OPS2) }
+__device__ __forceinline__ void wait_loads(int n, u32x4& a) { VS_WAIT_CASES(VS_OPS1) }
+#undef VS_OPS1
+#undef VS_OPS2
+#undef VS_OPS3
+#undef VS_WAIT_CASES
 // accumulate into LDS at a byte address (ds_add_u32 / ds_add_f64, no return)
 __device__ __forceinline__ void lds_add(uint32_t addr, int32_t v) {
     __hip_atomic_fetch_add(reinterpret_cast<__attribute__((address_space(3))) int32_t*>(addr), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -276,14 +290,14 @@ __device__ __forceinline__ void lds_add(uint32_t addr, double v) {
 template <int VM, int QT, int AM, int LG>
 __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
     static_assert(bp_acc_bytes<QT, AM>() >= kBpSortBytes, "the accumulator area holds the 8192-slot entry sort");
-    static_assert(kBpNB % LG == 0, "a lane owns NB / LG directory pairs of a slot");
+    static_assert(kBpNB % LG == 0 || LG % kBpNB == 0, "lane l of a group owns the directory pairs of lists l, l + LG, ... of a slot");
     using acc_t = typename std::conditional<AM == AM_F64, double, int32_t>::type;
     constexpr int PITCH = QT + 1;                 // accumulator row pitch in elements: a document's row starts an odd number of words
                                                   // after its neighbour's, so the adds of a wave spread over all LDS banks
     constexpr uint32_t PITCHB = PITCH * sizeof(acc_t);
     constexpr int RS = bp_rec_bytes(VM);
     constexpr int NB = kBpNB;
-    constexpr int OWN = NB / LG;                  // directory pairs a lane owns per slot
+    constexpr int OWN = NB >= LG ? NB / LG : 1;   // directory pairs a lane owns per slot (lanes >= NB of a wide group own none)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     acc_t* acc = reinterpret_cast<acc_t*>(smem);                                            // [kBpRowsMax][PITCH]
     uint64_t* sortbuf = reinterpret_cast<uint64_t*>(smem + bp_acc_bytes<QT, AM>());         // [kBpCap]
@@ -359,7 +373,7 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
                 for (int o = 0; o < OWN; ++o) {
                     const int e = gid + NG * (gl + LG * o);
                     nlo[o] = 0; nhi[o] = 0;
-                    if (e < n_ent) {
+                    if (gl + LG * o < NB && e < n_ent) {
                         const uint32_t cc = ent[e].x & 0xFFFFu;
                         nlo[o] = dirb[cc];
                         nhi[o] = dirb[cc + 1];
@@ -372,7 +386,7 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
                         clo[o] = nlo[o]; chi[o] = nhi[o];
                         nlo[o] = 0; nhi[o] = 0;
                         const int e = gid + NG * (gl + LG * o + NB * (j + 1));
-                        if (e < n_ent) {
+                        if (gl + LG * o < NB && e < n_ent) {
                             const uint32_t cc = ent[e].x & 0xFFFFu;
                             nlo[o] = dirb[cc];
                             nhi[o] = dirb[cc + 1];
@@ -404,8 +418,8 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
 #pragma unroll
                         for (int u = 0; u < NB; ++u) {
                             if constexpr (VM == VM_F32) wait_loads((NB - 1 - u) * 3, ids[u], va[u], vb[u]);
-                            else if constexpr (VM == VM_F16) wait_loads((NB - 1 - u) * 2, ids[u], va[u], va[u]);
-                            else wait_loads(NB - 1 - u, ids[u], ids[u], ids[u]);
+                            else if constexpr (VM == VM_F16) wait_loads((NB - 1 - u) * 2, ids[u], va[u]);
+                            else wait_loads(NB - 1 - u, ids[u]);
                             if (rec[u] < end[u]) {
                                 const float wq = __uint_as_float(en[u].y);
                                 const uint32_t so = (en[u].x >> 16) + lds0;         // LDS byte address of [document 0][slot]

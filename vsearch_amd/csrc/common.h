@@ -209,7 +209,11 @@ struct vs_index {
     vs::DevBuf bp_rec;   // records: 8 x uint16 document-in-block + 8 values (fp32 | fp16 | none)
     vs::DevBuf bp_df;    // uint64 [2][n_cols]: records / non-zeros per column over all blocks -- what a query entry walks
     int64_t bp_records = 0;
-    vs::DevBuf bp_vmax;  // float bits: max |value| of the index (bounds the fixed-point walk's products)
+    vs::DevBuf bp_vmax;  // [2] uint32: float bits of max |value| (bounds the fixed-point walk's products), any-value-negative flag
+    int bp_lanes = 8;    // option "postings_lanes": lanes per posting list of a valued index (4 | 8)
+    bool bp_force_fb = false;   // option "postings_force_fallback" (tests)
+    bool bp_quant = false;   // the records of this fp32 index hold fp16-rounded values (lossy filter copy, bp_refine.h)
+    int bp_quant_pref = -1;  // option "postings_quant": -1 auto (on when the data allow it), 0 = keep fp32 values in the records
     int bp_filter = 1;   // option "postings_filter": 1 = int32 fixed-point walk + exact refine (default), 0 = fp64 walk only
     int64_t last_walk_postings = 0;      // postings (multiply-adds) the most recent search's walk visited
     const uint32_t* last_flags = nullptr; // device [last_flags_n]: queries of the most recent filter search that took the exact walk

@@ -716,6 +716,12 @@ bool bp_wanted(const vs_index* idx) {
     return idx->n_rows >= 16384 && (double)idx->nnz / (double)idx->n_rows >= 256.0;
 }
 
+// value mode of the records: the index's own, or fp16 for the lossy filter copy of an fp32 index (bp_refine.h)
+inline int bp_record_vm(const vs_index* idx) {
+    if (idx->store_dtype == VS_NONE) return VM_BIN;
+    return (idx->store_dtype == VS_F16 || idx->bp_quant) ? VM_F16 : VM_F32;
+}
+
 void bp_release(vs_index* idx) {
     idx->bp_dir.release(); idx->bp_base.release(); idx->bp_rec.release(); idx->bp_df.release(); idx->bp_vmax.release();
     idx->bp_ready = false;
@@ -725,8 +731,10 @@ template <int QT, int AM>
 int launch_bp_walk(const vs_index* idx, const BpArgs& a, int grid, int ent_cap, hipStream_t s) {
     const size_t lds = bp_lds_bytes<QT, AM>(ent_cap);
     if (lds > 160 * 1024) return fail(VS_EUNSUPPORTED, "postings walk needs %zu B of LDS", lds);
-    void (*kern)(BpArgs) = idx->store_dtype == VS_F32 ? bp_walk_topk<VM_F32, QT, AM, 4>
-                         : idx->store_dtype == VS_F16 ? bp_walk_topk<VM_F16, QT, AM, 4> : bp_walk_topk<VM_BIN, QT, AM, 1>;
+    const int vm = bp_record_vm(idx);
+    void (*kern)(BpArgs) = vm == VM_F32 ? (idx->bp_lanes == 8 ? bp_walk_topk<VM_F32, QT, AM, 8> : bp_walk_topk<VM_F32, QT, AM, 4>)
+                         : vm == VM_F16 ? (idx->bp_lanes == 8 ? bp_walk_topk<VM_F16, QT, AM, 8> : bp_walk_topk<VM_F16, QT, AM, 4>)
+                                        : bp_walk_topk<VM_BIN, QT, AM, 1>;
     VS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kScanThreads), lds, s, a);
     VS_HIP(hipGetLastError());
@@ -741,7 +749,7 @@ int bp_build(vs_index* idx, hipStream_t s) {
     idx->bp_rows = idx->bp_rows_pref > 0 ? idx->bp_rows_pref : kBpRowsMax;
     const int64_t n_blocks = ceil_div64(idx->n_rows, idx->bp_rows);
     const int V = idx->n_cols;
-    const int RS = bp_rec_bytes(idx->store_dtype == VS_F32 ? VM_F32 : idx->store_dtype == VS_F16 ? VM_F16 : VM_BIN);
+    const int RS0 = bp_rec_bytes(idx->store_dtype == VS_F32 ? VM_F16 : idx->store_dtype == VS_F16 ? VM_F16 : VM_BIN);   // smallest record this index can get
     const size_t b_dir = (size_t)n_blocks * ((size_t)V + 1) * 4;
     size_t free_b = 0, total_b = 0;
     VS_HIP(hipMemGetInfo(&free_b, &total_b));
@@ -754,7 +762,7 @@ int bp_build(vs_index* idx, hipStream_t s) {
         return VS_OK;
     };
     // lower bound of the records: one per 8 non-zeros
-    if (free_b < b_dir + (size_t)idx->n_packets * RS + margin) return no_room(b_dir + (size_t)idx->n_packets * RS);
+    if (free_b < b_dir + (size_t)idx->n_packets * RS0 + margin) return no_room(b_dir + (size_t)idx->n_packets * RS0);
     DevBuf block_recs;
     if (idx->bp_dir.alloc(b_dir) != VS_OK || idx->bp_base.alloc((size_t)(n_blocks + 1) * 8) != VS_OK || idx->bp_df.alloc((size_t)V * 16) != VS_OK ||
         block_recs.alloc((size_t)n_blocks * 4) != VS_OK)
@@ -772,40 +780,44 @@ int bp_build(vs_index* idx, hipStream_t s) {
     hipLaunchKernelGGL(bp_base_kernel<0>, dim3(1), dim3(kScanThreads), 0, s, block_recs.as<uint32_t>(), n_blocks, idx->bp_base.as<unsigned long long>());
     VS_HIP(hipGetLastError());
     VS_STAGE("bp_base", s);
-    unsigned long long n_rec = 0;
-    VS_HIP(hipMemcpyAsync(&n_rec, idx->bp_base.as<unsigned long long>() + n_blocks, 8, hipMemcpyDeviceToHost, s));
-    VS_HIP(hipStreamSynchronize(s));
-    const size_t b_rec = ((size_t)n_rec + 1) * RS;                       // + one record: a lane past the last list's end re-reads "the record at the end"
-    VS_HIP(hipMemGetInfo(&free_b, &total_b));
-    if (free_b < b_rec + margin || idx->bp_rec.alloc(b_rec) != VS_OK) return no_room(b_rec);
-    idx->bp_records = (int64_t)n_rec;
-    VS_HIP(hipMemsetAsync(idx->bp_rec.p, 0, b_rec, s));                  // pad postings: document 0, value 0
-    if (idx->store_dtype == VS_F32) {
-        VS_HIP(hipFuncSetAttribute((const void*)bp_fill_kernel<VM_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(bp_fill_kernel<VM_F32>, dim3(grid), dim3(kScanThreads), lds, s, idx->pk_ptr.as<uint32_t>(), idx->cols.as<uint4>(), (const void*)idx->vals.p,
-                           idx->n_rows, V, idx->bp_rows, idx->bp_dir.as<uint32_t>(), idx->bp_base.as<unsigned long long>(), idx->bp_rec.as<char>());
-    } else if (idx->store_dtype == VS_F16) {
-        VS_HIP(hipFuncSetAttribute((const void*)bp_fill_kernel<VM_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(bp_fill_kernel<VM_F16>, dim3(grid), dim3(kScanThreads), lds, s, idx->pk_ptr.as<uint32_t>(), idx->cols.as<uint4>(), (const void*)idx->vals.p,
-                           idx->n_rows, V, idx->bp_rows, idx->bp_dir.as<uint32_t>(), idx->bp_base.as<unsigned long long>(), idx->bp_rec.as<char>());
-    } else {
-        VS_HIP(hipFuncSetAttribute((const void*)bp_fill_kernel<VM_BIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(bp_fill_kernel<VM_BIN>, dim3(grid), dim3(kScanThreads), lds, s, idx->pk_ptr.as<uint32_t>(), idx->cols.as<uint4>(), (const void*)nullptr,
-                           idx->n_rows, V, idx->bp_rows, idx->bp_dir.as<uint32_t>(), idx->bp_base.as<unsigned long long>(), idx->bp_rec.as<char>());
-    }
-    VS_HIP(hipGetLastError());
-    VS_STAGE("bp_fill", s);
-    // max |value|: bounds the products of the fixed-point walk (bp_refine.h); a binary index has none (every value is 1)
-    if (idx->store_dtype != VS_NONE && idx->bp_vmax.alloc(4) == VS_OK) {
-        VS_HIP(hipMemsetAsync(idx->bp_vmax.p, 0, 4, s));
+    // max |value| (bounds the products of the fixed-point walk) and "any value negative"; a binary index has no values
+    uint32_t hv[2] = {0x3F800000u, 0u};
+    if (idx->store_dtype != VS_NONE) {
+        VS_TRY(idx->bp_vmax.alloc(8));
+        VS_HIP(hipMemsetAsync(idx->bp_vmax.p, 0, 8, s));
         const int64_t nv = idx->n_packets * 8;
         const unsigned g = (unsigned)std::min<int64_t>(ceil_div64(nv, 256 * 16), (int64_t)idx->cu_count * 16);
         if (idx->store_dtype == VS_F32) hipLaunchKernelGGL(bp_vmax_kernel<VM_F32>, dim3(g), dim3(256), 0, s, (const void*)idx->vals.p, nv, idx->bp_vmax.as<uint32_t>());
         else hipLaunchKernelGGL(bp_vmax_kernel<VM_F16>, dim3(g), dim3(256), 0, s, (const void*)idx->vals.p, nv, idx->bp_vmax.as<uint32_t>());
         VS_HIP(hipGetLastError());
+        VS_HIP(hipMemcpyAsync(hv, idx->bp_vmax.p, 8, hipMemcpyDeviceToHost, s));
     }
-    VS_HIP(hipStreamSynchronize(s));                                     // `block_recs` is freed on return
+    unsigned long long n_rec = 0;
+    VS_HIP(hipMemcpyAsync(&n_rec, idx->bp_base.as<unsigned long long>() + n_blocks, 8, hipMemcpyDeviceToHost, s));
+    VS_HIP(hipStreamSynchronize(s));
     VS_STAGE("bp_vmax", s);
+    // Lossy filter copy of an fp32 index: values rounded to fp16 (4 instead of 6 bytes per posting); needs the filter-and-refine
+    // search, non-negative values and no fp16 overflow
+    float vmax_f;
+    memcpy(&vmax_f, &hv[0], 4);
+    idx->bp_quant = idx->store_dtype == VS_F32 && idx->bp_filter != 0 && idx->bp_quant_pref != 0 && hv[1] == 0u && vmax_f < 60000.f;
+    const int RS = bp_rec_bytes(bp_record_vm(idx));
+    const size_t b_rec = ((size_t)n_rec + 1) * RS;                       // + one record: a lane past the last list's end re-reads "the record at the end"
+    VS_HIP(hipMemGetInfo(&free_b, &total_b));
+    if (free_b < b_rec + margin || idx->bp_rec.alloc(b_rec) != VS_OK) return no_room(b_rec);
+    idx->bp_records = (int64_t)n_rec;
+    VS_HIP(hipMemsetAsync(idx->bp_rec.p, 0, b_rec, s));                  // pad postings: document 0, value 0
+    {
+        void (*fill)(const uint32_t*, const uint4*, const void*, int64_t, int32_t, int32_t, const uint32_t*, const unsigned long long*, char*) =
+            idx->store_dtype == VS_F32 ? (idx->bp_quant ? bp_fill_kernel<VM_F32, VM_F16> : bp_fill_kernel<VM_F32, VM_F32>)
+            : idx->store_dtype == VS_F16 ? bp_fill_kernel<VM_F16, VM_F16> : bp_fill_kernel<VM_BIN, VM_BIN>;
+        VS_HIP(hipFuncSetAttribute((const void*)fill, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(fill, dim3(grid), dim3(kScanThreads), lds, s, idx->pk_ptr.as<uint32_t>(), idx->cols.as<uint4>(), (const void*)idx->vals.p, idx->n_rows, V,
+                           idx->bp_rows, idx->bp_dir.as<uint32_t>(), idx->bp_base.as<unsigned long long>(), idx->bp_rec.as<char>());
+    }
+    VS_HIP(hipGetLastError());
+    VS_STAGE("bp_fill", s);
+    VS_HIP(hipStreamSynchronize(s));                                     // `block_recs` is freed on return
     if (debug_sync_on()) {
         std::vector<unsigned long long> hb((size_t)n_blocks + 1);
         std::vector<uint32_t> hd((size_t)V + 1);
@@ -829,12 +841,12 @@ int bp_build(vs_index* idx, hipStream_t s) {
 int mq_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64_t id_offset, int64_t* d_ids, float* d_scores,
               const ScanPlan& plan, hipStream_t s, bool* done, int32_t out_ld, int32_t col0, uint64_t* upper) {
     *done = false;
-    const bool use_bp = idx->bp_ready;
     // Filter and refine (bp_refine.h): the walk runs on int32 fixed-point sums and returns K' > k documents per query, the refine
     // kernel re-scores them exactly and proves the top k; unproven queries go through the fp64 walk.  Without it (option
     // "postings_filter" = 0, "search after" passes, k beyond the candidate buffers) every tile takes the fp64 walk.
     const int kp = k + std::max(28, k / 4);
-    const bool filter = use_bp && idx->bp_filter != 0 && col0 == 0 && !upper && kp <= kBpMaxK && (idx->store_dtype == VS_NONE || idx->bp_vmax.p);
+    const bool filter = idx->bp_ready && idx->bp_filter != 0 && col0 == 0 && !upper && kp <= kBpMaxK && (idx->store_dtype == VS_NONE || idx->bp_vmax.p);
+    const bool use_bp = idx->bp_ready && (filter || !idx->bp_quant);          // lossy records serve the filter only
     const int qt_plan = use_bp && !filter ? kBpExactQT : kQT;
     const int bp_cap = filter ? kBpEntCap : kBpEntCap / 2;
     const int vals_cap = use_bp ? std::min(mq_vals_cap(idx), bp_cap) : mq_vals_cap(idx);     // entries (non-zeros) one tile may hold
@@ -877,20 +889,21 @@ int mq_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64_t id_o
         // blocked postings: chunks are runs of blocks
         const int64_t n_blocks = ceil_div64(idx->n_rows, idx->bp_rows);
         nchunk = (int)std::min<int64_t>(nchunk, n_blocks);
-        // Big index: 16 chunks (or 12 / 24 when that fills the CUs better).  Workgroup b runs on XCD b % 8 and takes items
-        // b, b + grid, ...; what matters is how many chunks the 32 CUs behind one L2 work on at a time: tiles share directory
-        // and posting lines, so few chunks per XCD is good -- but exactly one (8 chunks) makes 32 workgroups hammer the same
-        // lines and is as slow as no affinity at all.
-        if (idx->n_rows >= (2 << 20) && (int64_t)n_tiles * 12 >= idx->cu_count) {
-            int best = 16;
+        // Big index, enough tiles: as FEW chunks as give every CU two work items.  Every tile sweeps its chunk's blocks in the same
+        // order at the same pace, so with few chunks all tiles are within a few blocks of each other and each block is fetched from
+        // HBM once for all of them (Infinity Cache): 21 M docs, 1024 queries: 4 chunks 300 ms, 8: 333, 16: 399, 64: 561, 2 (one item
+        // per CU, no second round to even out): 419.
+        if (idx->n_rows >= (2 << 20) && (int64_t)n_tiles * 4 >= idx->cu_count) {
+            int best = 1;
             double best_eff = 0.0;
-            for (int c : {16, 12, 24}) {
+            const int c0 = (int)std::max<int64_t>(1, ceil_div64(2 * (int64_t)idx->cu_count, n_tiles));
+            for (int c = c0; c <= c0 + 3; ++c) {
                 const int64_t it = (int64_t)n_tiles * c;
                 const double eff = (double)it / (double)(ceil_div64(it, idx->cu_count) * idx->cu_count);
                 if (eff > best_eff + 1e-9) { best_eff = eff; best = c; }
-                if (eff >= 0.92) break;
+                if (eff >= 0.95) break;
             }
-            nchunk = best;
+            nchunk = (int)std::min<int64_t>(best, n_blocks);
         }
         if (idx->bp_chunks > 0) nchunk = (int)std::min<int64_t>(idx->bp_chunks, n_blocks);
         const int64_t blocks_per_chunk = ceil_div64(n_blocks, nchunk);
@@ -899,7 +912,7 @@ int mq_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64_t id_o
         const int nchunk_fb = (int)std::min<int64_t>(n_blocks, 64);
         VS_TRY(idx->ws_mq_cand.reserve((size_t)idx->cu_count * kQT * kBpCap * 8));
         VS_TRY(idx->ws_cand.reserve(std::max((size_t)B * nchunk * (filter ? kp : k), filter ? (size_t)B * nchunk_fb * k : (size_t)0) * 8));
-        const int RS = bp_rec_bytes(idx->store_dtype == VS_F32 ? VM_F32 : idx->store_dtype == VS_F16 ? VM_F16 : VM_BIN);
+        const int RS = bp_rec_bytes(bp_record_vm(idx));
         BpArgs a{};
         a.rows = idx->bp_rows;
         a.dir = idx->bp_dir.as<uint32_t>();
@@ -924,14 +937,15 @@ int mq_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64_t id_o
         idx->last_scan_bytes += hplan[4] * RS + qnnz * n_blocks * 8;
         idx->last_walk_postings += hplan[5];
         if (filter) {
-            VS_TRY(idx->ws_fb.reserve((size_t)B * sizeof(int2) + (size_t)B * 12 + 64));
+            VS_TRY(idx->ws_fb.reserve((size_t)B * sizeof(int2) + (size_t)B * 16 + 64));
             int2* fb_tiles = idx->ws_fb.as<int2>();
             float* qscale = reinterpret_cast<float*>(fb_tiles + B);
             int32_t* qslack = reinterpret_cast<int32_t*>(qscale + B);
-            uint32_t* flags = reinterpret_cast<uint32_t*>(qslack + B);
+            float* qwsum = reinterpret_cast<float*>(qslack + B);
+            uint32_t* flags = reinterpret_cast<uint32_t*>(qwsum + B);
             int32_t* fb_n = reinterpret_cast<int32_t*>(flags + B);
             hipLaunchKernelGGL(bp_qscale_kernel<0>, dim3((unsigned)ceil_div(B, 4)), dim3(256), 0, s, qptr, qvals, B, idx->bp_vmax.as<uint32_t>(),
-                               idx->store_dtype == VS_NONE ? 1 : 0, qscale, qslack);
+                               idx->store_dtype == VS_NONE ? 1 : 0, idx->bp_quant ? 1 : 0, qscale, qslack, qwsum);
             VS_HIP(hipGetLastError());
             a.k = kp;
             a.qscale = qscale;
@@ -954,6 +968,9 @@ int mq_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64_t id_o
             r.q = dq;
             r.qscale = qscale;
             r.qslack = qslack;
+            r.qwsum = qwsum;
+            r.quant = idx->bp_quant ? 1 : 0;
+            r.force_flag = idx->bp_force_fb ? 1 : 0;
             r.id_offset = id_offset;
             r.out_ids = d_ids;
             r.out_scores = d_scores;
@@ -980,7 +997,27 @@ int mq_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64_t id_o
             a.ent_cap = std::min(vals_cap, kBpEntCap / 2);
             {
                 ProfScope prof("exact_fallback", s);
-                VS_TRY((launch_bp_walk<kBpExactQT, AM_F64>(idx, a, idx->cu_count, a.ent_cap, s)));
+                if (idx->bp_quant) {
+                    // the records are lossy: the unproven queries take a one-query-per-pass scan of the CSR packets (fp64 row sums)
+                    ScanArgs sa{};
+                    sa.pk_ptr = idx->pk_ptr.as<uint32_t>();
+                    sa.cols = idx->cols.as<uint4>();
+                    sa.vals = idx->vals.p;
+                    sa.q = dq;
+                    sa.n_rows = idx->n_rows;
+                    sa.n_cols = V;
+                    sa.B = B;
+                    sa.k = k;
+                    sa.nchunk = nchunk_fb;
+                    sa.rows_per_chunk = ceil_div64(idx->n_rows, nchunk_fb);
+                    sa.cand = a.cand;
+                    const size_t slds = scan_lds_bytes(V);
+                    VS_HIP(hipFuncSetAttribute((const void*)exact_scan_topk_kernel<VM_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds));
+                    hipLaunchKernelGGL(exact_scan_topk_kernel<VM_F32>, dim3(idx->cu_count), dim3(kScanThreads), slds, s, sa, (const int2*)fb_tiles, (const int32_t*)fb_n);
+                    VS_HIP(hipGetLastError());
+                } else {
+                    VS_TRY((launch_bp_walk<kBpExactQT, AM_F64>(idx, a, idx->cu_count, a.ent_cap, s)));
+                }
                 MergeArgs m{};
                 m.cand = a.cand;
                 m.n_cand = (int64_t)nchunk_fb * k;

@@ -292,6 +292,95 @@ __global__ __launch_bounds__(kScanThreads) void csr_scan_topk_shared(ScanArgs a)
     }
 }
 
+// ---- exact row score: fp32 products summed in fp64 (the numerics of the multi-query scan and of the postings walk) ------
+// One wave per row, a lane takes whole packets p0 + lane, p0 + lane + 64, ...; `weight(c)` returns the query weight of column c.
+template <int VM, class W>
+__device__ __forceinline__ double row_sum_f64(const uint32_t* pk_ptr, const uint4* cols, const void* vals, uint32_t row, int lane, W weight) {
+    const uint32_t p0 = pk_ptr[row], p1 = pk_ptr[row + 1];
+    double sum = 0.0;
+    for (uint32_t p = p0 + lane; p < p1; p += 64) {
+        const uint4 cw = cols[p];
+        const uint32_t cwv[4] = {cw.x, cw.y, cw.z, cw.w};
+        float v[8];
+        if constexpr (VM == VM_F32) {
+            const float4* vp = reinterpret_cast<const float4*>(vals);
+            const float4 v0 = vp[2 * (size_t)p], v1 = vp[2 * (size_t)p + 1];
+            v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
+        } else if constexpr (VM == VM_F16) {
+            const uint4 hv = reinterpret_cast<const uint4*>(vals)[p];
+            const __half2* h = reinterpret_cast<const __half2*>(&hv);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { const float2 f = __half22float2(h[t]); v[2 * t] = f.x; v[2 * t + 1] = f.y; }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) v[t] = 1.f;
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const uint32_t c = (t & 1) ? (cwv[t >> 1] >> 16) : (cwv[t >> 1] & 0xFFFFu);
+            sum += (double)(weight(c) * v[t]);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    return sum;
+}
+
+// ---- exact pass for queries picked on the device (sel[i].x, i < sel_n[0]): the filter-and-refine search's unproven queries when
+// the postings copy is lossy.  One query per pass like csr_scan_topk_shared, one wave per row, fp64 row sums.
+template <int VM>
+__global__ __launch_bounds__(kScanThreads) void exact_scan_topk_kernel(ScanArgs a, const int2* sel, const int32_t* sel_n) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* img = reinterpret_cast<float*>(smem);
+    uint64_t* cand = reinterpret_cast<uint64_t*>(smem + scan_img_bytes(a.n_cols));
+    int* cnt_sh = reinterpret_cast<int*>(cand + kWgCap);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    constexpr int SB = (kWgCap - kMaxKShared) / kScanWaves;      // iterations between prune checks
+    const int K = a.k;
+    const int64_t items = (int64_t)sel_n[0] * a.nchunk;
+    for (int64_t item = blockIdx.x; item < items; item += gridDim.x) {
+        const int qi = sel[item / a.nchunk].x, c = (int)(item % a.nchunk);
+        const int64_t r0 = (int64_t)c * a.rows_per_chunk;
+        const int64_t r1 = min(a.n_rows, r0 + a.rows_per_chunk);
+        __syncthreads();
+        load_image(a, img, qi, tid);
+        if (tid == 0) *cnt_sh = 0;
+        __syncthreads();
+        uint64_t tau = 0;
+        const int64_t iters = (r1 - r0 + kScanWaves - 1) / kScanWaves;
+        for (int64_t it0 = 0; it0 < iters; it0 += SB) {
+            const int64_t it1 = min(iters, it0 + SB);
+            for (int64_t it = it0; it < it1; ++it) {
+                const int64_t row = r0 + it * kScanWaves + w;
+                if (row < r1) {
+                    const double sum = row_sum_f64<VM>(a.pk_ptr, a.cols, a.vals, (uint32_t)row, lane, [&](uint32_t col) { return img[col]; });
+                    const uint64_t key = make_key((float)sum, (uint32_t)row);
+                    if (lane == 0 && key > tau) cand[atomicAdd(cnt_sh, 1)] = key;
+                }
+            }
+            __syncthreads();
+            const int cnt = *cnt_sh;
+            const bool last = it1 >= iters;
+            if (last || cnt > kMaxKShared) {                // uniform: cnt read after the barrier
+                for (int i = cnt + tid; i < kWgCap; i += kScanThreads) cand[i] = 0ull;
+                wg_sort_desc<kScanThreads>(cand, kWgCap, tid);
+                if (!last && cnt > K) {
+                    tau = cand[K - 1];
+                    __syncthreads();
+                    if (tid == 0) *cnt_sh = K;
+                }
+            }
+            __syncthreads();
+        }
+        if (iters == 0) {
+            for (int i = tid; i < kWgCap; i += kScanThreads) cand[i] = 0ull;
+            __syncthreads();
+        }
+        uint64_t* out = a.cand + ((size_t)qi * a.nchunk + c) * (size_t)K;
+        for (int i = tid; i < K; i += kScanThreads) out[i] = cand[i];
+    }
+}
+
 // ---- merge: per query, [n_lists * k] keys (each list sorted or not) -> top-k ids + scores --------
 struct MergeArgs {
     const uint64_t* cand;     // [B, n_cand]
