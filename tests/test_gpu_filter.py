@@ -1,0 +1,186 @@
+"""GPU parity tests of the filter-and-refine postings search (bp_walk.h / bp_refine.h) -- run on MI355X.
+
+The search is exact by construction: the fixed-point walk only proposes candidates, the refine step re-scores them with the
+library's exact numerics and proves the top k, unproven queries take an exact pass.  Every mode below must therefore return
+the CSR scan's ids and scores BIT FOR BIT (same canonical order), and a valid top-k of the oracle's score matrix."""
+import numpy as np
+import pytest
+
+import oracle
+from oracle import compare
+from conftest import V
+from vsearch_amd import synth
+from vsearch_amd import _native as nat
+from vsearch_amd.device_index import DeviceIndex
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+
+
+def _search(idx, q, k, **opts):
+    for name, value in opts.items():
+        idx.set_option(name, value)
+    ids, sc = idx.search(q, k)
+    return np.asarray(ids), np.asarray(sc), idx.info()
+
+
+def _modes(idx, q, k, want_quant, tied_queries=0):
+    """-> results of {csr scan, filter, filter on exact records, forced fallback x 2, fp64 walk}; checks paths and bit-equality."""
+    ref_ids, ref_sc, info = _search(idx, q, k, blocked_postings=0)
+    assert info.last_path == 1
+    out = {}
+    for name, opts in [("filter", dict(postings_filter=1, postings_quant=-1, postings_force_fallback=0)),
+                       ("filter-exact-records", dict(postings_filter=1, postings_quant=0, postings_force_fallback=0)),
+                       ("fallback", dict(postings_filter=1, postings_quant=-1, postings_force_fallback=1)),
+                       ("fallback-exact-records", dict(postings_filter=1, postings_quant=0, postings_force_fallback=1)),
+                       ("fp64-walk", dict(postings_filter=0, postings_force_fallback=0))]:
+        ids, sc, info = _search(idx, q, k, blocked_postings=1, **opts)
+        if name == "fp64-walk":
+            assert info.last_path == 2
+        else:
+            assert info.last_path == 3
+            assert info.last_fallbacks == (q.shape[0] if name.startswith("fallback") else tied_queries), name
+        assert (ids == ref_ids).all() and (sc == ref_sc).all(), f"{name}: differs from the CSR scan"
+        out[name] = info
+    idx.set_option("postings_force_fallback", 0)
+    idx.set_option("postings_quant", -1)
+    idx.set_option("postings_filter", 1)
+    return ref_ids, ref_sc
+
+
+@pytest.mark.parametrize("store", [nat.VS_F32, nat.VS_F16], ids=["fp32", "fp16"])
+@pytest.mark.parametrize("k", [1, 100, 700])
+def test_filter_refine_is_bit_identical_to_the_csr_scan(store, k):
+    n = 6000
+    ip, ix, d = oracle.synth_csr(0, 0, n)
+    if store == nat.VS_F16:
+        d = d.astype(np.float16).astype(np.float32)
+    idx = DeviceIndex.from_csr(ip, ix, d, V, store_dtype=store)
+    law = synth.VAL_GRID if store == nat.VS_F32 else synth.VAL_DYADIC
+    q = oracle.synth_queries(1, 19, val_law=law)                  # ragged batch: 2 full tiles + 3 queries
+    ids, sc = _modes(idx, q, k, want_quant=store == nat.VS_F32)
+    o_ids, o_sc, allsc = oracle.csr_search(ip, ix, d, V, q, k, acc64=True, return_all=True)
+    compare.check_topk_valid(allsc, ids, sc, rtol=RTOL)
+    compare.compare_topk(o_ids, o_sc, ids, sc, rtol=RTOL)
+
+
+def test_filter_on_ragged_rows_and_partial_last_block():
+    """Rows of 0..2000 non-zeros, 2 blocks + a partial one, empty rows, an all-zero query and a one-column query."""
+    rng = np.random.default_rng(7)
+    n = 2 * 2048 + 777
+    lens = rng.integers(0, 300, size=n)
+    lens[::131] = 2000
+    lens[[0, 5, n - 1]] = 0
+    ip = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(lens, out=ip[1:])
+    ix = np.concatenate([np.sort(rng.choice(V, size=l, replace=False)) for l in lens]).astype(np.int32)
+    d = (0.01 + 3 * rng.random(len(ix))).astype(np.float32)
+    q = oracle.synth_queries(3, 10)
+    q[4] = 0.0
+    q[7] = 0.0
+    q[7, ix[10]] = 2.5
+    idx = DeviceIndex.from_csr(ip, ix, d, V)
+    ids, sc = _modes(idx, q, 50, want_quant=True, tied_queries=1)      # the one-column query: thousands of documents tie at score 0
+    _, _, allsc = oracle.csr_search(ip, ix, d, V, q, 50, acc64=True, return_all=True)
+    compare.check_topk_valid(allsc, ids, sc, rtol=RTOL)
+
+
+def test_ties_beyond_the_candidate_margin_take_the_exact_pass():
+    """600 identical best documents: no candidate set of k + 28 can be proven, so those queries must fall back -- and still
+    return the canonical (lowest ids first) answer."""
+    ip, ix, d = oracle.synth_csr(2, 0, 5000)
+    ix2, d2 = ix.copy(), d.copy()
+    q = oracle.synth_queries(5, 8)
+    cols = np.nonzero(q[0])[0][:768].astype(ix.dtype)
+    for r in range(100, 700):                                      # rows 100..699: the same row, hitting query 0 on every column
+        ix2[ip[r]:ip[r + 1]] = np.sort(cols)
+        d2[ip[r]:ip[r + 1]] = 2.0
+    idx = DeviceIndex.from_csr(ip, ix2, d2, V)
+    ref_ids, ref_sc, _ = _search(idx, q, 100, blocked_postings=0)
+    ids, sc, info = _search(idx, q, 100, blocked_postings=1)
+    assert info.last_path == 3 and info.last_fallbacks >= 1
+    assert (ids == ref_ids).all() and (sc == ref_sc).all()
+    assert (ids[0] == np.arange(100, 200)).all()
+    ids, sc, info = _search(idx, q, 100, blocked_postings=1, postings_quant=0)
+    assert info.last_fallbacks >= 1 and (ids == ref_ids).all() and (sc == ref_sc).all()
+
+
+def test_signed_values_and_weights():
+    """Negative index values keep fp32 records (the lossy copy needs non-negative data); a negative query weight on a lossy
+    copy sends that query to the exact pass.  Results stay those of the CSR scan."""
+    ip, ix, d = oracle.synth_csr(4, 0, 5000)
+    rng = np.random.default_rng(1)
+    q = oracle.synth_queries(6, 9)
+    qneg = q.copy()
+    qneg[2, np.nonzero(q[2])[0][::3]] *= -1.0
+    idx = DeviceIndex.from_csr(ip, ix, d, V)                       # non-negative values: lossy copy
+    ref = _search(idx, qneg, 100, blocked_postings=0)
+    got = _search(idx, qneg, 100, blocked_postings=1)
+    assert got[2].last_path == 3 and got[2].last_fallbacks == 1
+    assert (got[0] == ref[0]).all() and (got[1] == ref[1]).all()
+    dneg = d * np.where(rng.random(len(d)) < 0.3, -1.0, 1.0).astype(np.float32)
+    idx2 = DeviceIndex.from_csr(ip, ix, dneg, V)                   # signed values: exact records, signed fixed-point sums
+    ref = _search(idx2, qneg, 100, blocked_postings=0)
+    got = _search(idx2, qneg, 100, blocked_postings=1)
+    assert got[2].last_path == 3
+    assert (got[0] == ref[0]).all() and (got[1] == ref[1]).all()
+    _, _, allsc = oracle.csr_search(ip, ix, dneg, V, qneg, 100, acc64=True, return_all=True)
+    compare.check_topk_valid(allsc, got[0], got[1], rtol=RTOL)
+
+
+@pytest.mark.parametrize("law", [synth.VAL_DYADIC, synth.VAL_GRID], ids=["dyadic", "fp32-weights"])
+def test_binary_index_on_the_postings_walk(law):
+    """Bag-of-token index (no values): dyadic weights are exact in fixed point (nothing to prove, scores and ids bit-equal to the
+    oracle); arbitrary fp32 weights go through the refine step."""
+    n = 30_000
+    ip, ix, _ = oracle.synth_csr(3, 0, n, V, 86, synth.KIND_BOT)
+    q = oracle.synth_queries(8, 21, val_law=law)
+    idx = DeviceIndex.from_csr(ip, ix, None, V)
+    ref = _search(idx, q, 100, blocked_postings=0)
+    got = _search(idx, q, 100, blocked_postings=1)
+    assert got[2].last_path == 3 and got[2].aux_bytes > 0
+    assert (got[0] == ref[0]).all() and (got[1] == ref[1]).all()
+    forced = _search(idx, q, 100, blocked_postings=1, postings_force_fallback=1)
+    assert forced[2].last_fallbacks == q.shape[0]
+    assert (forced[0] == ref[0]).all() and (forced[1] == ref[1]).all()
+    o_ids, o_sc = oracle.csr_search(ip, ix, None, V, q, 100)
+    if law == synth.VAL_DYADIC:
+        assert (got[0] == o_ids).all() and (got[1] == o_sc).all()
+    else:
+        compare.compare_topk(o_ids, o_sc, got[0], got[1], rtol=RTOL)
+
+
+def test_large_k_leaves_the_filter():
+    """k + margin beyond the candidate buffers: 'search after' passes of the CSR scan (lossy records) or the fp64 walk."""
+    ip, ix, d = oracle.synth_csr(0, 0, 4000)
+    q = oracle.synth_queries(1, 5)
+    idx = DeviceIndex.from_csr(ip, ix, d, V)
+    ref = _search(idx, q, 1500, blocked_postings=0)
+    for quant in (-1, 0):
+        got = _search(idx, q, 1500, blocked_postings=1, postings_quant=quant)
+        assert (got[0] == ref[0]).all() and (got[1] == ref[1]).all()
+        assert got[2].queries_per_pass == 8
+
+
+def test_baseline_sized_index_on_one_gpu():
+    """BASELINE.json's index: 21 015 324 docs x 768 nnz, V = 29 523, fp32 -- the bench's configuration (lossy filter copy, 8 lanes
+    per list, few chunks) against the dense score matrix of the same index and, bit for bit, against the CSR scan."""
+    n = 21_015_324
+    idx = DeviceIndex.synthetic(0, 0, n, V, 768, 0, 0, nat.VS_F32)
+    q = oracle.synth_queries(1, 4)
+    ids, sc, info = _search(idx, q, 100, blocked_postings=-1)
+    assert info.last_path == 3 and info.last_fallbacks == 0 and info.aux_bytes > 60e9
+    ref_ids, ref_sc, info = _search(idx, q, 100, blocked_postings=0)
+    assert info.last_path == 1
+    assert (ids == ref_ids).all() and (sc == ref_sc).all()
+    allsc = idx.scores(q)
+    compare.check_topk_valid(allsc, ids, sc, rtol=RTOL)
+    del allsc
+    # the bench's batch shape on the same index: 1024 queries, spot-checked against the CSR scan on a slice
+    qb = oracle.synth_queries(2, 1024)
+    idx.set_option("blocked_postings", -1)
+    ids_b, sc_b = idx.search(qb, 100)
+    info = idx.info()
+    assert info.last_path == 3 and info.last_fallbacks == 0
+    ref_ids, ref_sc, _ = _search(idx, qb[500:516], 100, blocked_postings=0)
+    assert (np.asarray(ids_b)[500:516] == ref_ids).all() and (np.asarray(sc_b)[500:516] == ref_sc).all()

@@ -1135,7 +1135,10 @@ int vs_csr_search(vs_index* idx, const void* q, int q_dtype, int64_t ldq, int32_
         bool done = false;
         // k > kMaxKMq: "search after" passes of kMaxKMq ranks each (the k-th key of a pass is the next pass's exclusive
         // upper bound); large batches are cut so that the candidate scratch stays bounded
-        const int max_k = idx->bp_ready ? kBpMaxK : kMaxKMq;      // ranks one pass delivers (1024 on the postings path, 512 on the CSR scan)
+        // ranks one pass delivers: the whole k when the filter-and-refine search takes it (k + its margin within the candidate
+        // buffers), else 1024 per pass of the fp64 postings walk (exact records only), else 512 per pass of the CSR scan
+        const bool one_pass = idx->bp_ready && idx->bp_filter != 0 && k + std::max(28, k / 4) <= kBpMaxK;
+        const int max_k = one_pass ? k : (idx->bp_ready && !idx->bp_quant) ? kBpMaxK : kMaxKMq;
         const int mq_passes = ceil_div(k, max_k);
         const int kk_mq = std::min<int>(k, max_k);
         DevBuf mq_upper;
