@@ -35,6 +35,7 @@ BATCH = 1024
 K = 100
 INDEX_SEED, QUERY_SEED = 0, 1
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+LDS_ADD_U32_PEAK = 5.0e12    # ds_add_u32 at random addresses, all 256 CUs (profiles/r02_lds_scatter.txt)
 
 
 def parse():
@@ -177,6 +178,8 @@ def main():
     Profile.enable(False)
     scan_ms, scan_launches = Profile.read("csr_scan_topk")
     merge_ms, _ = Profile.read("merge_topk")
+    refine_ms, _ = Profile.read("refine_topk")
+    fb_ms, _ = Profile.read("exact_fallback")
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -194,19 +197,48 @@ def main():
         algo_bytes_per_launch = info.last_scan_bytes / launches_per_step
         avg_launch_s = scan_ms / 1e3 / max(1, scan_launches)
         achieved = algo_bytes_per_launch / avg_launch_s / 1e9
-        path = {0: "csr scan, one query per pass", 1: "csr scan, 8 queries per pass", 2: "blocked postings, 8 queries per tile"}[info.last_path]
+        path = {0: "csr scan, one query per pass", 1: "csr scan, 8 queries per pass", 2: "blocked postings, fp64 walk, 4 queries per tile",
+                3: "blocked postings: int32 fixed-point filter walk (8 queries per tile) + exact refine of k+28 candidates"}[info.last_path]
+        kernel = {0: "csr_scan_topk_wave", 1: "csr_scan_topk_mq", 2: "bp_walk_topk", 3: "bp_walk_topk"}[info.last_path]
         csr_equiv = -(-args.batch // qt) * info.bytes_per_pass / launches_per_step / avg_launch_s / 1e9
-        traffic = None
+        traffic, traffic_src = None, None
         pmc = os.path.join(REPO, "profiles", "pmc_summary.json")
         if os.path.exists(pmc):
             try:
                 # PMC counters cannot be read in-process: HBM bytes of this kernel come from the committed rocprofv3 --pmc
                 # FETCH_SIZE / WRITE_SIZE passes over the same 21 M-doc index and batch size (profiles/pmc_summary.json)
-                rec = json.load(open(pmc)).get("bp_scan_topk" if info.last_path == 2 else "csr_scan_topk_mq", {})
-                if rec.get("hbm_bytes_per_launch"):
-                    traffic = rec["hbm_bytes_per_launch"] * (args.batch / rec["queries_per_launch"]) * (n_local / rec["docs"])
+                rec = json.load(open(pmc)).get(kernel, {})
+                # only when the profile was taken on this kernel build and this configuration (it goes stale otherwise)
+                if rec.get("hbm_bytes_per_launch") and rec.get("queries_per_launch") == args.batch and rec.get("docs") == n_local \
+                        and rec.get("store", "fp32") == args.store and rec.get("scan", "auto") == args.scan:
+                    traffic = rec["hbm_bytes_per_launch"]
+                    traffic_src = f"profiles/pmc_summary.json ({rec.get('tag', '?')}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command)"
             except Exception:
                 traffic = None
+        index_pass_bytes = info.bytes_per_pass                     # one pass over the shard's CSR packets (SURVEY 8(d) bytes_pass)
+        hbm_frac = (traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS) if traffic else None
+        adds_per_s = info.last_walk_postings / launches_per_step / avg_launch_s if info.last_path >= 2 else None
+        if info.last_path >= 2:
+            bound = "hbm" if (hbm_frac or 0.0) > 0.5 else "on-chip: L2->L1 line fill per CU (outstanding-line limit) + LDS scatter-adds"
+        else:
+            bound = "hbm"
+        roofline = {
+            "bound": bound, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "kernel": kernel, "launches": scan_launches, "avg_launch_ms": avg_launch_s * 1e3,
+            "algorithmic_bytes_per_launch": algo_bytes_per_launch,
+            "hbm_frac": hbm_frac, "hbm_GBps": (traffic / avg_launch_s / 1e9) if traffic else None, "traffic_source": traffic_src,
+            "one_pass_lower_bound_ms": index_pass_bytes / (HBM_PEAK_GBS * 1e9) * 1e3,
+            "frac_of_one_pass_lower_bound": index_pass_bytes / (HBM_PEAK_GBS * 1e9) / avg_launch_s,
+            "walk_adds_per_s": adds_per_s, "lds_add_u32_peak_per_s": LDS_ADD_U32_PEAK,
+            "frac_of_lds_add_peak": (adds_per_s / LDS_ADD_U32_PEAK) if adds_per_s else None,
+            "csr_scan_equivalent_GBps": csr_equiv, "bytes_per_csr_pass": info.bytes_per_pass, "merge_ms_total": merge_ms,
+            "refine_ms_total": refine_ms, "exact_fallback_ms_total": fb_ms, "fallback_queries_last_step": info.last_fallbacks,
+            "note": "achieved/frac: ALGORITHMIC bytes of the dominant kernel (the records of the batch's (query, column) posting lists + "
+                    "their directory entries, vs_index_info.last_scan_bytes) / its measured time -- most of these bytes are served by "
+                    "L2 / Infinity Cache, so this is NOT HBM utilisation; hbm_frac: PMC-measured HBM traffic of the same launch / time / "
+                    "8 TB/s; one_pass_lower_bound: a single pass over the index at 8 TB/s (SURVEY 8(d), Qt = B); walk_adds: postings "
+                    "multiplied and scatter-added into LDS per second vs the measured ds_add_u32 rate (tools/microbench/lds_scatter.hip)",
+        }
         line = {
             "metric": "queries/sec over 21M-doc sparse index, k=100; recall@100 vs reference",
             "value": qps, "unit": "queries/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -216,17 +248,11 @@ def main():
                                    f"row-sharded over {world} GPU(s); {args.batch} queries/step ({NNZ_Q} nnz), k={args.k}",
                        "docs": args.docs, "docs_per_gpu": n_local, "batch": args.batch, "k": args.k, "queries_per_pass": qt,
                        "lanes_per_row": info.lanes_per_row, "index_bytes_per_gpu": info.device_bytes,
-                       "postings_copy_bytes_per_gpu": info.aux_bytes, "scan_path": path, "index_build_s": round(build_s, 2)},
+                       "postings_copy_bytes_per_gpu": info.aux_bytes, "scan_path": path, "dominant_kernel": kernel, "index_build_s": round(build_s, 2)},
             "exchange": {"backend": ("rccl (torch.distributed nccl)" if backend == "nccl" else backend) if world > 1 else None,
                          "world_size": dist.get_world_size() if world > 1 else 1,
                          "collective": "one all_gather_into_tensor of B*k packed (score, global id) int64 per rank + vs_merge_topk" if world > 1 else None},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "bp_scan_topk" if info.last_path == 2 else "csr_scan_topk_mq", "launches": scan_launches,
-                         "avg_launch_ms": avg_launch_s * 1e3, "algorithmic_bytes_per_launch": algo_bytes_per_launch,
-                         "csr_scan_equivalent_GBps": csr_equiv, "bytes_per_csr_pass": info.bytes_per_pass, "merge_ms_total": merge_ms,
-                         "note": "achieved = bytes the scan kernel has to read for the batch (vs_index_info.last_scan_bytes) / measured "
-                                 "kernel time; traffic = PMC-measured HBM bytes of the same launch (profiles/); csr_scan_equivalent = "
-                                 "what a whole-index CSR pass per 8 queries (SURVEY 8(d)) would have to stream in that time"},
+            "roofline": roofline,
         }
         if world == 1:
             line["parity"] = parity_check(local_rank)

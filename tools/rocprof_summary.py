@@ -39,6 +39,8 @@ def main():
     ap.add_argument("--queries", type=int, default=0, help="queries in the bench-sized scan launch: with --fetch and --write, updates "
                     "profiles/pmc_summary.json (read by bench.py for roofline.traffic)")
     ap.add_argument("--docs", type=int, default=21015324)
+    ap.add_argument("--store", default="fp32", help="bench.py --store of the profiled command")
+    ap.add_argument("--scan", default="auto", help="bench.py --scan of the profiled command")
     ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles"))
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
@@ -75,14 +77,14 @@ def main():
         # bench-sized launch (largest) of each scan kernel present -> profiles/pmc_summary.json, read by bench.py for roofline.traffic
         pmc_path = os.path.join(a.out, "pmc_summary.json")
         pmc = json.load(open(pmc_path)) if os.path.exists(pmc_path) else {}
-        pmc = {k: v for k, v in pmc.items() if k in ("bp_scan_topk", "csr_scan_topk_mq")}
-        for key in ("bp_scan_topk", "csr_scan_topk_mq"):
+        pmc = {k: v for k, v in pmc.items() if k in ("bp_walk_topk", "csr_scan_topk_mq")}
+        for key in ("bp_walk_topk", "csr_scan_topk_mq"):
             scan = lambda rows: max((r["KiB"] for r in rows if key in r["kernel"]), default=0.0)
             fetch, write = scan(summary["FETCH_SIZE"]), scan(summary["WRITE_SIZE"])
             if fetch <= 0:
                 continue
             pmc[key] = {"hbm_bytes_per_launch": (2 * fetch + write) * 1024, "fetch_KiB": fetch, "write_KiB": write,
-                        "queries_per_launch": a.queries, "docs": a.docs,
+                        "queries_per_launch": a.queries, "docs": a.docs, "store": a.store, "scan": a.scan, "tag": a.tag,
                         "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024  (gfx950: FETCH_SIZE counts 1/2 of a 16 B/lane coalesced stream)",
                         "source": f"profiles/{a.tag}_fetch_size.txt, profiles/{a.tag}_write_size.txt (rocprofv3 --pmc, separate passes, {a.note})"}
         with open(pmc_path, "w") as f:
