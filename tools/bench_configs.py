@@ -61,7 +61,10 @@ def sparse_like(name, n, nnz, kind, store, batch, q_law):
     return {"config": name, "metric": "queries/sec", "value": batch / dt, "ms_per_batch": dt * 1e3, "docs": n, "batch": batch, "k": K,
             "queries_per_pass": qt, "lanes_per_row": info.lanes_per_row, "index_bytes": info.device_bytes,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK, "unit": "GB/s", "frac": achieved / HBM_PEAK,
-                         "kernel": "bp_scan_topk" if info.last_path == 2 else "csr_scan_topk_mq", "avg_launch_ms": scan_ms / launches,
+                         "kernel": "bp_walk_topk" if info.last_path >= 2 else "csr_scan_topk_mq", "avg_launch_ms": scan_ms / launches,
+                         "scan_path": info.last_path, "fallback_queries": info.last_fallbacks, "postings_copy_bytes": info.aux_bytes,
+                         "walk_adds_per_s": (info.last_walk_postings / (scan_ms / 1e3 / launches)) if info.last_path >= 2 else None,
+                         "note": "achieved = algorithmic bytes of the scan kernel / its time (served largely by L2 / Infinity Cache: not HBM utilisation)",
                          "scan_bytes": info.last_scan_bytes, "csr_bytes_per_pass": info.bytes_per_pass, "csr_passes": passes},
             "check": "top-k valid vs csr_scan_scores on 4 queries" + (" (bit-exact, canonical ids)" if kind == 1 else " (1e-4)")}
 

@@ -37,7 +37,9 @@ namespace vs {
 
 enum : int { AM_F64 = 0, AM_FIX = 1 };
 
-constexpr int kBpRowsMax = 2048;      // most documents per block (the epilogue takes them 1024 = one per thread at a time)
+constexpr int kBpRowsMax = 2048;      // most documents per block of a valued index (8 query slots x int32 sums fill the LDS)
+constexpr int kBpRowsMaxBin = 2048;   // binary (bag-of-token) index: same blocks (measured: 4096-document blocks with 4 query slots -- longer lists,
+                                      // half the list visits -- lose to the doubled number of tiles: 11.8 k vs 14.1 k q/s on the Wiki21M shape)
 constexpr int kBpCap = 2048;          // candidate slots per (workgroup, query slot): K' kept + 1024 new per epilogue round
 constexpr int kBpMaxK = kBpCap - kScanThreads;
 constexpr int kBpEntCap = 7168;       // (query, column) entries per tile: 56 KB of LDS, and the 8192-slot entry sort must hold them
@@ -167,11 +169,11 @@ __global__ __launch_bounds__(kScanThreads) void bp_fill_kernel(const uint32_t* p
         }
         if constexpr (VM == VM_BIN) {
             // a binary posting has no value to zero: the pad postings of a list's last record point at the scratch row behind
-            // the accumulators (document id kBpRowsMax), whatever they add is never read
+            // the accumulators (document id = the block capacity), whatever they add is never read
             __syncthreads();
             for (int i = tid; i < n_cols; i += kScanThreads) {
                 const uint32_t lim = d[i + 1] * 8u;
-                for (uint32_t pos = cur[i]; pos < lim; ++pos) reinterpret_cast<uint16_t*>(brec + (size_t)(pos >> 3) * RS)[pos & 7u] = (uint16_t)kBpRowsMax;
+                for (uint32_t pos = cur[i]; pos < lim; ++pos) reinterpret_cast<uint16_t*>(brec + (size_t)(pos >> 3) * RS)[pos & 7u] = (uint16_t)kBpRowsMaxBin;
             }
         }
     }
@@ -197,7 +199,7 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_kernel(const uint32_t* c
 
 // ---- walk ---------------------------------------------------------------------------------------------------------
 struct BpArgs {
-    int32_t rows;             // documents per block (<= kBpRowsMax)
+    int32_t rows;             // documents per block (<= the kernel's RMAX)
     const uint32_t* dir;      // [n_blocks, n_cols + 1] record offsets inside the block
     const unsigned long long* base;   // [n_blocks + 1] first record of a block
     const char* rec;          // records
@@ -219,12 +221,12 @@ struct BpArgs {
     const float* qscale;      // AM_FIX: [B] per-query power-of-two scale of the fixed-point sums
 };
 
-// accumulators [kBpRowsMax + 1][QT + 1]: the extra row absorbs the pad postings of a binary list (document id kBpRowsMax)
-template <int QT, int AM>
-__host__ __device__ constexpr size_t bp_acc_bytes() { return (((size_t)(kBpRowsMax + 1) * (QT + 1) * (AM == AM_F64 ? 8 : 4)) + 15) & ~(size_t)15; }
-template <int QT, int AM>
+// accumulators [RMAX + 1][QT + 1]: the extra row absorbs the pad postings of a binary list (document id RMAX)
+template <int QT, int AM, int RMAX>
+__host__ __device__ constexpr size_t bp_acc_bytes() { return (((size_t)(RMAX + 1) * (QT + 1) * (AM == AM_F64 ? 8 : 4)) + 15) & ~(size_t)15; }
+template <int QT, int AM, int RMAX>
 __host__ __device__ inline size_t bp_lds_bytes(int ent_cap) {
-    return bp_acc_bytes<QT, AM>() + (size_t)kBpCap * 8 + (size_t)QT * 16 + 64 * 4 + (size_t)ent_cap * 8;
+    return bp_acc_bytes<QT, AM, RMAX>() + (size_t)kBpCap * 8 + (size_t)QT * 16 + 64 * 4 + (size_t)ent_cap * 8;
 }
 
 __device__ __forceinline__ uint64_t make_key_fix(int32_t a, uint32_t row) {
@@ -286,10 +288,12 @@ __device__ __forceinline__ void lds_add(uint32_t addr, double v) {
     __hip_atomic_fetch_add(reinterpret_cast<__attribute__((address_space(3))) double*>(addr), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// LG = lanes per posting list (4 for the long lists of a valued index, 1 for the short lists of the bag-of-token index)
-template <int VM, int QT, int AM, int LG>
+// LG = lanes per posting list (8 for the long lists of a valued index, 1 for the short lists of the bag-of-token index),
+// RMAX = block capacity in documents
+template <int VM, int QT, int AM, int LG, int RMAX>
 __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
-    static_assert(bp_acc_bytes<QT, AM>() >= kBpSortBytes, "the accumulator area holds the 8192-slot entry sort");
+    static_assert(bp_acc_bytes<QT, AM, RMAX>() >= kBpSortBytes, "the accumulator area holds the 8192-slot entry sort");
+    static_assert(VM != VM_BIN || RMAX == kBpRowsMaxBin, "pad postings of a binary list carry document id kBpRowsMaxBin");
     static_assert(kBpNB % LG == 0 || LG % kBpNB == 0, "lane l of a group owns the directory pairs of lists l, l + LG, ... of a slot");
     using acc_t = typename std::conditional<AM == AM_F64, double, int32_t>::type;
     constexpr int PITCH = QT + 1;                 // accumulator row pitch in elements: a document's row starts an odd number of words
@@ -299,8 +303,8 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
     constexpr int NB = kBpNB;
     constexpr int OWN = NB >= LG ? NB / LG : 1;   // directory pairs a lane owns per slot (lanes >= NB of a wide group own none)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    acc_t* acc = reinterpret_cast<acc_t*>(smem);                                            // [kBpRowsMax][PITCH]
-    uint64_t* sortbuf = reinterpret_cast<uint64_t*>(smem + bp_acc_bytes<QT, AM>());         // [kBpCap]
+    acc_t* acc = reinterpret_cast<acc_t*>(smem);                                            // [RMAX + 1][PITCH]
+    uint64_t* sortbuf = reinterpret_cast<uint64_t*>(smem + bp_acc_bytes<QT, AM, RMAX>());   // [kBpCap]
     unsigned long long* tau = reinterpret_cast<unsigned long long*>(sortbuf + kBpCap);      // [QT]
     unsigned long long* upper_sh = tau + QT;                                                // [QT] exclusive upper bounds ("search after")
     int* scratch = reinterpret_cast<int*>(upper_sh + QT);                                   // [48]
@@ -348,7 +352,7 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
             }
             __syncthreads();
         }
-        for (int i = tid; i < kBpRowsMax * PITCH; i += kScanThreads) acc[i] = (acc_t)0;
+        for (int i = tid; i < RMAX * PITCH; i += kScanThreads) acc[i] = (acc_t)0;
         if (tid < QT) { tau[tid] = 0ull; ccnt[tid] = 0u; }
         if (tid < QT) upper_sh[tid] = (a.upper && tid < nq) ? a.upper[q0 + tid] : ~0ull;
         __syncthreads();
@@ -445,7 +449,7 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
                                 for (int t = 0; t < 8; ++t) {
                                     const uint32_t off = (t & 1) ? acc_off_hi(dw[t >> 1], PITCHB, so) : acc_off_lo(dw[t >> 1], PITCHB, so);
                                     if constexpr (VM == VM_BIN) {
-                                        // (pad postings of a binary list carry document id kBpRowsMax: the scratch row behind the accumulators)
+                                        // (pad postings of a binary list carry document id RMAX: the scratch row behind the accumulators)
                                         if constexpr (AM == AM_FIX) lds_add(off, wi);
                                         else lds_add(off, wd);
                                     } else {
@@ -506,5 +510,6 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
         }
     }
 }
+
 
 }  // namespace vs

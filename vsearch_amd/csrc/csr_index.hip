@@ -706,6 +706,7 @@ int mq_vals_cap(const vs_index* idx) {
 
 // ---- blocked postings (bp_walk.h): second, column-grouped copy of the index for sparse queries ---------------------
 constexpr int kBpExactQT = 4;     // queries per tile of the fp64 walk (its accumulators are twice as wide as the filter walk's)
+constexpr int kBpBinQT = 8;       // queries per tile of the binary index's filter walk
 
 bool bp_wanted(const vs_index* idx) {
     if (idx->bp_pref == 0 || idx->n_rows <= 0 || idx->n_packets <= 0) return false;
@@ -727,14 +728,23 @@ void bp_release(vs_index* idx) {
     idx->bp_ready = false;
 }
 
+// valued index: QT queries per tile, blocks of <= 2048 documents (exact fp64 walk: QT = 4, filter walk: QT = 8);
+// binary index: filter walk only, one lane per (short) list
 template <int QT, int AM>
 int launch_bp_walk(const vs_index* idx, const BpArgs& a, int grid, int ent_cap, hipStream_t s) {
-    const size_t lds = bp_lds_bytes<QT, AM>(ent_cap);
-    if (lds > 160 * 1024) return fail(VS_EUNSUPPORTED, "postings walk needs %zu B of LDS", lds);
     const int vm = bp_record_vm(idx);
-    void (*kern)(BpArgs) = vm == VM_F32 ? (idx->bp_lanes == 8 ? bp_walk_topk<VM_F32, QT, AM, 8> : bp_walk_topk<VM_F32, QT, AM, 4>)
-                         : vm == VM_F16 ? (idx->bp_lanes == 8 ? bp_walk_topk<VM_F16, QT, AM, 8> : bp_walk_topk<VM_F16, QT, AM, 4>)
-                                        : bp_walk_topk<VM_BIN, QT, AM, 1>;
+    size_t lds = bp_lds_bytes<QT, AM, kBpRowsMax>(ent_cap);
+    void (*kern)(BpArgs) = nullptr;
+    if (vm == VM_BIN) {
+        if (AM != AM_FIX) return fail(VS_EUNSUPPORTED, "binary postings serve the filter walk only");
+        kern = bp_walk_topk<VM_BIN, kBpBinQT, AM_FIX, 1, kBpRowsMaxBin>;
+        lds = bp_lds_bytes<kBpBinQT, AM_FIX, kBpRowsMaxBin>(ent_cap);
+    } else if (vm == VM_F32) {
+        kern = idx->bp_lanes == 8 ? bp_walk_topk<VM_F32, QT, AM, 8, kBpRowsMax> : bp_walk_topk<VM_F32, QT, AM, 4, kBpRowsMax>;
+    } else {
+        kern = idx->bp_lanes == 8 ? bp_walk_topk<VM_F16, QT, AM, 8, kBpRowsMax> : bp_walk_topk<VM_F16, QT, AM, 4, kBpRowsMax>;
+    }
+    if (lds > 160 * 1024) return fail(VS_EUNSUPPORTED, "postings walk needs %zu B of LDS", lds);
     VS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kScanThreads), lds, s, a);
     VS_HIP(hipGetLastError());
@@ -746,7 +756,8 @@ int bp_build(vs_index* idx, hipStream_t s) {
     bp_release(idx);
     // documents per block: as many as the filter walk's accumulators hold -- the longer a column's list in a block, the more of
     // every 128-byte line the walk fetches is used (768-nnz documents, V = 29 523: 53 postings = 6.7 records per list)
-    idx->bp_rows = idx->bp_rows_pref > 0 ? idx->bp_rows_pref : kBpRowsMax;
+    idx->bp_rows = idx->store_dtype == VS_NONE ? (idx->bp_rows_pref > 0 ? idx->bp_rows_pref : kBpRowsMaxBin)
+                                               : (idx->bp_rows_pref > 0 ? std::min(idx->bp_rows_pref, kBpRowsMax) : kBpRowsMax);
     const int64_t n_blocks = ceil_div64(idx->n_rows, idx->bp_rows);
     const int V = idx->n_cols;
     const int RS0 = bp_rec_bytes(idx->store_dtype == VS_F32 ? VM_F16 : idx->store_dtype == VS_F16 ? VM_F16 : VM_BIN);   // smallest record this index can get
@@ -846,9 +857,10 @@ int mq_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64_t id_o
     // "postings_filter" = 0, "search after" passes, k beyond the candidate buffers) every tile takes the fp64 walk.
     const int kp = k + std::max(28, k / 4);
     const bool filter = idx->bp_ready && idx->bp_filter != 0 && col0 == 0 && !upper && kp <= kBpMaxK && (idx->store_dtype == VS_NONE || idx->bp_vmax.p);
-    const bool use_bp = idx->bp_ready && (filter || !idx->bp_quant);          // lossy records serve the filter only
-    const int qt_plan = use_bp && !filter ? kBpExactQT : kQT;
-    const int bp_cap = filter ? kBpEntCap : kBpEntCap / 2;
+    const bool filter_only = idx->bp_quant || idx->store_dtype == VS_NONE;    // lossy / binary records serve the filter only
+    const bool use_bp = idx->bp_ready && (filter || !filter_only);
+    const int qt_plan = !use_bp ? kQT : (idx->store_dtype == VS_NONE ? kBpBinQT : (filter ? kQT : kBpExactQT));
+    const int bp_cap = qt_plan == kQT ? kBpEntCap : kBpEntCap / 2;
     const int vals_cap = use_bp ? std::min(mq_vals_cap(idx), bp_cap) : mq_vals_cap(idx);     // entries (non-zeros) one tile may hold
     if (vals_cap <= 0 || k > (use_bp ? kBpMaxK : kMaxKMq)) return VS_OK;     // (callers split larger k into passes)
     const int V = idx->n_cols;
@@ -911,6 +923,7 @@ int mq_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64_t id_o
         const int grid = (int)std::min<int64_t>(items, idx->cu_count);
         const int nchunk_fb = (int)std::min<int64_t>(n_blocks, 64);
         VS_TRY(idx->ws_mq_cand.reserve((size_t)idx->cu_count * kQT * kBpCap * 8));
+        if (idx->bp_rows > (idx->store_dtype == VS_NONE ? kBpRowsMaxBin : kBpRowsMax)) return fail(VS_EINVAL, "postings_rows beyond the walk's block capacity");
         VS_TRY(idx->ws_cand.reserve(std::max((size_t)B * nchunk * (filter ? kp : k), filter ? (size_t)B * nchunk_fb * k : (size_t)0) * 8));
         const int RS = bp_rec_bytes(bp_record_vm(idx));
         BpArgs a{};
@@ -997,8 +1010,8 @@ int mq_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64_t id_o
             a.ent_cap = std::min(vals_cap, kBpEntCap / 2);
             {
                 ProfScope prof("exact_fallback", s);
-                if (idx->bp_quant) {
-                    // the records are lossy: the unproven queries take a one-query-per-pass scan of the CSR packets (fp64 row sums)
+                if (filter_only) {
+                    // the records are lossy (or binary): the unproven queries take a one-query-per-pass scan of the CSR packets (fp64 row sums)
                     ScanArgs sa{};
                     sa.pk_ptr = idx->pk_ptr.as<uint32_t>();
                     sa.cols = idx->cols.as<uint4>();
@@ -1012,8 +1025,9 @@ int mq_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64_t id_o
                     sa.rows_per_chunk = ceil_div64(idx->n_rows, nchunk_fb);
                     sa.cand = a.cand;
                     const size_t slds = scan_lds_bytes(V);
-                    VS_HIP(hipFuncSetAttribute((const void*)exact_scan_topk_kernel<VM_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds));
-                    hipLaunchKernelGGL(exact_scan_topk_kernel<VM_F32>, dim3(idx->cu_count), dim3(kScanThreads), slds, s, sa, (const int2*)fb_tiles, (const int32_t*)fb_n);
+                    void (*ek)(ScanArgs, const int2*, const int32_t*) = idx->store_dtype == VS_NONE ? exact_scan_topk_kernel<VM_BIN> : exact_scan_topk_kernel<VM_F32>;
+                    VS_HIP(hipFuncSetAttribute((const void*)ek, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds));
+                    hipLaunchKernelGGL(ek, dim3(idx->cu_count), dim3(kScanThreads), slds, s, sa, (const int2*)fb_tiles, (const int32_t*)fb_n);
                     VS_HIP(hipGetLastError());
                 } else {
                     VS_TRY((launch_bp_walk<kBpExactQT, AM_F64>(idx, a, idx->cu_count, a.ent_cap, s)));
@@ -1138,7 +1152,7 @@ int vs_csr_search(vs_index* idx, const void* q, int q_dtype, int64_t ldq, int32_
         // ranks one pass delivers: the whole k when the filter-and-refine search takes it (k + its margin within the candidate
         // buffers), else 1024 per pass of the fp64 postings walk (exact records only), else 512 per pass of the CSR scan
         const bool one_pass = idx->bp_ready && idx->bp_filter != 0 && k + std::max(28, k / 4) <= kBpMaxK;
-        const int max_k = one_pass ? k : (idx->bp_ready && !idx->bp_quant) ? kBpMaxK : kMaxKMq;
+        const int max_k = one_pass ? k : (idx->bp_ready && !idx->bp_quant && idx->store_dtype != VS_NONE) ? kBpMaxK : kMaxKMq;
         const int mq_passes = ceil_div(k, max_k);
         const int kk_mq = std::min<int>(k, max_k);
         DevBuf mq_upper;
