@@ -15,9 +15,18 @@
  *   - Data pointers may be host or device (HIP) pointers; the library detects which
  *     (hipPointerGetAttributes).  Device pointers must belong to the index's device.
  *   - `stream` is a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream).  NULL = the
- *     device's null stream; the call then returns after the work has completed.  With a non-NULL
- *     stream the call is asynchronous when every in/out pointer is a device pointer.
- *   - One search at a time per vs_index handle (the handle owns scratch memory).
+ *     device's null stream AND a blocking call: it returns after the work has completed.  With a
+ *     non-NULL stream (hipStreamLegacy = (hipStream_t)1 names the null stream without blocking) and
+ *     device pointers for every input and output, vs_index_search on the blocked-postings filter
+ *     path (vs_index_info_t.last_path == 3: the default for large sparse / bag-of-token indexes)
+ *     only enqueues kernels: tile plan, candidate proof and the exact pass for unproven queries are
+ *     decided on the device.  The other paths (8-query CSR scan, fp64 walk, one-query scan)
+ *     synchronise once per call to read the tile plan; host pointers are copied and block.
+ *     vs_index_info() reads device-side statistics of the last search and therefore synchronises.
+ *   - ONE search at a time per vs_index handle, from ONE host thread, on ONE stream at a time: the
+ *     handle and a few per-device buffers (vs_merge_topk, the sparsify entry points) own grow-only
+ *     scratch memory that consecutive calls re-use in stream order.  Calls on a different stream
+ *     must be ordered after the previous call's work by the caller (event / synchronise).
  *   - Top-k order is canonical: score descending, then id ascending (torch.topk leaves ties
  *     unspecified, index.py:92).  fp32 accumulation order differs from MKL/cuSPARSE: scores agree to
  *     ~1e-6 relative; on binary index x dyadic query weights they are bit-exact.

@@ -23,9 +23,10 @@ for B in (1, 2, 4, 8, 16, 32, 64, 128):
     t = time.perf_counter()
     for _ in range(reps):
         ids, sc = idx.search(q, 100)
+    t_host = (time.perf_counter() - t) / reps                 # what the host spends in the call (asynchronous when nothing forces a sync)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t) / reps
     Profile.enable(True); Profile.reset()
     idx.search(q, 100); torch.cuda.synchronize()
     ms, n = Profile.read("csr_scan_topk"); Profile.enable(False)
-    print(f"B={B:4d}: {dt*1e3:8.3f} ms/call  {B/dt:9.1f} q/s   scan kernel {ms:.3f} ms  qt={idx.info().queries_per_pass}", flush=True)
+    print(f"B={B:4d}: {dt*1e3:8.3f} ms/call (host returns after {t_host*1e3:.3f} ms)  {B/dt:9.1f} q/s   scan kernel {ms:.3f} ms  path={idx.info().last_path}", flush=True)

@@ -99,7 +99,7 @@ struct RefineArgs {
     int64_t* out_ids;         // [B, out_ld]
     float* out_scores;
     int64_t out_ld;
-    uint32_t* flags;          // [B]: 1 = the top k could not be proven from K' candidates -> exact walk
+    uint32_t* flags;          // [B] in: 2 = the query entered no tile; out: 1 = the top k could not be proven from K' candidates
 };
 
 template <int VM>
@@ -110,6 +110,7 @@ __global__ __launch_bounds__(kScanThreads) void refine_topk_kernel(RefineArgs a)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int K = a.k, KP = a.kp;
     for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+        if (a.flags[b] == 2u) continue;                             // too dense for a tile: no candidates exist, the exact pass takes it
         merge_select(a.cand + (size_t)b * a.n_cand, a.n_cand, a.run_len, KP, nullptr, buf, &cnt_sh, tid);
         __syncthreads();
         const uint64_t cut_key = buf[KP - 1];                         // 0: fewer than K' documents exist -> every document is a candidate
@@ -153,7 +154,43 @@ __global__ __launch_bounds__(kScanThreads) void refine_topk_kernel(RefineArgs a)
     }
 }
 
-// flagged queries -> one-query tiles for the exact walk (and the query list of the merge behind it)
+// Device-side tile plan of the filter search: row pointers of the sparse batch + greedy tiling (<= qt queries and <= vals_cap
+// entries per tile, consecutive queries).  A query denser than vals_cap enters no tile: it gets no entries (qptr does not advance)
+// and flag 2 -- it takes the exact one-query scan.  plan[0] = tiles, plan[1] = densest query, plan[2] = entries in tiles.
+template <int UNUSED>
+__global__ void bp_plan_kernel(const int64_t* counts, int32_t B, int32_t qt, int32_t vals_cap, int64_t* qptr, int2* tiles, int64_t* plan, uint32_t* flags) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    int64_t acc = 0, mx = 0;
+    qptr[0] = 0;
+    int nt = 0, start = -1, cnt = 0;
+    int64_t nz = 0;
+    for (int b = 0; b < B; ++b) {
+        const int64_t c = counts[b];
+        mx = c > mx ? c : mx;
+        const bool dense = c > vals_cap;
+        flags[b] = dense ? 2u : 0u;
+        if (!dense && cnt > 0 && (cnt == qt || nz + c > vals_cap)) {          // the open tile is full: close it
+            tiles[nt++] = make_int2(start, cnt);
+            cnt = 0;
+        }
+        if (dense) {
+            if (cnt > 0) { tiles[nt++] = make_int2(start, cnt); cnt = 0; }     // tiles are runs of consecutive queries
+        } else {
+            if (cnt == 0) { start = b; nz = 0; }
+            ++cnt;
+            nz += c;
+            acc += c;
+        }
+        qptr[b + 1] = acc;
+    }
+    if (cnt > 0) tiles[nt++] = make_int2(start, cnt);
+    plan[0] = nt;
+    plan[1] = mx;
+    plan[2] = acc;
+    plan[3] = 0;
+}
+
+// flagged queries -> one-query tiles for the exact pass (and the query list of the merge behind it)
 template <int UNUSED>
 __global__ __launch_bounds__(kScanThreads) void fb_plan_kernel(const uint32_t* flags, int32_t B, int2* tiles, int32_t* n_tiles) {
     __shared__ int cnt;

@@ -218,6 +218,9 @@ struct vs_index {
     int64_t last_walk_postings = 0;      // postings (multiply-adds) the most recent search's walk visited
     const uint32_t* last_flags = nullptr; // device [last_flags_n]: queries of the most recent filter search that took the exact walk
     int last_flags_n = 0;
+    const int64_t* last_plan_dev = nullptr;   // device plan of the most recent filter search ([2] entries, [4] records, [5] postings walked)
+    int last_plan_rs = 0;
+    int64_t last_plan_blocks = 0;
     int bp_rows = 2048;  // documents per block of the copy (picked at build time)
     bool bp_ready = false, bp_tried = false;
     int64_t last_scan_bytes = 0;   // bytes the scan kernels of the most recent search had to read (algorithmic, per path)

@@ -462,6 +462,14 @@ extern "C" int vs_index_info(const vs_index* idx, vs_index_info_t* o) {
     o->last_scan_bytes = idx->last_scan_bytes;
     o->last_path = idx->last_path;
     o->last_walk_postings = idx->last_walk_postings;
+    if (idx->last_path == 3 && idx->last_plan_dev) {               // the filter search keeps its plan on the device: read it now
+        int64_t hp[6] = {0, 0, 0, 0, 0, 0};
+        VS_HIP(hipSetDevice(idx->device));
+        VS_HIP(hipDeviceSynchronize());
+        VS_HIP(hipMemcpy(hp, idx->last_plan_dev, sizeof(hp), hipMemcpyDeviceToHost));
+        o->last_scan_bytes = hp[4] * idx->last_plan_rs + hp[2] * idx->last_plan_blocks * 8;
+        o->last_walk_postings = hp[5];
+    }
     if (idx->last_path == 3 && idx->last_flags && idx->last_flags_n > 0) {
         std::vector<uint32_t> h((size_t)idx->last_flags_n);
         VS_HIP(hipSetDevice(idx->device));
@@ -845,6 +853,193 @@ int bp_build(vs_index* idx, hipStream_t s) {
     return VS_OK;
 }
 
+// chunks of the postings walk for `n_tiles` query tiles (see bp_filter_search)
+int bp_choose_chunks(const vs_index* idx, int n_tiles, int64_t n_blocks, int plan_nchunk) {
+    int nchunk = (int)std::min<int64_t>(choose_chunks(idx, n_tiles, plan_nchunk), n_blocks);
+    // Big index, enough tiles: as FEW chunks as give every CU two work items.  Every tile sweeps its chunk's blocks in the same
+    // order at the same pace, so with few chunks all tiles are within a few blocks of each other and each block is fetched from
+    // HBM once for all of them (Infinity Cache): 21 M docs, 1024 queries: 4 chunks 300 ms, 8: 333, 16: 399, 64: 561, 2 (one item
+    // per CU, no second round to even out): 419.
+    if (idx->n_rows >= (2 << 20) && (int64_t)n_tiles * 4 >= idx->cu_count) {
+        int best = 1;
+        double best_eff = 0.0;
+        const int c0 = (int)std::max<int64_t>(1, ceil_div64(2 * (int64_t)idx->cu_count, n_tiles));
+        for (int c = c0; c <= c0 + 3; ++c) {
+            const int64_t it = (int64_t)n_tiles * c;
+            const double eff = (double)it / (double)(ceil_div64(it, idx->cu_count) * idx->cu_count);
+            if (eff > best_eff + 1e-9) { best_eff = eff; best = c; }
+            if (eff >= 0.95) break;
+        }
+        nchunk = (int)std::min<int64_t>(best, n_blocks);
+    }
+    if (idx->bp_chunks > 0) nchunk = (int)std::min<int64_t>(idx->bp_chunks, n_blocks);
+    return std::max(1, nchunk);
+}
+
+// the filter-and-refine search takes this call: one pass, k + margin within the candidate buffers
+bool bp_filter_ok(const vs_index* idx, int k, int col0, const uint64_t* upper) {
+    return idx->bp_ready && idx->bp_filter != 0 && col0 == 0 && !upper && k + std::max(28, k / 4) <= kBpMaxK &&
+           (idx->store_dtype == VS_NONE || idx->bp_vmax.p) && mq_vals_cap(idx) > 0;
+}
+
+// Filter and refine (bp_walk.h, bp_refine.h), WITHOUT a host synchronisation: the query tiles are planned on the device and the
+// kernels read the tile count there; scratch is sized from upper bounds (B queries x the entry capacity of a tile); queries too
+// dense for a tile, and queries whose top k the refine step cannot prove, are collected on the device and take the exact
+// one-query scan, launched unconditionally (it returns at once when the list is empty).
+int bp_filter_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64_t id_offset, int64_t* d_ids, float* d_scores, const ScanPlan& plan,
+                     hipStream_t s, bool* done, int32_t out_ld) {
+    const int V = idx->n_cols;
+    const int kp = k + std::max(28, k / 4);
+    const int qt = idx->store_dtype == VS_NONE ? kBpBinQT : kQT;
+    const int vals_cap = std::min(mq_vals_cap(idx), kBpEntCap);
+    const int64_t qcap = (int64_t)B * vals_cap;                               // bound of the batch's (query, column) entries that enter a tile
+    const int64_t n_blocks = ceil_div64(idx->n_rows, idx->bp_rows);
+    if (idx->bp_rows > (idx->store_dtype == VS_NONE ? kBpRowsMaxBin : kBpRowsMax)) return fail(VS_EINVAL, "postings_rows beyond the walk's block capacity");
+    // scratch: per-query metadata (counts, qptr, plan, tiles, flags, scale, slack, weight sums), column frequencies, the sparse batch
+    const size_t off_counts = 0, off_qptr = off_counts + (size_t)B * 8, off_plan = off_qptr + (size_t)(B + 1) * 8, off_tiles = off_plan + 64,
+                 off_fb = off_tiles + (size_t)B * 8, off_scale = off_fb + (size_t)B * 8, off_slack = off_scale + (size_t)B * 4,
+                 off_wsum = off_slack + (size_t)B * 4, off_flags = off_wsum + (size_t)B * 4, off_nfb = off_flags + (size_t)B * 4,
+                 off_freq = (off_nfb + 64 + 15) & ~(size_t)15;
+    VS_TRY(idx->ws_mq_meta.reserve(off_freq + (size_t)(V + 4) * 4 + 8));
+    char* meta = idx->ws_mq_meta.as<char>();
+    int64_t* counts = (int64_t*)(meta + off_counts);
+    int64_t* qptr = (int64_t*)(meta + off_qptr);
+    int64_t* dplan = (int64_t*)(meta + off_plan);
+    int2* tiles = (int2*)(meta + off_tiles);
+    int2* fb_tiles = (int2*)(meta + off_fb);
+    float* qscale = (float*)(meta + off_scale);
+    int32_t* qslack = (int32_t*)(meta + off_slack);
+    float* qwsum = (float*)(meta + off_wsum);
+    uint32_t* flags = (uint32_t*)(meta + off_flags);
+    int32_t* fb_n = (int32_t*)(meta + off_nfb);
+    uint32_t* colfreq = (uint32_t*)(meta + off_freq);
+    VS_TRY(idx->ws_mq_q.reserve(std::max<size_t>((size_t)qcap * 8, 16)));
+    int32_t* qcols = idx->ws_mq_q.as<int32_t>();
+    float* qvals = reinterpret_cast<float*>(qcols + qcap);
+    // 1. sparsify the batch and plan the tiles, all on the device
+    VS_HIP(hipMemsetAsync(colfreq, 0, (size_t)(V + 4) * 4 + 8, s));
+    hipLaunchKernelGGL(count_nz_kernel<0>, dim3(std::min(B, 2048)), dim3(kSpThreads), 0, s, dq, (int64_t)V, B, V, counts);
+    hipLaunchKernelGGL(mq_colfreq_kernel<0>, dim3(std::min(B, 2048)), dim3(kSpThreads), 0, s, dq, (int64_t)V, B, V, colfreq);
+    hipLaunchKernelGGL(bp_plan_kernel<0>, dim3(1), dim3(64), 0, s, counts, B, qt, vals_cap, qptr, tiles, dplan, flags);
+    hipLaunchKernelGGL(fill_csr_kernel<0>, dim3(std::min(B, 2048)), dim3(kSpThreads), 0, s, dq, (int64_t)V, B, V, qptr, qcols, qvals, qcap);
+    if (idx->bp_df.p)
+        hipLaunchKernelGGL(bp_walk_kernel<0>, dim3(1), dim3(kScanThreads), 0, s, colfreq, idx->bp_df.as<unsigned long long>(),
+                           idx->bp_df.as<unsigned long long>() + V, V, dplan + 4);
+    hipLaunchKernelGGL(bp_qscale_kernel<0>, dim3((unsigned)ceil_div(B, 4)), dim3(256), 0, s, qptr, qvals, B, idx->bp_vmax.as<uint32_t>(),
+                       idx->store_dtype == VS_NONE ? 1 : 0, idx->bp_quant ? 1 : 0, qscale, qslack, qwsum);
+    VS_HIP(hipGetLastError());
+    VS_STAGE("sparsify", s);
+    // 2. the walk.  Work items = (tile, chunk); the tile count lives on the device, the chunks follow its lower bound ceil(B / qt)
+    const int n_tiles_est = ceil_div(B, qt);
+    const int nchunk = bp_choose_chunks(idx, n_tiles_est, n_blocks, plan.nchunk);
+    const int nchunk_fb = (int)std::min<int64_t>(n_blocks, 64);
+    const int grid = (int)std::min<int64_t>((int64_t)B * nchunk, idx->cu_count);
+    VS_TRY(idx->ws_mq_cand.reserve((size_t)idx->cu_count * kQT * kBpCap * 8));
+    VS_TRY(idx->ws_cand.reserve(std::max((size_t)B * nchunk * kp, (size_t)B * nchunk_fb * k) * 8));
+    BpArgs a{};
+    a.rows = idx->bp_rows;
+    a.dir = idx->bp_dir.as<uint32_t>();
+    a.base = idx->bp_base.as<unsigned long long>();
+    a.rec = idx->bp_rec.as<char>();
+    a.n_rows = idx->n_rows;
+    a.n_cols = V;
+    a.k = kp;
+    a.nchunk = nchunk;
+    a.blocks_per_chunk = ceil_div64(n_blocks, nchunk);
+    a.qptr = qptr;
+    a.qcols = qcols;
+    a.qvals = qvals;
+    a.tiles = tiles;
+    a.n_tiles = 0;
+    a.n_tiles_dev = reinterpret_cast<const int32_t*>(dplan);                  // plan[0] (little endian: the low word of the int64)
+    a.ent_cap = vals_cap;
+    a.cand = idx->ws_cand.as<uint64_t>();
+    a.gcand = idx->ws_mq_cand.as<uint64_t>();
+    a.qscale = qscale;
+    idx->last_path = 3;
+    idx->last_plan_dev = dplan;
+    idx->last_plan_rs = bp_rec_bytes(bp_record_vm(idx));
+    idx->last_plan_blocks = n_blocks;
+    {
+        ProfScope prof("csr_scan_topk", s);
+        VS_TRY((launch_bp_walk<kQT, AM_FIX>(idx, a, grid, vals_cap, s)));
+    }
+    VS_STAGE("filter walk", s);
+    // 3. refine: exact scores of the K' candidates, the proof, the flags
+    RefineArgs r{};
+    r.cand = a.cand;
+    r.n_cand = (int64_t)nchunk * kp;
+    r.run_len = kp;
+    r.B = B; r.k = k; r.kp = kp;
+    r.pk_ptr = idx->pk_ptr.as<uint32_t>();
+    r.cols = idx->cols.as<uint4>();
+    r.vals = idx->vals.p;
+    r.n_cols = V;
+    r.n_rows = idx->n_rows;
+    r.q = dq;
+    r.qscale = qscale;
+    r.qslack = qslack;
+    r.qwsum = qwsum;
+    r.quant = idx->bp_quant ? 1 : 0;
+    r.force_flag = idx->bp_force_fb ? 1 : 0;
+    r.id_offset = id_offset;
+    r.out_ids = d_ids;
+    r.out_scores = d_scores;
+    r.out_ld = out_ld;
+    r.flags = flags;
+    {
+        ProfScope prof("refine_topk", s);
+        const int rgrid = std::min(B, idx->cu_count * 2);
+        if (idx->store_dtype == VS_F32) hipLaunchKernelGGL(refine_topk_kernel<VM_F32>, dim3(rgrid), dim3(kScanThreads), 0, s, r);
+        else if (idx->store_dtype == VS_F16) hipLaunchKernelGGL(refine_topk_kernel<VM_F16>, dim3(rgrid), dim3(kScanThreads), 0, s, r);
+        else hipLaunchKernelGGL(refine_topk_kernel<VM_BIN>, dim3(rgrid), dim3(kScanThreads), 0, s, r);
+        VS_HIP(hipGetLastError());
+    }
+    VS_STAGE("refine", s);
+    // 4. flagged queries (too dense for a tile, or unproven; normally none): exact one-query scan of the CSR packets + merge
+    {
+        ProfScope prof("exact_fallback", s);
+        hipLaunchKernelGGL(fb_plan_kernel<0>, dim3(1), dim3(kScanThreads), 0, s, flags, B, fb_tiles, fb_n);
+        ScanArgs sa{};
+        sa.pk_ptr = idx->pk_ptr.as<uint32_t>();
+        sa.cols = idx->cols.as<uint4>();
+        sa.vals = idx->vals.p;
+        sa.q = dq;
+        sa.n_rows = idx->n_rows;
+        sa.n_cols = V;
+        sa.B = B;
+        sa.k = k;
+        sa.nchunk = nchunk_fb;
+        sa.rows_per_chunk = ceil_div64(idx->n_rows, nchunk_fb);
+        sa.cand = a.cand;
+        const size_t slds = scan_lds_bytes(V);
+        void (*ek)(ScanArgs, const int2*, const int32_t*) = idx->store_dtype == VS_NONE  ? exact_scan_topk_kernel<VM_BIN>
+                                                            : idx->store_dtype == VS_F16 ? exact_scan_topk_kernel<VM_F16> : exact_scan_topk_kernel<VM_F32>;
+        VS_HIP(hipFuncSetAttribute((const void*)ek, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds));
+        hipLaunchKernelGGL(ek, dim3(idx->cu_count), dim3(kScanThreads), slds, s, sa, (const int2*)fb_tiles, (const int32_t*)fb_n);
+        MergeArgs m{};
+        m.cand = a.cand;
+        m.n_cand = (int64_t)nchunk_fb * k;
+        m.B = B;
+        m.k = k;
+        m.id_offset = id_offset;
+        m.out_ids = d_ids;
+        m.out_scores = d_scores;
+        m.out_ld = out_ld;
+        m.col0 = 0;
+        m.run_len = k;
+        m.sel = fb_tiles;
+        m.sel_n = fb_n;
+        hipLaunchKernelGGL(merge_topk_kernel<0>, dim3(std::min(B, idx->cu_count)), dim3(kScanThreads), 0, s, m);
+        VS_HIP(hipGetLastError());
+    }
+    VS_STAGE("fallback", s);
+    idx->last_flags = flags;
+    idx->last_flags_n = B;
+    *done = true;
+    return VS_OK;
+}
+
 // Multi-query pass (Qt = kQT).  Returns VS_OK and sets *done = false when the batch does not qualify
 // (a query denser than the LDS weight capacity): the caller then takes the dense-image path.
 // One pass delivers ranks [col0, col0 + k) of every query into columns col0.. of the [B, out_ld] outputs; `upper`
@@ -855,12 +1050,11 @@ int mq_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64_t id_o
     // Filter and refine (bp_refine.h): the walk runs on int32 fixed-point sums and returns K' > k documents per query, the refine
     // kernel re-scores them exactly and proves the top k; unproven queries go through the fp64 walk.  Without it (option
     // "postings_filter" = 0, "search after" passes, k beyond the candidate buffers) every tile takes the fp64 walk.
-    const int kp = k + std::max(28, k / 4);
-    const bool filter = idx->bp_ready && idx->bp_filter != 0 && col0 == 0 && !upper && kp <= kBpMaxK && (idx->store_dtype == VS_NONE || idx->bp_vmax.p);
+    if (bp_filter_ok(idx, k, col0, upper)) return bp_filter_search(idx, dq, B, k, id_offset, d_ids, d_scores, plan, s, done, out_ld);
     const bool filter_only = idx->bp_quant || idx->store_dtype == VS_NONE;    // lossy / binary records serve the filter only
-    const bool use_bp = idx->bp_ready && (filter || !filter_only);
-    const int qt_plan = !use_bp ? kQT : (idx->store_dtype == VS_NONE ? kBpBinQT : (filter ? kQT : kBpExactQT));
-    const int bp_cap = qt_plan == kQT ? kBpEntCap : kBpEntCap / 2;
+    const bool use_bp = idx->bp_ready && !filter_only;                         // the fp64 walk over exact records
+    const int qt_plan = use_bp ? kBpExactQT : kQT;
+    const int bp_cap = kBpEntCap / 2;
     const int vals_cap = use_bp ? std::min(mq_vals_cap(idx), bp_cap) : mq_vals_cap(idx);     // entries (non-zeros) one tile may hold
     if (vals_cap <= 0 || k > (use_bp ? kBpMaxK : kMaxKMq)) return VS_OK;     // (callers split larger k into passes)
     const int V = idx->n_cols;
@@ -894,37 +1088,19 @@ int mq_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64_t id_o
     hipLaunchKernelGGL(fill_csr_kernel<0>, dim3(std::min(B, 2048)), dim3(kSpThreads), 0, s, dq, (int64_t)V, B, V, qptr, qcols, qvals, qnnz);
     VS_HIP(hipGetLastError());
     VS_STAGE("sparsify", s);
-    if (debug_sync_on()) fprintf(stderr, "[vsearch_hip] plan: tiles %d qnnz %lld max %lld filter %d cap %d\n", n_tiles, (long long)qnnz, (long long)hplan[1], (int)filter, vals_cap);
+    if (debug_sync_on()) fprintf(stderr, "[vsearch_hip] plan: tiles %d qnnz %lld max %lld cap %d\n", n_tiles, (long long)qnnz, (long long)hplan[1], vals_cap);
     // 2. scan.  Work items = (tile, row chunk)
     int nchunk = choose_chunks(idx, n_tiles, plan.nchunk);
     if (use_bp) {
         // blocked postings: chunks are runs of blocks
         const int64_t n_blocks = ceil_div64(idx->n_rows, idx->bp_rows);
         nchunk = (int)std::min<int64_t>(nchunk, n_blocks);
-        // Big index, enough tiles: as FEW chunks as give every CU two work items.  Every tile sweeps its chunk's blocks in the same
-        // order at the same pace, so with few chunks all tiles are within a few blocks of each other and each block is fetched from
-        // HBM once for all of them (Infinity Cache): 21 M docs, 1024 queries: 4 chunks 300 ms, 8: 333, 16: 399, 64: 561, 2 (one item
-        // per CU, no second round to even out): 419.
-        if (idx->n_rows >= (2 << 20) && (int64_t)n_tiles * 4 >= idx->cu_count) {
-            int best = 1;
-            double best_eff = 0.0;
-            const int c0 = (int)std::max<int64_t>(1, ceil_div64(2 * (int64_t)idx->cu_count, n_tiles));
-            for (int c = c0; c <= c0 + 3; ++c) {
-                const int64_t it = (int64_t)n_tiles * c;
-                const double eff = (double)it / (double)(ceil_div64(it, idx->cu_count) * idx->cu_count);
-                if (eff > best_eff + 1e-9) { best_eff = eff; best = c; }
-                if (eff >= 0.95) break;
-            }
-            nchunk = (int)std::min<int64_t>(best, n_blocks);
-        }
-        if (idx->bp_chunks > 0) nchunk = (int)std::min<int64_t>(idx->bp_chunks, n_blocks);
+        nchunk = bp_choose_chunks(idx, n_tiles, n_blocks, plan.nchunk);
         const int64_t blocks_per_chunk = ceil_div64(n_blocks, nchunk);
         const int64_t items = (int64_t)n_tiles * nchunk;
         const int grid = (int)std::min<int64_t>(items, idx->cu_count);
-        const int nchunk_fb = (int)std::min<int64_t>(n_blocks, 64);
         VS_TRY(idx->ws_mq_cand.reserve((size_t)idx->cu_count * kQT * kBpCap * 8));
-        if (idx->bp_rows > (idx->store_dtype == VS_NONE ? kBpRowsMaxBin : kBpRowsMax)) return fail(VS_EINVAL, "postings_rows beyond the walk's block capacity");
-        VS_TRY(idx->ws_cand.reserve(std::max((size_t)B * nchunk * (filter ? kp : k), filter ? (size_t)B * nchunk_fb * k : (size_t)0) * 8));
+        VS_TRY(idx->ws_cand.reserve((size_t)B * nchunk * k * 8));
         const int RS = bp_rec_bytes(bp_record_vm(idx));
         BpArgs a{};
         a.rows = idx->bp_rows;
@@ -945,115 +1121,9 @@ int mq_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64_t id_o
         a.cand = idx->ws_cand.as<uint64_t>();
         a.gcand = idx->ws_mq_cand.as<uint64_t>();
         a.upper = col0 > 0 ? upper : nullptr;
-        if (debug_sync_on()) fprintf(stderr, "[vsearch_hip] walk: blocks %lld nchunk %d bpc %lld grid %d kp %d\n", (long long)n_blocks, nchunk, (long long)blocks_per_chunk, grid, kp);
         // what this launch has to read: the records of the batch's (query, column) entries + one directory pair per entry and block
         idx->last_scan_bytes += hplan[4] * RS + qnnz * n_blocks * 8;
         idx->last_walk_postings += hplan[5];
-        if (filter) {
-            VS_TRY(idx->ws_fb.reserve((size_t)B * sizeof(int2) + (size_t)B * 16 + 64));
-            int2* fb_tiles = idx->ws_fb.as<int2>();
-            float* qscale = reinterpret_cast<float*>(fb_tiles + B);
-            int32_t* qslack = reinterpret_cast<int32_t*>(qscale + B);
-            float* qwsum = reinterpret_cast<float*>(qslack + B);
-            uint32_t* flags = reinterpret_cast<uint32_t*>(qwsum + B);
-            int32_t* fb_n = reinterpret_cast<int32_t*>(flags + B);
-            hipLaunchKernelGGL(bp_qscale_kernel<0>, dim3((unsigned)ceil_div(B, 4)), dim3(256), 0, s, qptr, qvals, B, idx->bp_vmax.as<uint32_t>(),
-                               idx->store_dtype == VS_NONE ? 1 : 0, idx->bp_quant ? 1 : 0, qscale, qslack, qwsum);
-            VS_HIP(hipGetLastError());
-            a.k = kp;
-            a.qscale = qscale;
-            idx->last_path = 3;
-            {
-                ProfScope prof("csr_scan_topk", s);
-                VS_TRY((launch_bp_walk<kQT, AM_FIX>(idx, a, grid, vals_cap, s)));
-            }
-            VS_STAGE("filter walk", s);
-            RefineArgs r{};
-            r.cand = a.cand;
-            r.n_cand = (int64_t)nchunk * kp;
-            r.run_len = kp;
-            r.B = B; r.k = k; r.kp = kp;
-            r.pk_ptr = idx->pk_ptr.as<uint32_t>();
-            r.cols = idx->cols.as<uint4>();
-            r.vals = idx->vals.p;
-            r.n_cols = V;
-            r.n_rows = idx->n_rows;
-            r.q = dq;
-            r.qscale = qscale;
-            r.qslack = qslack;
-            r.qwsum = qwsum;
-            r.quant = idx->bp_quant ? 1 : 0;
-            r.force_flag = idx->bp_force_fb ? 1 : 0;
-            r.id_offset = id_offset;
-            r.out_ids = d_ids;
-            r.out_scores = d_scores;
-            r.out_ld = out_ld;
-            r.flags = flags;
-            {
-                ProfScope prof("refine_topk", s);
-                const int rgrid = std::min(B, idx->cu_count * 2);
-                if (idx->store_dtype == VS_F32) hipLaunchKernelGGL(refine_topk_kernel<VM_F32>, dim3(rgrid), dim3(kScanThreads), 0, s, r);
-                else if (idx->store_dtype == VS_F16) hipLaunchKernelGGL(refine_topk_kernel<VM_F16>, dim3(rgrid), dim3(kScanThreads), 0, s, r);
-                else hipLaunchKernelGGL(refine_topk_kernel<VM_BIN>, dim3(rgrid), dim3(kScanThreads), 0, s, r);
-                VS_HIP(hipGetLastError());
-            }
-            VS_STAGE("refine", s);
-            // unproven queries (normally none): one-query tiles, planned on the device, through the exact walk + merge
-            hipLaunchKernelGGL(fb_plan_kernel<0>, dim3(1), dim3(kScanThreads), 0, s, flags, B, fb_tiles, fb_n);
-            VS_HIP(hipGetLastError());
-            a.k = k;
-            a.qscale = nullptr;
-            a.tiles = fb_tiles;
-            a.n_tiles_dev = fb_n;
-            a.nchunk = nchunk_fb;
-            a.blocks_per_chunk = ceil_div64(n_blocks, nchunk_fb);
-            a.ent_cap = std::min(vals_cap, kBpEntCap / 2);
-            {
-                ProfScope prof("exact_fallback", s);
-                if (filter_only) {
-                    // the records are lossy (or binary): the unproven queries take a one-query-per-pass scan of the CSR packets (fp64 row sums)
-                    ScanArgs sa{};
-                    sa.pk_ptr = idx->pk_ptr.as<uint32_t>();
-                    sa.cols = idx->cols.as<uint4>();
-                    sa.vals = idx->vals.p;
-                    sa.q = dq;
-                    sa.n_rows = idx->n_rows;
-                    sa.n_cols = V;
-                    sa.B = B;
-                    sa.k = k;
-                    sa.nchunk = nchunk_fb;
-                    sa.rows_per_chunk = ceil_div64(idx->n_rows, nchunk_fb);
-                    sa.cand = a.cand;
-                    const size_t slds = scan_lds_bytes(V);
-                    void (*ek)(ScanArgs, const int2*, const int32_t*) = idx->store_dtype == VS_NONE ? exact_scan_topk_kernel<VM_BIN> : exact_scan_topk_kernel<VM_F32>;
-                    VS_HIP(hipFuncSetAttribute((const void*)ek, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds));
-                    hipLaunchKernelGGL(ek, dim3(idx->cu_count), dim3(kScanThreads), slds, s, sa, (const int2*)fb_tiles, (const int32_t*)fb_n);
-                    VS_HIP(hipGetLastError());
-                } else {
-                    VS_TRY((launch_bp_walk<kBpExactQT, AM_F64>(idx, a, idx->cu_count, a.ent_cap, s)));
-                }
-                MergeArgs m{};
-                m.cand = a.cand;
-                m.n_cand = (int64_t)nchunk_fb * k;
-                m.B = B;
-                m.k = k;
-                m.id_offset = id_offset;
-                m.out_ids = d_ids;
-                m.out_scores = d_scores;
-                m.out_ld = out_ld;
-                m.col0 = 0;
-                m.run_len = k;
-                m.sel = fb_tiles;
-                m.sel_n = fb_n;
-                hipLaunchKernelGGL(merge_topk_kernel<0>, dim3(std::min(B, idx->cu_count)), dim3(kScanThreads), 0, s, m);
-                VS_HIP(hipGetLastError());
-            }
-            VS_STAGE("fallback", s);
-            idx->last_flags = flags;
-            idx->last_flags_n = B;
-            *done = true;
-            return VS_OK;
-        }
         idx->last_path = 2;
         ProfScope prof("csr_scan_topk", s);
         VS_TRY((launch_bp_walk<kBpExactQT, AM_F64>(idx, a, grid, vals_cap, s)));
@@ -1143,6 +1213,7 @@ int vs_csr_search(vs_index* idx, const void* q, int q_dtype, int64_t ldq, int32_
     idx->last_walk_postings = 0;
     idx->last_flags = nullptr;
     idx->last_flags_n = 0;
+    idx->last_plan_dev = nullptr;
     idx->last_path = 0;
     if (idx->qt_pref != 1) {
         if (!idx->bp_ready && !idx->bp_tried && bp_wanted(idx)) VS_TRY(bp_build(idx, s));

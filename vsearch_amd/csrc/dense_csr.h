@@ -76,6 +76,7 @@ __global__ __launch_bounds__(kSpThreads) void fill_csr_kernel(const float* x, in
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
         int64_t base = rowptr[b];
+        if (rowptr[b + 1] == base) continue;                   // empty row (or one the planner left out): nothing to write
         int buf = 0;
         for (int c0 = 0; c0 < V; c0 += kSpThreads, buf ^= 1) {
             const int i = c0 + tid;

@@ -51,7 +51,8 @@ def current_stream(device: int):
     try:
         import torch
         if torch.cuda.is_available():
-            return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+            # the null stream is passed as hipStreamLegacy ((hipStream_t)1): same stream, but not "no stream given" (which blocks)
+            return C.c_void_p(torch.cuda.current_stream(device).cuda_stream or 1)
     except Exception:
         pass
     return None
@@ -62,6 +63,13 @@ class DeviceIndex:
 
     def __init__(self, handle):
         self._h = handle
+        self._device = None        # cached: info() reads device-side search statistics and therefore synchronises
+
+    @property
+    def device(self) -> int:
+        if self._device is None:
+            self._device = int(self.info().device)
+        return self._device
 
     # ---- constructors -------------------------------------------------------------------------
     @classmethod
@@ -162,16 +170,17 @@ class DeviceIndex:
         return p, dt, keep, int(q.shape[0]), int(q.shape[1])
 
     def search(self, q, k: int, id_offset: int = 0):
-        """Top-k per query -> (ids int64 [B,k], scores float32 [B,k]); canonical order (score desc, id asc)."""
-        info = self.info()
+        """Top-k per query -> (ids int64 [B,k], scores float32 [B,k]); canonical order (score desc, id asc).
+        Device queries: the call returns once the kernels are enqueued on torch's current stream (no host synchronisation on
+        the postings filter path); host queries / outputs are copied and the call blocks."""
         p, dt, keep, B, ldq = self._q_args(q)
         k = int(k)
         if _is_torch(q) and q.is_cuda:
             import torch
-            dev = torch.device("cuda", info.device)
+            dev = torch.device("cuda", self.device)
             ids = torch.empty((B, k), dtype=torch.int64, device=dev)
             scores = torch.empty((B, k), dtype=torch.float32, device=dev)
-            stream = current_stream(info.device)
+            stream = current_stream(self.device)
             nat.check(nat.lib().vs_index_search(self._h, p, dt, ldq, B, k, int(id_offset), C.c_void_p(ids.data_ptr()),
                                                 C.c_void_p(scores.data_ptr()), stream))
             return ids, scores
