@@ -50,18 +50,24 @@ def parse():
     ap.add_argument("--scan", choices=["auto", "csr", "postings"], default="auto",
                     help="auto: blocked postings when HBM has room for the second copy (default); csr: the 8-query CSR scan only")
     ap.add_argument("--cpu-sample-docs", type=int, default=100_000)
+    ap.add_argument("--columns", choices=["uniform", "zipf"], default="uniform",
+                    help="column law of the synthetic corpus AND queries: uniform (the metric's workload) or zipf (popularity ~ 1 / rank, "
+                         "SURVEY 8(d) C3's secondary run: vsearch_amd/synth.py KIND_SKEW)")
     ap.add_argument("--store", choices=["fp32", "fp16"], default="fp32",
                     help="value dtype streamed by the scan (fp16 = the reference's fp16=True load default, index.py:135)")
     return ap.parse_args()
 
 
-def make_query_batches(n_batches, batch, device):
+KIND = {"uniform": 0, "zipf": 2}
+
+
+def make_query_batches(n_batches, batch, device, kind=0):
     """Distinct synthetic query batches, generated on the GPU by the library's own generator (rows of the
     seed-1 synthetic matrix with 776 non-zeros) and left resident in HBM as dense [B, V] fp32."""
     from vsearch_amd.device_index import DeviceIndex
     out = []
     for i in range(n_batches):
-        gen = DeviceIndex.synthetic(QUERY_SEED, i * batch, batch, V, NNZ_Q, 0, 0, 0, device.index or 0)
+        gen = DeviceIndex.synthetic(QUERY_SEED, i * batch, batch, V, NNZ_Q, kind, 0, 0, device.index or 0)
         ip, ix, d = gen.export_csr()
         gen.close()
         q = torch.zeros((batch, V), dtype=torch.float32, device=device)
@@ -71,15 +77,15 @@ def make_query_batches(n_batches, batch, device):
     return out
 
 
-def parity_check(device):
+def parity_check(device, kind=0):
     """Small prefix of the same synthetic index (rows are a pure function of (seed, row id)) searched
     by the HIP path and by the CPU oracle: recall@100 and max relative score error."""
     import oracle
     from oracle import compare
     from vsearch_amd.device_index import DeviceIndex
     n = 20_000
-    idx = DeviceIndex.synthetic(INDEX_SEED, 0, n, V, NNZ_DOC, 0, 0, 0, device)
-    q = oracle.synth_queries(QUERY_SEED, 8, V, NNZ_Q)
+    idx = DeviceIndex.synthetic(INDEX_SEED, 0, n, V, NNZ_DOC, kind, 0, 0, device)
+    q = oracle.synth_queries(QUERY_SEED, 8, V, NNZ_Q, kind=kind)
     ids, sc = idx.search(q, K)
     ip, ix, d = idx.export_csr()
     o_ids, o_sc, allsc = oracle.csr_search(ip, ix.astype(np.int32), d, V, q, K, acc64=True, return_all=True)
@@ -88,19 +94,19 @@ def parity_check(device):
     return {"docs": n, "queries": 8, "recall_at_100_vs_oracle": compare.recall_at_k(o_ids, ids), "max_rel_score_err": rel}
 
 
-def cpu_baseline(sample_docs, device):
+def cpu_baseline(sample_docs, device, kind=0):
     """The reference's Index.search (index.py:89-92: cast, torch.matmul(q, csr.t()), topk) restated in
     oracle/torch_ref.py and timed on this box's host cores on a bounded sample of the same index."""
     from oracle import torch_ref
     from vsearch_amd.device_index import DeviceIndex
     n = sample_docs
-    idx = DeviceIndex.synthetic(INDEX_SEED, 0, n, V, NNZ_DOC, 0, 0, 0, device)   # bit-identical rows, generated on the GPU
+    idx = DeviceIndex.synthetic(INDEX_SEED, 0, n, V, NNZ_DOC, kind, 0, 0, device)   # bit-identical rows, generated on the GPU
     ip, ix, d = idx.export_csr()
     idx.close()
     vec = torch_ref.make_csr(ip, ix, d, (n, V))
     import oracle
     bq = 32
-    q = torch.from_numpy(oracle.synth_queries(QUERY_SEED, bq, V, NNZ_Q))
+    q = torch.from_numpy(oracle.synth_queries(QUERY_SEED, bq, V, NNZ_Q, kind=kind))
     torch_ref.search(vec, q, K)                                   # warm-up
     reps, t0 = 0, time.perf_counter()
     while reps < 3 or (time.perf_counter() - t0 < 10.0 and reps < 50):
@@ -148,9 +154,10 @@ def main():
     row0, n_local = shard_rows(args.docs, world, rank)
     t0 = time.perf_counter()
     store = nat.VS_F16 if args.store == "fp16" else nat.VS_F32
-    index = DeviceIndex.synthetic(INDEX_SEED, row0, n_local, V, NNZ_DOC, 0, 0, store, local_rank)
+    kind = KIND[args.columns]
+    index = DeviceIndex.synthetic(INDEX_SEED, row0, n_local, V, NNZ_DOC, kind, 0, store, local_rank)
     index.set_option("blocked_postings", {"auto": -1, "csr": 0, "postings": 1}[args.scan])
-    batches = make_query_batches(min(4, args.steps + args.warmup), args.batch, device)
+    batches = make_query_batches(min(4, args.steps + args.warmup), args.batch, device, kind)
     index.search(batches[0][:8], min(args.k, n_local))            # first sparse search builds the column-grouped copy: part of the build
     torch.cuda.synchronize()
     info = index.info()
@@ -244,9 +251,9 @@ def main():
             "value": qps, "unit": "queries/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32" if args.store == "fp32" else "f16 values, f32/f64 accumulate", "data": "synthetic",
-            "config": {"workload": f"wiki21m-shaped sparse CSR index: {args.docs} docs x {NNZ_DOC} nnz, V={V}, {args.store} values, "
+            "config": {"workload": f"wiki21m-shaped sparse CSR index: {args.docs} docs x {NNZ_DOC} nnz, V={V}, {args.store} values, {args.columns} columns, "
                                    f"row-sharded over {world} GPU(s); {args.batch} queries/step ({NNZ_Q} nnz), k={args.k}",
-                       "docs": args.docs, "docs_per_gpu": n_local, "batch": args.batch, "k": args.k, "queries_per_pass": qt,
+                       "docs": args.docs, "docs_per_gpu": n_local, "batch": args.batch, "k": args.k, "queries_per_pass": qt, "columns": args.columns,
                        "lanes_per_row": info.lanes_per_row, "index_bytes_per_gpu": info.device_bytes,
                        "postings_copy_bytes_per_gpu": info.aux_bytes, "scan_path": path, "dominant_kernel": kernel, "index_build_s": round(build_s, 2)},
             "exchange": {"backend": ("rccl (torch.distributed nccl)" if backend == "nccl" else backend) if world > 1 else None,
@@ -255,9 +262,9 @@ def main():
             "roofline": roofline,
         }
         if world == 1:
-            line["parity"] = parity_check(local_rank)
+            line["parity"] = parity_check(local_rank, kind)
             if not args.no_cpu_baseline:
-                line["cpu_baseline"] = cpu_baseline(args.cpu_sample_docs, local_rank)
+                line["cpu_baseline"] = cpu_baseline(args.cpu_sample_docs, local_rank, kind)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -135,7 +135,8 @@ VS_API int vs_index_create_dense_auto(const void* mat, int dtype, int store_dtyp
 /* Synthetic corpus generated straight into the device format (bench / tests; no reference
  * counterpart).  Rows are the pure function of (seed, global row id) defined in
  * vsearch_amd/synth.py; this shard holds rows [row0, row0 + n_rows).
- *   kind: 0 = fixed `nnz` per row with values, 1 = bag-of-token lengths (binary).               */
+ *   kind: 0 = fixed `nnz` per row with values, uniform columns; 1 = bag-of-token lengths (binary);
+ *         2 = fixed `nnz`, column popularity ~ 1 / rank (Zipf s = 1, the most popular ~127 columns in every row).  */
 VS_API int vs_index_create_synthetic(uint64_t seed, int64_t row0, int64_t n_rows, int32_t n_cols, int32_t nnz,
                                      int kind, int val_law, int store_dtype, int device, vs_index** out);
 
@@ -220,6 +221,18 @@ VS_API int vs_head_pool(const float* logits, int32_t B, int32_t L, int32_t V, fl
  * The reference's [B, L, V] logits tensor is never materialised.                                          */
 VS_API int vs_head_project_pool(const float* hidden, const float* W, int32_t B, int32_t L, int32_t H, int32_t V, float* out,
                                 int device, void* stream);
+
+/* ---- rerank of bag-of-token hits: Retriever.retrieve(rerank=True) (retriever.py:137-147) --------
+ * The reference re-embeds the B * k hit texts with encoder_p into a dense [B * k, V] tensor, takes torch.bmm against the query
+ * embeddings, and topk(k) re-sorts every row.  Here the two steps are separate entry points so that the re-embedding can be
+ * streamed in batches (the dense tensor is 12 GB at B = 1024, k = 100): vs_rerank_scores fills scores[row0 .. row0 + n_rows) of
+ * the flat [B * k] score array from one batch of passage embeddings (row r of the batch is hit (row0 + r) % k of query
+ * (row0 + r) / k; fp32 products, fp64 sums), vs_rerank_topk then orders every query's k hits by (score descending,
+ * first-stage rank ascending) and gathers their ids.  Device pointers only; k <= 2048.                                    */
+VS_API int vs_rerank_scores(const void* p_emb, int p_dtype, int64_t ldp, int64_t n_rows, int64_t row0, const float* q, int64_t ldq, int32_t B,
+                            int32_t k, int32_t n_cols, float* scores, int device, void* stream);
+VS_API int vs_rerank_topk(const float* scores, const int64_t* hit_ids, int32_t B, int32_t k, int64_t* out_ids, float* out_scores, int device,
+                          void* stream);
 
 /* elu1p (sparse.py:6) elementwise. */
 VS_API int vs_elu1p(const float* x, int64_t n, float* out, int device, void* stream);

@@ -166,8 +166,8 @@ def synth_csr(seed, row0, n_rows, n_cols=29523, nnz=768, kind=0, val_law=0):
     return indptr, indices, data
 
 
-def synth_queries(seed, n_q, n_cols=29523, nnz_q=776, val_law=0, q0=0):
-    indptr, cols, data = synth_csr(seed, q0, n_q, n_cols, nnz_q, 0, val_law)
+def synth_queries(seed, n_q, n_cols=29523, nnz_q=776, val_law=0, q0=0, kind=0):
+    indptr, cols, data = synth_csr(seed, q0, n_q, n_cols, nnz_q, kind, val_law)
     q = np.zeros((n_q, n_cols), dtype=np.float32)
     q[np.repeat(np.arange(n_q), np.diff(indptr)), cols] = data
     return q

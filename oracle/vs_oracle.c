@@ -289,6 +289,29 @@ static inline uint32_t perm_col(uint64_t key, uint32_t j, uint32_t n_cols) {
     while (x >= n_cols) x = feistel16(x, key);
     return x;
 }
+/* kind 2: skewed column popularity, twin of synth_skew_col (vsearch_amd/csrc/synth_device.h) */
+static inline uint32_t skew_col(uint64_t key, uint32_t j, uint32_t len, uint32_t n_cols) {
+    const uint32_t kHead = 127;
+    uint32_t rank, kmax = 0;
+    while ((2u << kmax) <= n_cols) ++kmax;
+    if (len <= kHead + 8 || kmax < 8) {
+        rank = j + 1;
+    } else if (j < kHead) {
+        rank = j + 1;
+    } else {
+        const uint32_t n_oct = kmax - 7 + 1, per = (len - kHead) / n_oct, t = j - kHead;
+        uint32_t o = t / per;
+        if (o > n_oct - 1) o = n_oct - 1;
+        const uint32_t i = t - o * per, k = 7 + o;
+        const uint32_t lo = 1u << k, size = (2u << k) <= n_cols + 1 ? lo : n_cols + 1 - lo, mask = lo - 1;
+        const uint64_t h = splitmix64(key + 0x9E3779B97F4A7C15ull * (k + 1));
+        const uint32_t odd = (uint32_t)h | 1u, add = (uint32_t)(h >> 32);
+        uint32_t x = i;
+        do { x = (x * odd + add) & mask; } while (x >= size);
+        rank = lo + x;
+    }
+    return perm_col(0x5A495046534B4557ull, rank - 1, n_cols);
+}
 static inline int64_t row_len(uint64_t seed, int64_t row, int kind, int32_t nnz, int32_t n_cols) {
     int64_t len = nnz;
     if (kind == 1) {
@@ -306,7 +329,7 @@ static inline float synth_val(uint64_t seed, int64_t row, uint32_t col, int val_
     return 1.0f;
 }
 
-/* indices == NULL -> fill indptr only. kind: 0 = fixed nnz, 1 = BoT lengths (binary). */
+/* indices == NULL -> fill indptr only. kind: 0 = fixed nnz, 1 = BoT lengths (binary), 2 = fixed nnz, skewed column popularity. */
 VSO_API int vso_synth_csr(uint64_t seed, int64_t row0, int64_t n_rows, int32_t n_cols, int32_t nnz, int kind,
                           int val_law, int64_t* indptr, int32_t* indices, float* data) {
     if (n_cols <= 0 || n_cols > 65536) return -1;
@@ -321,7 +344,7 @@ VSO_API int vso_synth_csr(uint64_t seed, int64_t row0, int64_t n_rows, int32_t n
         int64_t row = row0 + r, len = indptr[r + 1] - indptr[r];
         uint64_t key = hash3(seed, (uint64_t)row, 0x4B4559ull);
         for (int64_t j = 0; j < len; ++j) {
-            uint32_t c = perm_col(key, (uint32_t)j, (uint32_t)n_cols);
+            uint32_t c = kind == 2 ? skew_col(key, (uint32_t)j, (uint32_t)len, (uint32_t)n_cols) : perm_col(key, (uint32_t)j, (uint32_t)n_cols);
             tmp[c >> 6] |= 1ull << (c & 63);
         }
         int64_t w = indptr[r];

@@ -167,7 +167,11 @@ def test_retrieve_and_rerank_golden(golden):
     assert (r_t.ids == r_n.ids).all()
     compare.compare_topk(g["ids"], g["scores"], r_t.ids.cpu().numpy(), r_t.scores.cpu().numpy(), rtol=RTOL)
     r_r = Retriever.retrieve(fake, torch.from_numpy(q), k=k, rerank=True)
-    compare.compare_topk(g["rerank_ids"], g["rerank_scores"], r_r.ids.numpy(), r_r.scores.numpy(), rtol=RTOL)
+    assert r_r.ids.is_cuda and r_r.scores.is_cuda                         # scored and sorted on the device (vs_rerank_scores / vs_rerank_topk)
+    compare.compare_topk(g["rerank_ids"], g["rerank_scores"], r_r.ids.cpu().numpy(), r_r.scores.cpu().numpy(), rtol=RTOL)
+    # the same through a small re-embedding batch (several vs_rerank_scores calls per query batch)
+    r_r2 = Retriever.retrieve(fake, torch.from_numpy(q), k=k, rerank=True, batch_size=1)
+    assert (r_r2.ids == r_r.ids).all() and (r_r2.scores == r_r.scores).all()
     sparse = SparseIndex()
     sparse.data = bot.data
     sparse.vector = csr_tensor(ip2, ix2, d2)

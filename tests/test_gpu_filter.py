@@ -184,3 +184,17 @@ def test_baseline_sized_index_on_one_gpu():
     assert info.last_path == 3 and info.last_fallbacks == 0
     ref_ids, ref_sc, _ = _search(idx, qb[500:516], 100, blocked_postings=0)
     assert (np.asarray(ids_b)[500:516] == ref_ids).all() and (np.asarray(sc_b)[500:516] == ref_sc).all()
+
+
+def test_skewed_columns_device_generator_and_search():
+    """KIND_SKEW (column popularity ~ 1 / rank, SURVEY 8(d) C3's secondary run): the device generator equals its host twins row for
+    row, and the filter search on it -- long lists for popular columns, saturated head -- stays bit-identical to the CSR scan."""
+    n = 9000
+    idx = DeviceIndex.synthetic(0, 100, n, V, 768, synth.KIND_SKEW, 0, nat.VS_F32)
+    ip, ix, d = idx.export_csr()
+    o_ip, o_ix, o_d = oracle.synth_csr(0, 100, n, V, 768, synth.KIND_SKEW)
+    assert (ip == o_ip).all() and (ix == o_ix).all() and (d == o_d).all()
+    q = oracle.synth_queries(1, 21, kind=synth.KIND_SKEW)
+    ids, sc = _modes(idx, q, 100, want_quant=True)
+    _, _, allsc = oracle.csr_search(o_ip, o_ix, o_d, V, q, 100, acc64=True, return_all=True)
+    compare.check_topk_valid(allsc, ids, sc, rtol=RTOL)

@@ -233,3 +233,22 @@ def test_save_load_manifest(golden):
     assert (g["shift999_indices"] == ix[keep] - 999).all() and (g["shift999_data"] == d[keep]).all()
     cnt = np.add.reduceat(keep.astype(np.int64), ip[:-1])
     assert (np.diff(g["shift999_indptr"]) == cnt).all()
+
+
+def test_skewed_column_law_twins_agree():
+    """KIND_SKEW rows: numpy generator == C twin; rows are sorted, duplicate-free, of the requested length; the head ranks sit in
+    every row and popularity falls off like 1 / rank."""
+    import oracle
+    from vsearch_amd import synth
+    for n_cols, nnz in [(29523, 768), (29523, 776), (5000, 300), (300, 100)]:
+        a = synth.synth_csr(3, 5, 30, n_cols, nnz, synth.KIND_SKEW)
+        b = oracle.synth_csr(3, 5, 30, n_cols, nnz, synth.KIND_SKEW)
+        assert all((x == y).all() for x, y in zip(a, b))
+        assert (np.diff(a[0]) == min(nnz, n_cols)).all()
+        for r in range(30):
+            c = a[1][a[0][r]:a[0][r + 1]]
+            assert (np.diff(c) > 0).all()
+    ip, ix, _ = oracle.synth_csr(0, 0, 1500, 29523, 768, synth.KIND_SKEW)
+    freq = np.sort(np.bincount(ix, minlength=29523))[::-1]
+    assert (freq[:127] == 1500).all()                                   # saturated head
+    assert 0.5 < freq[127] / 1500 < 0.8 and 0.25 < freq[255] / 1500 < 0.45 and 0.03 < freq[2047] / 1500 < 0.12 and freq[20000] / 1500 < 0.02

@@ -60,6 +60,8 @@ _SIGNATURES = {
     "vs_head_pool": ([_vp, _i32, _i32, _i32, _vp, _int, _vp], _int),
     "vs_head_project_pool": ([_vp, _vp, _i32, _i32, _i32, _i32, _vp, _int, _vp], _int),
     "vs_elu1p": ([_vp, _i64, _vp, _int, _vp], _int),
+    "vs_rerank_scores": ([_vp, _int, _i64, _i64, _i64, _vp, _i64, _i32, _i32, _i32, _vp, _int, _vp], _int),
+    "vs_rerank_topk": ([_vp, _vp, _i32, _i32, _vp, _vp, _int, _vp], _int),
     "vs_bot_build": ([_vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp], _int),
     "vs_profile_enable": ([_int], _int),
     "vs_profile_reset": ([], _int),

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(kSynthWaves * 64) void synth_rows_kernel(uint64_t s
         for (int i = lane; i < words; i += 64) bm[i] = 0;
         __builtin_amdgcn_wave_barrier();
         for (int64_t j = lane; j < len; j += 64) {
-            const uint32_t c = perm_col(key, (uint32_t)j, (uint32_t)n_cols);
+            const uint32_t c = synth_col(key, (uint32_t)j, (uint32_t)len, kind, (uint32_t)n_cols);
             atomicOr(&bm[c >> 5], 1u << (c & 31));
         }
         __builtin_amdgcn_wave_barrier();
@@ -402,7 +402,7 @@ extern "C" int vs_index_create_synthetic(uint64_t seed, int64_t row0, int64_t n_
     if (!out) return fail(VS_EINVAL, "out is NULL");
     *out = nullptr;
     if (n_rows < 0 || n_cols <= 0 || n_cols > 65535 || nnz <= 0 || nnz > n_cols) return fail(VS_EINVAL, "bad synthetic shape");
-    if (kind != 0 && kind != 1) return fail(VS_EINVAL, "kind must be 0 (fixed nnz) or 1 (bag-of-token)");
+    if (kind < 0 || kind > 2) return fail(VS_EINVAL, "kind must be 0 (fixed nnz), 1 (bag-of-token) or 2 (fixed nnz, skewed column popularity)");
     if (kind == 1) store_dtype = VS_NONE;
     vs_index* idx = nullptr;
     VS_TRY(new_index(device, &idx));

@@ -232,7 +232,84 @@ int run_mask(MaskArgs a, const float* x_in, float* emb_io, const int64_t* ids, u
     return VS_OK;
 }
 
+// ---- rerank (retriever.py:137-147): scores[b, j] = <p_emb[b * k + j, :], q[b, :]>, then a stable descending sort ------------
+// One wave per re-embedded passage; fp32 products summed in fp64 (the library's exact numerics); the passage rows are ~97 %
+// zeros, the query row comes from L2.  `row0` = index (b * k + j) of the chunk's first row: the re-embedding can be streamed in
+// batches, the dense [B * k, V] tensor of the reference never has to exist.
+template <class T>
+__global__ __launch_bounds__(256) void rerank_scores_kernel(const T* p, int64_t ldp, int64_t n_rows, int64_t row0, const float* q, int64_t ldq, int32_t k,
+                                                            int32_t V, float* scores) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < n_rows; r += (int64_t)gridDim.x * 4) {
+        const int64_t g = row0 + r;
+        const T* pr = p + (size_t)r * ldp;
+        const float* qr = q + (size_t)(g / k) * ldq;
+        double sum = 0.0;
+        for (int c = lane; c < V; c += 64) {
+            float v;
+            if constexpr (sizeof(T) == 2) v = __half2float(pr[c]);
+            else v = pr[c];
+            if (v != 0.f) sum += (double)(v * qr[c]);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        if (lane == 0) scores[g] = (float)sum;
+    }
+}
+
+// per query: (score desc, first-stage rank asc) -> ids of the hits in the new order + their scores.  k <= kSpThreads * 2.
+__global__ __launch_bounds__(kSpThreads) void rerank_topk_kernel(const float* scores, const int64_t* hit_ids, int32_t B, int32_t k, int64_t* out_ids, float* out_scores) {
+    __shared__ uint64_t keys[2 * kSpThreads];
+    const int tid = threadIdx.x;
+    int n2 = 64;
+    while (n2 < k) n2 <<= 1;
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        __syncthreads();
+        for (int i = tid; i < n2; i += kSpThreads) keys[i] = i < k ? make_key(scores[(size_t)b * k + i], (uint32_t)i) : 0ull;
+        wg_sort_desc<kSpThreads>(keys, n2, tid);
+        for (int i = tid; i < k; i += kSpThreads) {
+            const uint64_t key = keys[i];
+            out_ids[(size_t)b * k + i] = hit_ids[(size_t)b * k + key_row(key)];
+            out_scores[(size_t)b * k + i] = key_score(key);
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int vs_rerank_scores(const void* p_emb, int p_dtype, int64_t ldp, int64_t n_rows, int64_t row0, const float* q, int64_t ldq, int32_t B,
+                                int32_t k, int32_t n_cols, float* scores, int device, void* stream) {
+    if (!p_emb || !q || !scores || n_rows < 0 || row0 < 0 || B <= 0 || k <= 0 || n_cols <= 0 || ldp < n_cols || ldq < n_cols)
+        return fail(VS_EINVAL, "bad argument");
+    if (row0 + n_rows > (int64_t)B * k) return fail(VS_ERANGE, "rows %lld..%lld beyond B * k = %lld", (long long)row0, (long long)(row0 + n_rows), (long long)B * k);
+    if (p_dtype != VS_F32 && p_dtype != VS_F16) return fail(VS_EINVAL, "p_dtype must be VS_F32 or VS_F16");
+    if (!is_device_ptr(p_emb) || !is_device_ptr(q) || !is_device_ptr(scores)) return fail(VS_EINVAL, "vs_rerank_scores takes device pointers");
+    VS_TRY(check_device(device));
+    hipStream_t s = (hipStream_t)stream;
+    if (n_rows > 0) {
+        const unsigned grid = (unsigned)std::min<int64_t>(ceil_div64(n_rows, 4), 8192);
+        if (p_dtype == VS_F32)
+            hipLaunchKernelGGL(rerank_scores_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)p_emb, ldp, n_rows, row0, q, ldq, k, n_cols, scores);
+        else
+            hipLaunchKernelGGL(rerank_scores_kernel<__half>, dim3(grid), dim3(256), 0, s, (const __half*)p_emb, ldp, n_rows, row0, q, ldq, k, n_cols, scores);
+    }
+    VS_HIP(hipGetLastError());
+    if (!stream) VS_HIP(hipStreamSynchronize(s));
+    return VS_OK;
+}
+
+extern "C" int vs_rerank_topk(const float* scores, const int64_t* hit_ids, int32_t B, int32_t k, int64_t* out_ids, float* out_scores, int device, void* stream) {
+    if (!scores || !hit_ids || !out_ids || !out_scores || B <= 0 || k <= 0) return fail(VS_EINVAL, "bad argument");
+    if (k > 2 * kSpThreads) return fail(VS_EUNSUPPORTED, "rerank of k = %d hits per query (at most %d)", k, 2 * kSpThreads);
+    if (!is_device_ptr(scores) || !is_device_ptr(hit_ids) || !is_device_ptr(out_ids) || !is_device_ptr(out_scores))
+        return fail(VS_EINVAL, "vs_rerank_topk takes device pointers");
+    VS_TRY(check_device(device));
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(rerank_topk_kernel, dim3((unsigned)std::min(B, 4096)), dim3(kSpThreads), 0, s, scores, hit_ids, B, k, out_ids, out_scores);
+    VS_HIP(hipGetLastError());
+    if (!stream) VS_HIP(hipStreamSynchronize(s));
+    return VS_OK;
+}
 
 extern "C" int vs_elu1p(const float* x, int64_t n, float* out, int device, void* stream) {
     if (!x || !out || n < 0) return fail(VS_EINVAL, "bad argument");

@@ -102,16 +102,36 @@ class Retriever(BiEncoder):
     retrieve_negatives = retireve_negatives
 
     def _rerank(self, index: Index, q_emb: T, results: SearchResults, k: int, batch_size: int) -> SearchResults:
-        """Re-embed the k hits with encoder_p, score against q, re-sort (retriever.py:137-147)."""
+        """Re-embed the k hits with encoder_p, score against q, re-sort (retriever.py:137-147) -- on the device:
+        ``vs_rerank_scores`` per re-embedding batch (the reference's dense [B*k, V] tensor is never held) and
+        ``vs_rerank_topk`` for the order (score descending; equal scores keep their first-stage order)."""
+        import ctypes as C
+        from ... import _native as nat
+        from ...device_index import current_stream
         hit_ids = results.ids
+        B = int(hit_ids.shape[0])
         texts = [index.get_sample(i) for i in hit_ids.flatten().tolist()]
-        p_emb = self.encoder_p.embed(texts, batch_size=batch_size, require_grad=False)
-        dev = p_emb.device
-        q = q_emb.to(dev).to(p_emb.dtype)
-        scores = torch.einsum("bkv,bv->bk", p_emb.view(q.shape[0], k, q.shape[-1]), q).cpu()
-        # canonical order among equal rerank scores: earlier first-stage rank first
-        order = torch.argsort(-scores.double(), dim=1, stable=True)
-        return SearchResults(torch.gather(hit_ids.cpu(), 1, order), torch.gather(scores, 1, order))
+        nat.require_device()
+        dev = hit_ids.device if hit_ids.is_cuda else torch.device("cuda", 0)
+        ordinal = dev.index or 0
+        stream = current_stream(ordinal)
+        q = q_emb.to(dev).to(torch.float32).contiguous()
+        ids_dev = hit_ids.to(dev).contiguous()
+        scores = torch.empty((B, k), dtype=torch.float32, device=dev)
+        chunk = max(int(batch_size), 1) * 32               # re-embedded passages held at a time
+        for r0 in range(0, B * k, chunk):
+            p_emb = self.encoder_p.embed(texts[r0:r0 + chunk], batch_size=batch_size, require_grad=False)
+            if p_emb.dtype not in (torch.float32, torch.float16):
+                p_emb = p_emb.to(torch.float32)
+            p_emb = p_emb.to(dev).contiguous()
+            nat.check(nat.lib().vs_rerank_scores(C.c_void_p(p_emb.data_ptr()), nat.VS_F16 if p_emb.dtype == torch.float16 else nat.VS_F32,
+                                                 int(p_emb.shape[1]), int(p_emb.shape[0]), r0, C.c_void_p(q.data_ptr()), int(q.shape[1]), B, int(k),
+                                                 int(q.shape[1]), C.c_void_p(scores.data_ptr()), ordinal, stream))
+        out_ids = torch.empty_like(ids_dev)
+        out_scores = torch.empty_like(scores)
+        nat.check(nat.lib().vs_rerank_topk(C.c_void_p(scores.data_ptr()), C.c_void_p(ids_dev.data_ptr()), B, int(k), C.c_void_p(out_ids.data_ptr()),
+                                           C.c_void_p(out_scores.data_ptr()), ordinal, stream))
+        return SearchResults(out_ids, out_scores)
 
     # ---- index build (retriever.py:208-317) ----------------------------------------------------------
     def _tokenize_for_bot(self, texts: List[str], max_len: int):

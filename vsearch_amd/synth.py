@@ -26,6 +26,7 @@ _M64 = (1 << 64) - 1
 
 KIND_VDR = 0       # fixed nnz per row, fp32 values
 KIND_BOT = 1       # binary, variable nnz
+KIND_SKEW = 2      # fixed nnz per row, fp32 values, column popularity ~ 1 / rank (Zipf s = 1 with a saturated head)
 VAL_GRID = 0       # (164 + h % 49152) / 16384
 VAL_DYADIC = 1     # (1 + h % 255) / 64
 VAL_ONE = 2        # 1.0
@@ -76,9 +77,49 @@ def perm_cols(key, j, n_cols):
     return x
 
 
+def skew_cols(key, j, lens, n_cols):
+    """KIND_SKEW: element j of a row of `lens` non-zeros (arrays) -> column id; twin of synth_skew_col
+    (vsearch_amd/csrc/synth_device.h): ranks 1..127 always, equal counts from every octave [2^k, 2^(k+1)) above."""
+    j = np.asarray(j, dtype=np.int64)
+    lens = np.asarray(lens, dtype=np.int64)
+    key = np.asarray(key, dtype=U64)
+    head = 127
+    kmax = 0
+    while (2 << kmax) <= n_cols:
+        kmax += 1
+    rank = j + 1
+    if kmax >= 8:
+        gen = (lens > head + 8) & (j >= head)
+        if gen.any():
+            n_oct = kmax - 7 + 1
+            per = (lens[gen] - head) // n_oct
+            t = j[gen] - head
+            o = np.minimum(t // per, n_oct - 1)
+            i = (t - o * per).astype(U64)
+            k = 7 + o
+            lo = (np.int64(1) << k)
+            size = np.where((np.int64(2) << k) <= n_cols + 1, lo, n_cols + 1 - lo)
+            mask = (lo - 1).astype(U64)
+            with np.errstate(over="ignore"):
+                h = splitmix64(key[gen] + U64(0x9E3779B97F4A7C15) * (k + 1).astype(U64))
+            odd = (h & U64(0xFFFFFFFF)) | U64(1)
+            add = h >> U64(32)
+            x = i.copy()
+            todo = np.ones(x.shape, dtype=bool)
+            while todo.any():
+                with np.errstate(over="ignore"):
+                    nx = ((x * odd + add) & U64(0xFFFFFFFF)) & mask        # 32-bit arithmetic, then the octave mask
+                x = np.where(todo, nx, x)
+                todo = todo & (x >= size.astype(U64))
+            rank = rank.copy()
+            rank[gen] = lo + x.astype(np.int64)
+    gkey = np.full(rank.shape, 0x5A495046534B4557, dtype=U64)
+    return perm_cols(gkey, (rank - 1).astype(U32), n_cols)
+
+
 def row_lengths(seed, rows, kind, nnz):
     rows = np.asarray(rows, dtype=np.int64)
-    if kind == KIND_VDR:
+    if kind in (KIND_VDR, KIND_SKEW):
         return np.full(rows.shape, nnz, dtype=np.int64)
     h = hash3(seed, rows, 0x4C454E)  # "LEN"
     # 4 x 16-bit uniforms -> Irwin-Hall; mean = 1 + 4*0.5*(nnz-1)*0.5 ... scaled so mean == nnz
@@ -114,7 +155,10 @@ def synth_csr(seed, row0, n_rows, n_cols=29523, nnz=768, kind=KIND_VDR, val_law=
     row_of = np.repeat(rows, lens)
     j = np.arange(total, dtype=np.int64) - np.repeat(indptr[:-1], lens)
     key = hash3(seed, row_of, 0x4B4559)  # "KEY"
-    cols = perm_cols(key, j, n_cols).astype(np.int64)
+    if kind == KIND_SKEW:
+        cols = skew_cols(key, j, np.repeat(lens, lens), n_cols).astype(np.int64)
+    else:
+        cols = perm_cols(key, j, n_cols).astype(np.int64)
     # sort columns within each row (canonical CSR): composite key sort
     order = np.argsort(row_of * 65536 + cols, kind="stable")
     cols = cols[order]
@@ -125,9 +169,9 @@ def synth_csr(seed, row0, n_rows, n_cols=29523, nnz=768, kind=KIND_VDR, val_law=
     return indptr, cols.astype(np.int32), data
 
 
-def synth_queries(seed, n_q, n_cols=29523, nnz_q=776, val_law=VAL_GRID, q0=0):
-    """Dense [n_q, n_cols] float32 query matrix, nnz_q non-zeros per row."""
-    indptr, cols, data = synth_csr(seed, q0, n_q, n_cols, nnz_q, KIND_VDR, val_law)
+def synth_queries(seed, n_q, n_cols=29523, nnz_q=776, val_law=VAL_GRID, q0=0, kind=KIND_VDR):
+    """Dense [n_q, n_cols] float32 query matrix, nnz_q non-zeros per row (kind: KIND_VDR | KIND_SKEW column law)."""
+    indptr, cols, data = synth_csr(seed, q0, n_q, n_cols, nnz_q, kind, val_law)
     q = np.zeros((n_q, n_cols), dtype=np.float32)
     rows = np.repeat(np.arange(n_q), np.diff(indptr))
     q[rows, cols] = data
