@@ -447,6 +447,31 @@ def test_native_shard_file_roundtrip(tmp_path):
     (tmp_path / "bad.vsx").write_bytes(b"not a shard file")
     with pytest.raises(ValueError, match="native shard"):
         SparseIndex(str(tmp_path / "bad.vsx"), None, device="cuda")
+    # the file is searched as it is: the loader checks what the scan kernels rely on
+    raw = (tmp_path / "a.vsx").read_bytes()
+    hdr = 8 + 4 + 4 + 8 + 8 + 8 + 32                                     # magic, store_dtype, n_cols, n_rows, n_packets, nnz, reserved
+    n_pk = int(np.frombuffer(raw, dtype=np.int64, count=1, offset=24)[0])
+    cases = {
+        "truncated": raw[:-100],                                                                   # payload shorter than the header says
+        "padded": raw + b"\0" * 64,
+        "rowptr": raw[:hdr + 8] + (2 ** 31).to_bytes(4, "little") + raw[hdr + 12:],                # pk_ptr[2] beyond the packets
+        "column": raw[:hdr + (n + 1) * 4] + (V + 5).to_bytes(2, "little") + raw[hdr + (n + 1) * 4 + 2:],   # a column id above n_cols
+        "pad-inside": raw[:hdr + (n + 1) * 4] + V.to_bytes(2, "little") + raw[hdr + (n + 1) * 4 + 2:],     # a pad column at a row's start
+        "nnz": raw[:32] + (int(ip[-1]) + 8).to_bytes(8, "little") + raw[40:],                       # header nnz != payload
+    }
+    assert n_pk * 16 < len(raw)
+    for name, blob in cases.items():
+        (tmp_path / f"{name}.vsx").write_bytes(blob)
+        with pytest.raises(ValueError):
+            SparseIndex(str(tmp_path / f"{name}.vsx"), None, device="cuda")
+            pytest.fail(f"corrupt file '{name}' was accepted")
+    # a file is the index kind it was saved as: no valued file into a BoTIndex, no binary file into a SparseIndex, no shift
+    with pytest.raises(ValueError, match="valued"):
+        BoTIndex(str(tmp_path / "a.vsx"), None, device="cuda")
+    with pytest.raises(ValueError, match="binary"):
+        SparseIndex(str(tmp_path / "b.vsx"), None, device="cuda")
+    with pytest.raises(ValueError, match="shift"):
+        SparseIndex(str(tmp_path / "a.vsx"), None, device="cuda", shift=999)
 
 
 def test_retireve_negatives(tiny_retriever):

@@ -237,4 +237,5 @@ struct vs_index {
     int qt_pref = 0;     // 0 = auto (multi-query pass when the batch qualifies), 1 = force the dense-image pass
     int last_qt = 0;     // queries per pass of the most recent search
     int cu_count = 256;
+    double load_GBps = 0.0;   // vs_index_load_native: file -> HBM rate of the load that created this handle
 };

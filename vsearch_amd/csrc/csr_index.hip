@@ -8,6 +8,7 @@
 #include "synth_device.h"
 
 #include <algorithm>
+#include <chrono>
 
 using namespace vs;
 
@@ -1420,15 +1421,74 @@ int copy_dev_to_file(FILE* f, const void* dev, size_t bytes) {
     }
     return VS_OK;
 }
-int copy_file_to_dev(FILE* f, void* dev, size_t bytes) {
-    const size_t chunk = (size_t)64 << 20;
-    std::vector<char> host(std::min(bytes, chunk));
-    for (size_t off = 0; off < bytes; off += chunk) {
-        const size_t n = std::min(chunk, bytes - off);
-        if (fread(host.data(), 1, n, f) != n) return fail(VS_EINVAL, "short read: truncated .vsx file");
-        VS_HIP(hipMemcpy((char*)dev + off, host.data(), n, hipMemcpyHostToDevice));
+// file -> device through two pinned 64 MB buffers: the read of chunk i + 1 overlaps the DMA of chunk i
+struct PinnedPair {
+    void* buf[2] = {nullptr, nullptr};
+    hipEvent_t done[2] = {nullptr, nullptr};
+    hipStream_t stream = nullptr;
+    size_t chunk = (size_t)64 << 20;
+    bool busy[2] = {false, false};
+    int init() {
+        for (int i = 0; i < 2; ++i) {
+            VS_HIP(hipHostMalloc(&buf[i], chunk, hipHostMallocDefault));
+            VS_HIP(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
+        }
+        VS_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        return VS_OK;
+    }
+    ~PinnedPair() {
+        if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
+        for (int i = 0; i < 2; ++i) {
+            if (done[i]) (void)hipEventDestroy(done[i]);
+            if (buf[i]) (void)hipHostFree(buf[i]);
+        }
+    }
+};
+int copy_file_to_dev(FILE* f, void* dev, size_t bytes, PinnedPair& pp, int* turn) {
+    for (size_t off = 0; off < bytes; off += pp.chunk) {
+        const size_t n = std::min(pp.chunk, bytes - off);
+        const int b = *turn;
+        if (pp.busy[b]) VS_HIP(hipEventSynchronize(pp.done[b]));              // the DMA that last used this buffer has finished
+        if (fread(pp.buf[b], 1, n, f) != n) return fail(VS_EINVAL, "short read: truncated .vsx file");
+        VS_HIP(hipMemcpyAsync((char*)dev + off, pp.buf[b], n, hipMemcpyHostToDevice, pp.stream));
+        VS_HIP(hipEventRecord(pp.done[b], pp.stream));
+        pp.busy[b] = true;
+        *turn = b ^ 1;
     }
     return VS_OK;
+}
+
+// A loaded shard file is searched as is: check what the scan kernels rely on.  flags: |1 row pointers not monotone / last != packets,
+// |2 a column id above n_cols, |4 a real column after a pad column inside a row, |8 pad column outside a row's last packet;
+// nnz_out = non-pad column slots.
+template <int UNUSED>
+__global__ __launch_bounds__(256) void validate_packets_kernel(const uint32_t* pk_ptr, const uint16_t* cols, int64_t n_rows, int64_t n_packets, int32_t n_cols,
+                                                               int* flags, unsigned long long* nnz_out) {
+    unsigned long long nnz = 0;
+    int bad = 0;
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n_rows; r += (int64_t)gridDim.x * 256) {
+        const uint32_t p0 = pk_ptr[r], p1 = pk_ptr[r + 1];
+        if (p1 < p0 || (int64_t)p1 > n_packets) { bad |= 1; continue; }
+        bool seen_pad = false;
+        for (uint32_t p = p0; p < p1; ++p) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const uint32_t c = cols[(size_t)p * 8 + i];
+                if (c > (uint32_t)n_cols) bad |= 2;
+                if (c == (uint32_t)n_cols) {
+                    seen_pad = true;
+                    if (p + 1 != p1) bad |= 8;
+                } else {
+                    if (seen_pad) bad |= 4;
+                    ++nnz;
+                }
+            }
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && (pk_ptr[0] != 0u || (int64_t)pk_ptr[n_rows] != n_packets)) bad |= 1;
+    if (bad) atomicOr(flags, bad);
+    for (int o = 32; o > 0; o >>= 1) nnz += __shfl_xor(nnz, o, 64);
+    if ((threadIdx.x & 63) == 0 && nnz) atomicAdd(nnz_out, nnz);
 }
 }  // namespace
 
@@ -1463,13 +1523,51 @@ extern "C" int vs_index_load_native(const char* path, int device, vs_index** out
     VsxHeader h{};
     if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "VSXCSR1", 8) != 0) return fail(VS_EINVAL, "%s is not a vsearch native shard file", path);
     VS_TRY(check_csr_shape(h.n_rows, h.n_cols, h.store_dtype));
-    if (h.n_packets < 0 || h.n_packets >= (1ll << 32)) return fail(VS_EINVAL, "corrupt header");
+    if (h.n_packets < 0 || h.n_packets >= (1ll << 32) || h.nnz < 0 || h.nnz > h.n_packets * 8) return fail(VS_EINVAL, "corrupt header");
+    // the payload must be exactly what the header announces
+    const size_t b_ptr = (size_t)(h.n_rows + 1) * 4, b_cols = (size_t)h.n_packets * 16,
+                 b_vals = h.store_dtype == VS_NONE ? 0 : (size_t)h.n_packets * (h.store_dtype == VS_F32 ? 32 : 16);
+    {
+        const long here = ftell(f);
+        if (fseek(f, 0, SEEK_END) != 0) return fail(VS_EINVAL, "cannot seek in %s", path);
+        const long long end = ftell(f);
+        if (fseek(f, here, SEEK_SET) != 0) return fail(VS_EINVAL, "cannot seek in %s", path);
+        if ((unsigned long long)end != sizeof(h) + b_ptr + b_cols + b_vals)
+            return fail(VS_EINVAL, "%s: %lld bytes on disk, the header announces %zu (truncated or mismatched file)", path, end, sizeof(h) + b_ptr + b_cols + b_vals);
+    }
     vs_index* idx = nullptr;
     VS_TRY(vs_index_create_reserved(h.n_rows, h.n_packets, h.n_cols, h.store_dtype, device, &idx));
     struct Guard { vs_index* p; ~Guard() { if (p) vs_index_destroy(p); } } guard{idx};
-    VS_TRY(copy_file_to_dev(f, idx->pk_ptr.p, (size_t)(h.n_rows + 1) * 4));
-    VS_TRY(copy_file_to_dev(f, idx->cols.p, (size_t)h.n_packets * 16));
-    if (h.store_dtype != VS_NONE) VS_TRY(copy_file_to_dev(f, idx->vals.p, (size_t)h.n_packets * (h.store_dtype == VS_F32 ? 32 : 16)));
+    {
+        PinnedPair pp;
+        VS_TRY(pp.init());
+        int turn = 0;
+        const auto t0 = std::chrono::steady_clock::now();
+        VS_TRY(copy_file_to_dev(f, idx->pk_ptr.p, b_ptr, pp, &turn));
+        VS_TRY(copy_file_to_dev(f, idx->cols.p, b_cols, pp, &turn));
+        if (b_vals) VS_TRY(copy_file_to_dev(f, idx->vals.p, b_vals, pp, &turn));
+        VS_HIP(hipStreamSynchronize(pp.stream));
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        idx->load_GBps = dt > 0 ? (double)(b_ptr + b_cols + b_vals) / dt / 1e9 : 0.0;
+        if (getenv("VS_VERBOSE")) fprintf(stderr, "[vsearch_hip] %s: %.2f GB in %.2f s = %.2f GB/s (file -> pinned -> HBM)\n", path,
+                                          (double)(b_ptr + b_cols + b_vals) / 1e9, dt, idx->load_GBps);
+    }
+    // the scan kernels index LDS tables by column id and walk packets by the row pointers: refuse a payload that would send them astray
+    {
+        DevBuf chk;
+        VS_TRY(chk.alloc(16));
+        VS_HIP(hipMemset(chk.p, 0, 16));
+        const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div64(h.n_rows, 256), 8192));
+        hipLaunchKernelGGL(validate_packets_kernel<0>, dim3(grid), dim3(256), 0, 0, idx->pk_ptr.as<uint32_t>(), idx->cols.as<uint16_t>(), h.n_rows, h.n_packets,
+                           h.n_cols, chk.as<int>(), reinterpret_cast<unsigned long long*>(chk.as<char>() + 8));
+        VS_HIP(hipGetLastError());
+        struct { int flags; int pad; unsigned long long nnz; } res;
+        VS_HIP(hipMemcpy(&res, chk.p, 16, hipMemcpyDeviceToHost));
+        if (res.flags & 1) return fail(VS_EINVAL, "%s: row pointers are not monotone or do not end at %lld packets", path, (long long)h.n_packets);
+        if (res.flags & 2) return fail(VS_EINVAL, "%s: column id above n_cols = %d", path, h.n_cols);
+        if (res.flags & 12) return fail(VS_EINVAL, "%s: pad columns inside a row (rows are padded at their tail only)", path);
+        if ((long long)res.nnz != h.nnz) return fail(VS_EINVAL, "%s: %llu non-zeros in the payload, the header says %lld", path, res.nnz, (long long)h.nnz);
+    }
     idx->n_rows = h.n_rows;
     idx->n_packets = h.n_packets;
     idx->nnz = h.nnz;

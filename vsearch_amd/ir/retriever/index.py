@@ -84,6 +84,17 @@ class Index:
             self._dev.close()
         self._dev = None
 
+    def adopt_device_index(self, dev: DeviceIndex, dtype=torch.float32, device: Optional[str] = None):
+        """Take ownership of an index already built in HBM (Retriever.build_index emits the CSR per batch straight into the
+        device format): `vector` is exported from it on demand."""
+        self._drop_device()
+        info = dev.info()
+        self._vector = None
+        self._dev = dev
+        self._dtype = dtype
+        self._shape = (int(info.n_rows), int(info.n_cols))
+        self.device = device or f"cuda:{info.device}"
+
     def _export_vector(self):
         mat = self._dev.export_dense(np.float16 if self._dtype == torch.float16 else np.float32)
         return torch.from_numpy(mat).to(self.device)
@@ -133,7 +144,7 @@ class Index:
         logger.info("Moving index to %s.", device)
         if self._vector is not None:
             self._vector = self._vector.to(device)
-        same_gpu = self._dev is not None and self._dev.info().device == _gpu_ordinal(device)
+        same_gpu = self._dev is not None and self._dev.device == _gpu_ordinal(device)
         if not same_gpu:
             if self._vector is None and self._dev is not None:
                 self._vector = self._export_vector()
@@ -172,7 +183,7 @@ class Index:
         if isinstance(q_embs, np.ndarray):
             q_embs = torch.from_numpy(q_embs)
         dev_index = self._device_index()
-        gpu = torch.device("cuda", dev_index.info().device)
+        gpu = torch.device("cuda", dev_index.device)         # (cached: info() reads search statistics and synchronises)
         q = q_embs.detach().to(gpu)
         q = q.to(self._dtype) if self._dtype in (torch.float16, torch.float32) else q.float()   # `.type(self.vector.dtype)`
         if q.dim() == 1:
@@ -281,6 +292,20 @@ class SparseIndex(Index):
             self._vector = None
             self._dev = DeviceIndex.load_native(files[0], device=_gpu_ordinal(self.device))
             info = self._dev.info()
+            # the file holds the device format verbatim: it must be the kind of index this class searches
+            if info.kind != nat.VS_KIND_CSR:
+                self._drop_device()
+                raise ValueError(f"{files[0]} holds a dense index (sparsity-aware dense store): load it with Index, not {type(self).__name__}")
+            if self._binary() != (info.store_dtype == nat.VS_NONE):
+                kind = "binary (bag-of-token)" if info.store_dtype == nat.VS_NONE else "valued"
+                self._drop_device()
+                raise ValueError(f"{files[0]} holds a {kind} index: it cannot be loaded as {type(self).__name__}")
+            if self.shift:
+                self._drop_device()
+                raise ValueError("a native .vsx shard stores the columns after the shift was applied: load it with shift=0 "
+                                 f"(got shift={self.shift}); convert from .npz shards to change it")
+            if not fp16 and info.store_dtype == nat.VS_F16:
+                logger.warning("%s stores fp16 values; fp16=False cannot restore fp32 precision", files[0])
             self._dtype = torch.float32 if info.store_dtype == nat.VS_F32 else torch.float16
             self._shape = (info.n_rows, info.n_cols)
             return

@@ -173,8 +173,34 @@ class Retriever(BiEncoder):
         return torch.cat(parts, dim=0)
 
     def _build_embedding_csr(self, texts: List[str], batch_size: int = 32, max_len: int = 128):
-        """Same embeddings as `_build_embedding_vectors(...).to_sparse_csr()` (retriever.py:303-304), emitted
-        as CSR per batch on the GPU: the dense [N, V] fp32 matrix (118 KB per passage) is never held."""
+        """Same embeddings as `_build_embedding_vectors(...).to_sparse_csr()` (retriever.py:303-304), emitted as CSR per batch
+        on the GPU and appended to the index IN HBM (``vs_index_append_csr`` takes the device pointers): neither the dense
+        [N, V] fp32 matrix (118 KB per passage) nor a host copy of the CSR pieces is ever held.  -> DeviceIndex."""
+        from ...device_index import DeviceIndex
+        from ... import _native as nat
+        n = len(texts)
+        dev_index, row_cap, pk_cap = None, n, 0
+        pending = []                                        # batches embedded before the first reservation / beyond it
+        for s in range(0, n, batch_size):
+            emb = self.encode_corpus(texts[s:s + batch_size], batch_size=batch_size, max_len=max_len, convert_to_tensor=True)
+            rp, ci, va = sp.dense_to_csr(emb.float().contiguous())        # device tensors
+            if dev_index is None:
+                # reserve from the first batch: the encoder keeps at most topk (+ the lexical tokens) non-zeros per passage
+                per_row = int((rp[1:] - rp[:-1]).max().item()) if rp.numel() > 1 else 0
+                bound = max(per_row, int(getattr(getattr(self.encoder_p, "config", None), "topk", 0) or 0)) + int(max_len)
+                pk_cap = n * ((min(bound, emb.shape[1]) + 7) // 8)
+                dev_index = DeviceIndex.reserved(row_cap, max(pk_cap, 1), int(emb.shape[1]), nat.VS_F32, device=emb.device.index or 0)
+            try:
+                dev_index.append_csr(rp, ci, va)
+            except (nat.VsearchNativeError, ValueError):
+                pending.append((rp.cpu(), ci.cpu(), va.cpu(), s))          # a passage denser than the bound: rebuild with exact sizes
+                break
+        if pending:
+            return None
+        return dev_index
+
+    def _build_embedding_csr_host(self, texts: List[str], batch_size: int = 32, max_len: int = 128):
+        """Fallback of `_build_embedding_csr` (a passage denser than the reservation bound): CSR pieces gathered on the host."""
         ptrs, cols, vals, base, V = [torch.zeros(1, dtype=torch.int64)], [], [], 0, None
         for s in range(0, len(texts), batch_size):
             emb = self.encode_corpus(texts[s:s + batch_size], batch_size=batch_size, max_len=max_len, convert_to_tensor=True)
@@ -199,7 +225,11 @@ class Retriever(BiEncoder):
         elif index_type == IndexType.SPARSE:
             self.index = SparseIndex()
             self.index.data = texts
-            self.index.vector = self._build_embedding_csr(texts, batch_size=batch_size)
+            built = self._build_embedding_csr(texts, batch_size=batch_size) if len(texts) else None
+            if built is not None:
+                self.index.adopt_device_index(built, dtype=torch.float32)
+            else:
+                self.index.vector = self._build_embedding_csr_host(texts, batch_size=batch_size)
         elif index_type == IndexType.BAG_OF_TOKEN:
             self.index = BoTIndex()
             self.index.data = texts
