@@ -174,6 +174,21 @@ VS_API int  vs_index_set_queries_per_pass(vs_index* index, int qt);
  *   "mq_variant"        -1 = auto (from the batch's query overlap), 0 = plain, 1 = shared-column variant of the 8-query scan */
 VS_API int  vs_index_set_option(vs_index* index, const char* name, int value);
 
+/* ---- row-sharded search in one process: one vs_index per GPU (the reference searches one index on one device,
+ * its only sharding precedent is the per-shard index build, examples/inference_sparse/README.md:90-107, index.py:172-175) -----
+ * `shards` are consecutive row ranges of one corpus (shard i holds rows [sum of n_rows of the shards before it, ...)), each on
+ * its own device; the group does not own them.  vs_shard_group_search scores the batch on every GPU concurrently, moves the
+ * B * k (id, score) pairs of each shard to the first shard's device with peer copies (xGMI), and merges there: the result is
+ * identical to searching the unsharded index (global ids, canonical order).  q: host pointer or device pointer on any GPU;
+ * outputs: host pointers or device pointers on the first shard's device.  Blocking.  Fewer than 2^32 - 1 documents in total.
+ * (One process per GPU with torch.distributed / RCCL uses vs_index_search's id_offset + vs_merge_topk instead:
+ * vsearch_amd/distributed.py.)                                                                                                */
+typedef struct vs_shard_group vs_shard_group;
+VS_API int  vs_shard_group_create(vs_index* const* shards, int32_t n_shards, vs_shard_group** out);
+VS_API int  vs_shard_group_search(vs_shard_group* group, const void* q, int q_dtype, int64_t ldq, int32_t B, int32_t k,
+                                  int64_t* out_ids, float* out_scores);
+VS_API void vs_shard_group_destroy(vs_shard_group* group);
+
 /* SparseIndex.save (index.py:181-202) needs crow/col/values back: int64 rowptr [n_rows+1], int64
  * colidx [nnz], values [nnz] as val_dtype (VS_F32 | VS_F16).  Pass NULL colidx/values to get rowptr
  * only (to size the other two).                                                                  */
@@ -183,6 +198,7 @@ VS_API void vs_index_destroy(vs_index* index);
 
 /* Row-sharded search, merge step (new in this build): candidates gathered from
  * all shards ([B, n_cand] global ids + scores, e.g. after an RCCL all-gather) -> canonical top-k. */
+/* (ids must be in [0, 2^32 - 1): the merge keys hold 32-bit ids; a candidate outside that range is dropped, never aliased) */
 VS_API int vs_merge_topk(const int64_t* cand_ids, const float* cand_scores, int32_t B, int64_t n_cand, int32_t k,
                          int64_t* out_ids, float* out_scores, int device, void* stream);
 
@@ -221,6 +237,10 @@ VS_API int vs_head_pool(const float* logits, int32_t B, int32_t L, int32_t V, fl
  * The reference's [B, L, V] logits tensor is never materialised.                                          */
 VS_API int vs_head_project_pool(const float* hidden, const float* W, int32_t B, int32_t L, int32_t H, int32_t V, float* out,
                                 int device, void* stream);
+
+/* VDREncoder.forward with pooling = "mean" and pooling_topk = t (vdr.py:76-79):
+ * out[b, c] = mean over the t largest elu1p(logits[b, l, c]), l < L.  logits [B, L, V], out [B, V]: device pointers, t <= 32. */
+VS_API int vs_head_pool_mean_topk(const float* logits, int32_t B, int32_t L, int32_t V, int32_t topk, float* out, int device, void* stream);
 
 /* ---- rerank of bag-of-token hits: Retriever.retrieve(rerank=True) (retriever.py:137-147) --------
  * The reference re-embeds the B * k hit texts with encoder_p into a dense [B * k, V] tensor, takes torch.bmm against the query

@@ -1,0 +1,6 @@
+"""`python -m inference.build_index.dense_index` -> vsearch_amd.inference.build_index.dense_index (same arguments)."""
+from vsearch_amd.inference.build_index.dense_index import *  # noqa: F401,F403
+from vsearch_amd.inference.build_index.dense_index import main
+
+if __name__ == "__main__":
+    main()

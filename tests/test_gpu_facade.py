@@ -490,3 +490,16 @@ def test_retireve_negatives(tiny_retriever):
     everything = [[t.split()[1] for t in texts]] * 3                            # every passage "answers": pool empty -> random padding
     padded = r.retrieve_negatives(q_emb, everything, ret_neg_num=3, ret_topk=10)
     assert all(len(n) == 3 and all(x in texts for x in n) for n in padded)
+
+
+def test_mean_pooling_with_pooling_topk():
+    """vdr.py:76-79 (pooling = "mean" with pooling_topk): mean of the t largest elu1p activations per vocabulary dimension."""
+    g = torch.Generator().manual_seed(3)
+    logits = (torch.randn((3, 37, 1000), generator=g) * 2).cuda()
+    for t in (1, 4, 32):
+        got = sp.head_pool_mean_topk(logits, t)
+        act = torch.where(logits > 0, logits + 1, torch.exp(logits))          # elu1p (sparse.py:6)
+        want = act.topk(t, dim=1).values.mean(1)
+        torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-6)
+    with pytest.raises(RuntimeError):
+        sp.head_pool_mean_topk(logits[:, :8], 9)

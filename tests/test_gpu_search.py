@@ -12,7 +12,7 @@ from oracle import compare
 from conftest import V
 from vsearch_amd import synth
 from vsearch_amd import _native as nat
-from vsearch_amd.device_index import DeviceIndex, merge_topk
+from vsearch_amd.device_index import DeviceIndex, ShardGroup, merge_topk
 
 pytestmark = pytest.mark.gpu
 
@@ -538,3 +538,25 @@ def test_blocked_postings_other_vocabulary_sizes(n_cols, qnnz):
     compare.check_topk_valid(allsc, ids, sc, rtol=RTOL)
     compare.compare_topk(o_ids, o_sc, ids, sc, rtol=RTOL)
     assert idx.info().last_path == 3
+
+
+@pytest.mark.parametrize("kind", [synth.KIND_VDR, synth.KIND_BOT], ids=["sparse", "bag-of-token"])
+def test_shard_group_equals_the_unsharded_index(kind):
+    """vs_shard_group_*: uneven consecutive row shards (one smaller than k), host and device queries; ids are global and the
+    result is the unsharded search bit for bit."""
+    import torch
+    n = 5000
+    nnz, law = (86, synth.VAL_DYADIC) if kind == synth.KIND_BOT else (768, synth.VAL_GRID)
+    cuts = [0, 40, 1900, 3100, n]
+    full = DeviceIndex.synthetic(7, 0, n, V, nnz, kind, 0, nat.VS_NONE if kind == synth.KIND_BOT else nat.VS_F32)
+    shards = [DeviceIndex.synthetic(7, a, b - a, V, nnz, kind, 0, nat.VS_NONE if kind == synth.KIND_BOT else nat.VS_F32) for a, b in zip(cuts[:-1], cuts[1:])]
+    group = ShardGroup(shards)
+    q = oracle.synth_queries(8, 9, val_law=law)
+    want_ids, want_sc = full.search(q, 100)
+    ids, sc = group.search(q, 100)
+    assert (ids == want_ids).all() and (sc == want_sc).all()
+    ids_d, sc_d = group.search(torch.from_numpy(q).cuda(), 100)
+    assert (ids_d.cpu().numpy() == want_ids).all() and (sc_d.cpu().numpy() == want_sc).all()
+    with pytest.raises(RuntimeError):
+        group.search(q, n + 1)
+    group.close()

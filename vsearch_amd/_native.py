@@ -52,6 +52,9 @@ _SIGNATURES = {
     "vs_index_export_csr": ([_vp, _vp, _vp, _vp, _int], _int),
     "vs_index_export_dense": ([_vp, _vp, _int, _i64], _int),
     "vs_index_destroy": ([_vp], None),
+    "vs_shard_group_create": ([C.POINTER(_vp), _i32, C.POINTER(_vp)], _int),
+    "vs_shard_group_search": ([_vp, _vp, _int, _i64, _i32, _i32, _vp, _vp], _int),
+    "vs_shard_group_destroy": ([_vp], None),
     "vs_merge_topk": ([_vp, _vp, _i32, _i64, _i32, _vp, _vp, _int, _vp], _int),
     "vs_topk_mask": ([_vp, _i32, _i32, _i64, _i32, _vp, _int, _vp], _int),
     "vs_bow_mask": ([_vp, _i32, _i32, _i32, _i32, _int, _vp, _int, _vp], _int),
@@ -60,6 +63,7 @@ _SIGNATURES = {
     "vs_head_pool": ([_vp, _i32, _i32, _i32, _vp, _int, _vp], _int),
     "vs_head_project_pool": ([_vp, _vp, _i32, _i32, _i32, _i32, _vp, _int, _vp], _int),
     "vs_elu1p": ([_vp, _i64, _vp, _int, _vp], _int),
+    "vs_head_pool_mean_topk": ([_vp, _i32, _i32, _i32, _i32, _vp, _int, _vp], _int),
     "vs_rerank_scores": ([_vp, _int, _i64, _i64, _i64, _vp, _i64, _i32, _i32, _i32, _vp, _int, _vp], _int),
     "vs_rerank_topk": ([_vp, _vp, _i32, _i32, _vp, _vp, _int, _vp], _int),
     "vs_bot_build": ([_vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp], _int),

@@ -119,6 +119,135 @@ extern "C" int vs_index_set_option(vs_index* idx, const char* name, int value) {
     return fail(VS_EINVAL, "unknown option '%s'", name);
 }
 
+// ---- row-sharded search inside ONE process: one vs_index per GPU, no RCCL -- the exchange is B * k (id, score)
+// pairs per shard, moved with peer copies over xGMI to the first shard's device and merged there.
+struct vs_shard_group {
+    std::vector<vs_index*> shards;
+    std::vector<int64_t> row0;
+    std::vector<hipStream_t> streams;
+    std::vector<hipEvent_t> done;
+    std::vector<vs::DevBuf*> q, ids, sc;      // per shard, on the shard's device
+    vs::DevBuf all_ids, all_sc, out_ids, out_sc;   // on shards[0]'s device
+    int64_t n_total = 0;
+};
+
+extern "C" void vs_shard_group_destroy(vs_shard_group* g) {
+    if (!g) return;
+    for (size_t i = 0; i < g->shards.size(); ++i) {
+        (void)hipSetDevice(g->shards[i]->device);
+        if (i < g->streams.size() && g->streams[i]) { (void)hipStreamSynchronize(g->streams[i]); (void)hipStreamDestroy(g->streams[i]); }
+        if (i < g->done.size() && g->done[i]) (void)hipEventDestroy(g->done[i]);
+        if (i < g->q.size()) delete g->q[i];
+        if (i < g->ids.size()) delete g->ids[i];
+        if (i < g->sc.size()) delete g->sc[i];
+    }
+    if (!g->shards.empty()) (void)hipSetDevice(g->shards[0]->device);
+    delete g;
+}
+
+extern "C" int vs_shard_group_create(vs_index* const* shards, int32_t n_shards, vs_shard_group** out) {
+    if (!shards || !out || n_shards <= 0) return fail(VS_EINVAL, "bad argument");
+    *out = nullptr;
+    vs_shard_group* g = new vs_shard_group();
+    struct Guard { vs_shard_group* p; ~Guard() { if (p) vs_shard_group_destroy(p); } } guard{g};
+    int64_t row = 0;
+    for (int i = 0; i < n_shards; ++i) {
+        vs_index* s = shards[i];
+        if (!s) return fail(VS_EINVAL, "shard %d is NULL", i);
+        if (s->n_cols != shards[0]->n_cols) return fail(VS_EINVAL, "shard %d has %d columns, shard 0 has %d", i, s->n_cols, shards[0]->n_cols);
+        g->shards.push_back(s);
+        g->row0.push_back(row);
+        row += s->n_rows;
+        VS_HIP(hipSetDevice(s->device));
+        hipStream_t st = nullptr;
+        hipEvent_t ev = nullptr;
+        VS_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        g->streams.push_back(st);
+        VS_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        g->done.push_back(ev);
+        g->q.push_back(new vs::DevBuf());
+        g->ids.push_back(new vs::DevBuf());
+        g->sc.push_back(new vs::DevBuf());
+    }
+    if (row >= 0xFFFFFFFFll) return fail(VS_EUNSUPPORTED, "a shard group addresses fewer than 2^32 - 1 documents (%lld given): merged ids are 32-bit", (long long)row);
+    g->n_total = row;
+    guard.p = nullptr;
+    *out = g;
+    return VS_OK;
+}
+
+extern "C" int vs_shard_group_search(vs_shard_group* g, const void* q, int q_dtype, int64_t ldq, int32_t B, int32_t k, int64_t* out_ids, float* out_scores) {
+    if (!g || !q || !out_ids || !out_scores) return fail(VS_EINVAL, "NULL argument");
+    if (B <= 0 || k <= 0) return fail(VS_EINVAL, "B and k must be positive");
+    if (k > g->n_total) return fail(VS_ERANGE, "selected index k out of range (k = %d > %lld rows)", k, (long long)g->n_total);
+    if (q_dtype != VS_F32 && q_dtype != VS_F16) return fail(VS_EINVAL, "q_dtype must be VS_F32 or VS_F16");
+    const int n = (int)g->shards.size();
+    const int V = g->shards[0]->n_cols;
+    if (ldq < V) return fail(VS_EINVAL, "query has %lld columns, index has %d", (long long)ldq, V);
+    const size_t esz = dtype_size(q_dtype);
+    const size_t q_bytes = ((size_t)(B - 1) * ldq + V) * esz;
+    const bool q_dev = is_device_ptr(q);
+    int q_device = 0;
+    if (q_dev) {
+        hipPointerAttribute_t attr;
+        VS_HIP(hipPointerGetAttributes(&attr, q));
+        q_device = attr.device;
+    }
+    // 1. every shard scores the whole batch on its own GPU and stream (asynchronous on the postings filter path)
+    std::vector<int> ki((size_t)n);
+    int64_t k_tot = 0;
+    for (int i = 0; i < n; ++i) {
+        vs_index* s = g->shards[i];
+        ki[i] = (int)std::min<int64_t>(k, s->n_rows);
+        k_tot += ki[i];
+        if (ki[i] == 0) continue;
+        VS_HIP(hipSetDevice(s->device));
+        const void* dq = q;
+        if (!q_dev || q_device != s->device) {
+            VS_TRY(g->q[i]->reserve(q_bytes));
+            if (q_dev) VS_HIP(hipMemcpyPeerAsync(g->q[i]->p, s->device, q, q_device, q_bytes, g->streams[i]));
+            else VS_HIP(hipMemcpyAsync(g->q[i]->p, q, q_bytes, hipMemcpyHostToDevice, g->streams[i]));
+            dq = g->q[i]->p;
+        }
+        VS_TRY(g->ids[i]->reserve((size_t)B * ki[i] * 8));
+        VS_TRY(g->sc[i]->reserve((size_t)B * ki[i] * 4));
+        VS_TRY(vs_index_search(s, dq, q_dtype, ldq, B, ki[i], g->row0[i], g->ids[i]->as<int64_t>(), g->sc[i]->as<float>(), (void*)g->streams[i]));
+        VS_HIP(hipEventRecord(g->done[i], g->streams[i]));
+    }
+    // 2. the exchange: every shard's [B, k_i] block lands in columns of the [B, sum k_i] candidate matrix on the first shard's GPU
+    vs_index* s0 = g->shards[0];
+    VS_HIP(hipSetDevice(s0->device));
+    hipStream_t st0 = g->streams[0];
+    VS_TRY(g->all_ids.reserve((size_t)B * k_tot * 8));
+    VS_TRY(g->all_sc.reserve((size_t)B * k_tot * 4));
+    int64_t col = 0;
+    for (int i = 0; i < n; ++i) {
+        if (ki[i] == 0) continue;
+        if (i > 0) VS_HIP(hipStreamWaitEvent(st0, g->done[i], 0));
+        VS_HIP(hipMemcpy2DAsync(g->all_ids.as<int64_t>() + col, (size_t)k_tot * 8, g->ids[i]->p, (size_t)ki[i] * 8, (size_t)ki[i] * 8, (size_t)B, hipMemcpyDefault, st0));
+        VS_HIP(hipMemcpy2DAsync(g->all_sc.as<float>() + col, (size_t)k_tot * 4, g->sc[i]->p, (size_t)ki[i] * 4, (size_t)ki[i] * 4, (size_t)B, hipMemcpyDefault, st0));
+        col += ki[i];
+    }
+    // 3. merge on the first shard's GPU (canonical order: identical to searching the unsharded index)
+    const bool out_dev = is_device_ptr(out_ids);
+    if (out_dev != is_device_ptr(out_scores)) return fail(VS_EINVAL, "out_ids and out_scores must both be host or both device pointers");
+    int64_t* d_ids = out_ids;
+    float* d_sc = out_scores;
+    if (!out_dev) {
+        VS_TRY(g->out_ids.reserve((size_t)B * k * 8));
+        VS_TRY(g->out_sc.reserve((size_t)B * k * 4));
+        d_ids = g->out_ids.as<int64_t>();
+        d_sc = g->out_sc.as<float>();
+    }
+    VS_TRY(vs_merge_topk(g->all_ids.as<int64_t>(), g->all_sc.as<float>(), B, k_tot, k, d_ids, d_sc, s0->device, (void*)st0));
+    if (!out_dev) {
+        VS_HIP(hipMemcpyAsync(out_ids, d_ids, (size_t)B * k * 8, hipMemcpyDeviceToHost, st0));
+        VS_HIP(hipMemcpyAsync(out_scores, d_sc, (size_t)B * k * 4, hipMemcpyDeviceToHost, st0));
+    }
+    VS_HIP(hipStreamSynchronize(st0));
+    return VS_OK;
+}
+
 extern "C" int vs_profile_enable(int on) {
     Profiler::get().on = on != 0;
     return VS_OK;

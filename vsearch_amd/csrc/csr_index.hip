@@ -153,9 +153,12 @@ __global__ void prep_queries_kernel(const T* q, int64_t ldq, int32_t B, int32_t 
     }
 }
 
+// keys hold 32-bit ids: a candidate whose id does not fit (or the pad sentinel 2^32 - 1) is dropped, never aliased to another document
 __global__ void keys_from_pairs_kernel(const int64_t* ids, const float* scores, int64_t n, uint64_t* keys) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        keys[i] = make_key(scores[i], (uint32_t)ids[i]);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t id = ids[i];
+        keys[i] = (id >= 0 && id < 0xFFFFFFFFll) ? make_key(scores[i], (uint32_t)id) : 0ull;
+    }
 }
 
 int pick_lanes_per_row(int64_t n_packets, int64_t n_rows) {

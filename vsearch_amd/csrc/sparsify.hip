@@ -34,6 +34,33 @@ __global__ void head_pool_kernel(const float* logits, int32_t B, int32_t L, int3
     }
 }
 
+// out[b, c] = mean of the `topk` largest elu1p(logits[b, :, c])   (vdr.py:76-79: pooling = "mean" with pooling_topk)
+constexpr int kPoolTopkMax = 32;
+__global__ void head_pool_mean_topk_kernel(const float* logits, int32_t B, int32_t L, int32_t V, int32_t topk, float* out) {
+    const int64_t n = (int64_t)B * V;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / V, c = i % V;
+        const float* p = logits + (size_t)b * L * V + c;
+        float top[kPoolTopkMax];                            // ascending: top[0] = smallest kept
+        int have = 0;
+        for (int l = 0; l < L; ++l) {
+            const float v = p[(size_t)l * V];
+            if (have < topk) {
+                int j = have++;
+                while (j > 0 && top[j - 1] > v) { top[j] = top[j - 1]; --j; }
+                top[j] = v;
+            } else if (v > top[0]) {
+                int j = 0;
+                while (j + 1 < topk && top[j + 1] < v) { top[j] = top[j + 1]; ++j; }
+                top[j] = v;
+            }
+        }
+        float sum = 0.f;
+        for (int j = have - 1; j >= 0; --j) sum += elu1p_dev(top[j]);       // largest first: torch.topk(...).values.mean(1) adds in that order
+        out[i] = sum / (float)have;
+    }
+}
+
 struct MaskArgs {
     float* emb;            // [B, V] (ld) in/out; may be null when only `mask` is wanted from x
     const float* x;        // source values (== emb for in-place)
@@ -276,6 +303,20 @@ __global__ __launch_bounds__(kSpThreads) void rerank_topk_kernel(const float* sc
 }
 
 }  // namespace
+
+extern "C" int vs_head_pool_mean_topk(const float* logits, int32_t B, int32_t L, int32_t V, int32_t topk, float* out, int device, void* stream) {
+    if (!logits || !out || B <= 0 || L <= 0 || V <= 0) return fail(VS_EINVAL, "bad argument");
+    if (topk <= 0 || topk > kPoolTopkMax) return fail(VS_EUNSUPPORTED, "pooling_topk = %d (1..%d)", topk, kPoolTopkMax);
+    if (topk > L) return fail(VS_ERANGE, "selected index k out of range (pooling_topk = %d > %d positions)", topk, L);
+    if (!is_device_ptr(logits) || !is_device_ptr(out)) return fail(VS_EINVAL, "vs_head_pool_mean_topk takes device pointers");
+    VS_TRY(check_device(device));
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n = (int64_t)B * V;
+    hipLaunchKernelGGL(head_pool_mean_topk_kernel, dim3((unsigned)std::min<int64_t>(ceil_div64(n, 256), 16384)), dim3(256), 0, s, logits, B, L, V, topk, out);
+    VS_HIP(hipGetLastError());
+    if (!stream) VS_HIP(hipStreamSynchronize(s));
+    return VS_OK;
+}
 
 extern "C" int vs_rerank_scores(const void* p_emb, int p_dtype, int64_t ldp, int64_t n_rows, int64_t row0, const float* q, int64_t ldq, int32_t B,
                                 int32_t k, int32_t n_cols, float* scores, int device, void* stream) {

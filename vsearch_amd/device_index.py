@@ -220,6 +220,47 @@ class DeviceIndex:
         return out
 
 
+class ShardGroup:
+    """Row-sharded search inside one process (``vs_shard_group_*``): one DeviceIndex per GPU holding consecutive row ranges of one
+    corpus; search() scores the batch on every GPU, gathers B * k pairs per shard on the first shard's GPU and merges there."""
+
+    def __init__(self, shards):
+        nat.require_device()
+        self._shards = list(shards)                      # keep them alive: the group does not own the handles
+        arr = (C.c_void_p * len(self._shards))(*[s._h for s in self._shards])
+        h = C.c_void_p()
+        nat.check(nat.lib().vs_shard_group_create(arr, len(self._shards), C.byref(h)))
+        self._h = h
+
+    def search(self, q, k: int):
+        if q.ndim != 2:
+            raise ValueError("queries must be [B, V]")
+        p, dt, keep = as_arg(q, (nat.VS_F32, nat.VS_F16))
+        B, ldq, k = int(q.shape[0]), int(q.shape[1]), int(k)
+        if _is_torch(q) and q.is_cuda:
+            import torch
+            dev = torch.device("cuda", self._shards[0].device)
+            ids = torch.empty((B, k), dtype=torch.int64, device=dev)
+            sc = torch.empty((B, k), dtype=torch.float32, device=dev)
+            nat.check(nat.lib().vs_shard_group_search(self._h, p, dt, ldq, B, k, C.c_void_p(ids.data_ptr()), C.c_void_p(sc.data_ptr())))
+            return ids, sc
+        ids = np.empty((B, k), dtype=np.int64)
+        sc = np.empty((B, k), dtype=np.float32)
+        nat.check(nat.lib().vs_shard_group_search(self._h, p, dt, ldq, B, k, C.c_void_p(ids.ctypes.data), C.c_void_p(sc.ctypes.data)))
+        return ids, sc
+
+    def close(self):
+        if self._h:
+            nat.lib().vs_shard_group_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def merge_topk(cand_ids, cand_scores, k: int, device: int = 0):
     """Canonical top-k of gathered per-shard candidates [B, n_cand] (global ids + scores)."""
     nat.require_device()

@@ -7,6 +7,7 @@ from typing import Dict, List, Union
 from transformers import PretrainedConfig, PreTrainedModel
 
 from ..encoder.types import CONFIG_TYPES, ENCODER_TYPES
+from ..encoder.vdr import VDREncoderConfig
 
 logger = logging.getLogger(__name__)
 
@@ -34,7 +35,7 @@ class BiEncoder(PreTrainedModel):
         if config.shared_encoder:
             self.encoder_p = self.encoder_q
             if encoder_p is None and config.encoder_p is not None:
-                self.encoder_q.config.max_len = max(self.encoder_q.config.max_len, config.encoder_p.get("max_len", 0))
+                self.encoder_q.config.max_len = max(self.encoder_q.config.max_len, config.encoder_p.get("max_len", VDREncoderConfig().max_len))
         else:
             self.encoder_p = encoder_p if encoder_p is not None else self._make_tower(config.encoder_p)
         self.default_batch_size = None

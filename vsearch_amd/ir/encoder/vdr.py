@@ -66,8 +66,11 @@ class VDREncoder(PreTrainedModel):
     def forward(self, input_ids, token_type_ids=None, attention_mask=None):
         """[B, L] token ids -> [B, V] lexical representation (vdr.py:58-84). Pad positions are pooled
         like the reference (no attention mask in the max)."""
-        if self.config.pooling != "max":
-            raise NotImplementedError("only max pooling is implemented (the reference's mean branch is dead code, vdr.py:80)")
+        if self.config.pooling == "mean" and not self.config.pooling_topk:
+            # vdr.py:80 reads an undefined name: the reference cannot run this configuration either
+            raise NotImplementedError('pooling="mean" needs pooling_topk (the reference\'s plain-mean branch is dead code, vdr.py:80)')
+        if self.config.pooling not in ("max", "mean"):
+            raise NotImplementedError
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
             raise NotImplementedError("vsearch_amd implements the inference path only (HIP head has no backward)")
         with torch.no_grad():
@@ -76,6 +79,10 @@ class VDREncoder(PreTrainedModel):
             if not hidden.is_cuda:
                 raise RuntimeError("VDREncoder runs on an MI355X: move the encoder with .to('cuda') (no CPU fallback)")
             w = self.bert_model.embeddings.word_embeddings.weight[self.config.shift_vocab_num:, :]
+            if self.config.pooling == "mean":
+                # vdr.py:76-79: mean of the pooling_topk largest activations per vocabulary dimension
+                emb = sp.head_pool_mean_topk(hidden @ w.t(), int(self.config.pooling_topk))
+                return F.normalize(emb) if self.config.norm else emb
             if hidden.shape[-1] % 32 == 0 and hidden.dtype == torch.float32 and hidden.shape[1] > 64:
                 # passage-shaped batches: fused projection + max-pool + elu1p, no [B, L, V] logits (1.9 GB at 64 x 256);
                 # short query batches are faster through the library GEMM + vs_head_pool

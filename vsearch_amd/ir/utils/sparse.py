@@ -102,6 +102,18 @@ def head_pool(logits: torch.Tensor):
     return out
 
 
+def head_pool_mean_topk(logits: torch.Tensor, topk: int):
+    """Mean of the `topk` largest elu1p(logits) over the sequence axis of [B, L, V] logits (vdr.py:76-79) -> [B, V]."""
+    assert logits.is_cuda and logits.dim() == 3
+    x = logits.detach().to(torch.float32).contiguous()
+    dev = _dev_of(x)
+    B, L, V = x.shape
+    out = torch.empty((B, V), dtype=torch.float32, device=x.device)
+    # (pooling_topk > L -> RuntimeError "selected index k out of range", like torch.topk)
+    nat.check(nat.lib().vs_head_pool_mean_topk(C.c_void_p(x.data_ptr()), B, L, V, int(topk), C.c_void_p(out.data_ptr()), dev, current_stream(dev)))
+    return out
+
+
 def head_project_pool(hidden_ln: torch.Tensor, weight: torch.Tensor):
     """Fused encoder head (vdr.py:72-75): elu1p(max over positions of hidden_ln @ weight.T) without the [B, L, V] logits.
     hidden_ln [B, L, H] and weight [V, H]: CUDA fp32, H % 32 == 0."""
