@@ -217,7 +217,7 @@ def main():
                 rec = json.load(open(pmc)).get(kernel, {})
                 # only when the profile was taken on this kernel build and this configuration (it goes stale otherwise)
                 if rec.get("hbm_bytes_per_launch") and rec.get("queries_per_launch") == args.batch and rec.get("docs") == n_local \
-                        and rec.get("store", "fp32") == args.store and rec.get("scan", "auto") == args.scan:
+                        and rec.get("store", "fp32") == args.store and rec.get("scan", "auto") == args.scan and rec.get("columns", "uniform") == args.columns:
                     traffic = rec["hbm_bytes_per_launch"]
                     traffic_src = f"profiles/pmc_summary.json ({rec.get('tag', '?')}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command)"
             except Exception:

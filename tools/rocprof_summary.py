@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--docs", type=int, default=21015324)
     ap.add_argument("--store", default="fp32", help="bench.py --store of the profiled command")
     ap.add_argument("--scan", default="auto", help="bench.py --scan of the profiled command")
+    ap.add_argument("--columns", default="uniform", help="bench.py --columns of the profiled command")
     ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles"))
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
@@ -84,7 +85,7 @@ def main():
             if fetch <= 0:
                 continue
             pmc[key] = {"hbm_bytes_per_launch": (2 * fetch + write) * 1024, "fetch_KiB": fetch, "write_KiB": write,
-                        "queries_per_launch": a.queries, "docs": a.docs, "store": a.store, "scan": a.scan, "tag": a.tag,
+                        "queries_per_launch": a.queries, "docs": a.docs, "store": a.store, "scan": a.scan, "columns": a.columns, "tag": a.tag,
                         "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024  (gfx950: FETCH_SIZE counts 1/2 of a 16 B/lane coalesced stream)",
                         "source": f"profiles/{a.tag}_fetch_size.txt, profiles/{a.tag}_write_size.txt (rocprofv3 --pmc, separate passes, {a.note})"}
         with open(pmc_path, "w") as f:

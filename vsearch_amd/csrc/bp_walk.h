@@ -288,6 +288,11 @@ __device__ __forceinline__ void lds_add(uint32_t addr, double v) {
     __hip_atomic_fetch_add(reinterpret_cast<__attribute__((address_space(3))) double*>(addr), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+template <int U>
+__device__ __forceinline__ uint32_t quad_bcast(uint32_t x) {          // lane U of every quad -> the whole quad: a VALU move, no LDS
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, U | (U << 2) | (U << 4) | (U << 6), 0xF, 0xF, false);
+}
+
 // LG = lanes per posting list (8 for the long lists of a valued index, 1 for the short lists of the bag-of-token index),
 // RMAX = block capacity in documents
 template <int VM, int QT, int AM, int LG, int RMAX>
@@ -375,9 +380,9 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
                 uint32_t nlo[OWN], nhi[OWN];
 #pragma unroll
                 for (int o = 0; o < OWN; ++o) {
-                    const int e = gid + NG * (gl + LG * o);
+                    const int e = gid + NG * ((LG >= NB ? (gl & (NB - 1)) : gl) + LG * o);       // LG >= NB: every quad of the group holds all NB pairs
                     nlo[o] = 0; nhi[o] = 0;
-                    if (gl + LG * o < NB && e < n_ent) {
+                    if (e < n_ent) {
                         const uint32_t cc = ent[e].x & 0xFFFFu;
                         nlo[o] = dirb[cc];
                         nhi[o] = dirb[cc + 1];
@@ -389,8 +394,8 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
                     for (int o = 0; o < OWN; ++o) {
                         clo[o] = nlo[o]; chi[o] = nhi[o];
                         nlo[o] = 0; nhi[o] = 0;
-                        const int e = gid + NG * (gl + LG * o + NB * (j + 1));
-                        if (gl + LG * o < NB && e < n_ent) {
+                        const int e = gid + NG * ((LG >= NB ? (gl & (NB - 1)) : gl) + LG * o + NB * (j + 1));
+                        if (e < n_ent) {
                             const uint32_t cc = ent[e].x & 0xFFFFu;
                             nlo[o] = dirb[cc];
                             nhi[o] = dirb[cc + 1];
@@ -399,10 +404,18 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
                     uint32_t rec[NB], end[NB];
                     uint2 en[NB];
                     bool more = false;
+                    uint32_t blo[NB], bhi[NB];                      // list u of the slot: its pair sits in lane u of every quad (LG >= 4) / in register u
+                    if constexpr (LG == 1) {
 #pragma unroll
-                    for (int u = 0; u < NB; ++u) {                  // list u of the slot: its pair sits in lane u % LG, register u / LG
-                        const uint32_t lo = LG == 1 ? clo[u] : (uint32_t)__shfl((int)clo[u / LG], u % LG, LG);
-                        const uint32_t hi = LG == 1 ? chi[u] : (uint32_t)__shfl((int)chi[u / LG], u % LG, LG);
+                        for (int u = 0; u < NB; ++u) { blo[u] = clo[u]; bhi[u] = chi[u]; }
+                    } else {
+                        static_assert(NB == 4 && OWN == 1, "quad broadcast of four pairs");
+                        blo[0] = quad_bcast<0>(clo[0]); blo[1] = quad_bcast<1>(clo[0]); blo[2] = quad_bcast<2>(clo[0]); blo[3] = quad_bcast<3>(clo[0]);
+                        bhi[0] = quad_bcast<0>(chi[0]); bhi[1] = quad_bcast<1>(chi[0]); bhi[2] = quad_bcast<2>(chi[0]); bhi[3] = quad_bcast<3>(chi[0]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < NB; ++u) {
+                        const uint32_t lo = blo[u], hi = bhi[u];
                         rec[u] = lo + gl; end[u] = hi;
                         more = more || (rec[u] < end[u]);
                         en[u] = ent[min(gid + NG * (u + NB * j), n_ent - 1)];       // (column | slot offset << 16, weight): LDS broadcast per group
