@@ -3,7 +3,8 @@
 import csv, glob, os, sys
 root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc_walk"
 tag = sys.argv[2] if len(sys.argv) > 2 else "r02"
-kern = sys.argv[3] if len(sys.argv) > 3 else "bp_scan_topk"
+kern = sys.argv[3] if len(sys.argv) > 3 else "bp_walk_topk"
+shape = sys.argv[4] if len(sys.argv) > 4 else "4 M docs, 1024 queries"
 out = {}
 for f in sorted(glob.glob(os.path.join(root, "*", "**", "*counter_collection.csv"), recursive=True)):
     per = {}
@@ -23,7 +24,7 @@ for f in sorted(glob.glob(os.path.join(root, "*", "**", "*counter_collection.csv
     for (d, c), v in per.items():
         if d == big:
             out[c] = v
-lines = [f"# rocprofv3 --pmc passes (tools/pmc_walk.sh), largest (bench-sized: 21 M docs, 1024 queries) launch of {kern}; sums over all XCDs/SEs"]
+lines = [f"# rocprofv3 --pmc passes (tools/pmc_walk.sh), largest launch of {kern} ({shape}: tools/probe_filter.py under rocprofv3); sums over all XCDs/SEs"]
 for c in sorted(out):
     lines.append(f"{c:44s} {out[c]:24.0f}")
 g = out.get
@@ -32,7 +33,15 @@ if g("SQ_WAVE_CYCLES"):
     lines.append("")
     lines.append(f"wave-cycle split: waiting (s_waitcnt/barrier) {g('SQ_WAIT_ANY', 0)/wc:.3f}, issue stall {g('SQ_WAIT_INST_ANY', 0)/wc:.3f}, issuing {g('SQ_ACTIVE_INST_ANY', 0)/wc:.3f}")
 if g("SQ_BUSY_CYCLES") and g("SQ_ACTIVE_INST_LDS") is not None:
-    lines.append(f"SQ_ACTIVE_INST_LDS / SQ_BUSY_CYCLES = {g('SQ_ACTIVE_INST_LDS')/g('SQ_BUSY_CYCLES'):.3f}; VALU {g('SQ_ACTIVE_INST_VALU', 0)/g('SQ_BUSY_CYCLES'):.3f}; VMEM {g('SQ_ACTIVE_INST_VMEM', 0)/g('SQ_BUSY_CYCLES'):.3f}")
+    lines.append(f"SQ_ACTIVE_INST_LDS / SQ_BUSY_CYCLES = {g('SQ_ACTIVE_INST_LDS')/g('SQ_BUSY_CYCLES'):.3f}; VALU {g('SQ_ACTIVE_INST_VALU', 0)/g('SQ_BUSY_CYCLES'):.3f}  (per shader engine: 8 CUs x 4 SIMDs)")
+if g("SQ_LDS_IDX_ACTIVE") and g("SQ_BUSY_CYCLES"):
+    cu_cycles = g("SQ_BUSY_CYCLES") / 32 * 256                      # SQ_BUSY_CYCLES is summed over 32 shader engines; 256 CUs
+    lines.append(f"LDS busy (SQ_LDS_IDX_ACTIVE / CU cycles) = {g('SQ_LDS_IDX_ACTIVE')/cu_cycles:.3f}, of which bank-conflict cycles {g('SQ_LDS_BANK_CONFLICT', 0)/g('SQ_LDS_IDX_ACTIVE'):.3f}")
+    if g("SQ_INSTS_LDS_ATOMIC"):
+        lines.append(f"VALU instructions per LDS atomic instruction = {g('SQ_INSTS_VALU', 0)/g('SQ_INSTS_LDS_ATOMIC'):.2f}")
+if g("TCP_TCC_READ_REQ_sum") and g("SQ_BUSY_CYCLES"):
+    cu_cycles = g("SQ_BUSY_CYCLES") / 32 * 256
+    lines.append(f"L1->L2 read requests per CU and cycle = {g('TCP_TCC_READ_REQ_sum')/cu_cycles:.3f}; L1 pending-data stall {g('TCP_PENDING_STALL_CYCLES_sum', 0)/cu_cycles:.3f} of the cycles")
 if g("TCC_HIT_sum") is not None and g("TCC_MISS_sum") is not None:
     lines.append(f"L2 hit rate = {g('TCC_HIT_sum')/(g('TCC_HIT_sum')+g('TCC_MISS_sum')):.3f}")
 if g("TCP_TCC_READ_REQ_LATENCY_sum") and g("TCP_TCC_READ_REQ_sum"):
