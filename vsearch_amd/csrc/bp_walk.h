@@ -266,6 +266,8 @@ __device__ __forceinline__ void load_rec16(u32x4& a, uint32_t off, unsigned long
         case 2: asm volatile("s_waitcnt vmcnt(2)" : OPS); break;                                                        \
         case 3: asm volatile("s_waitcnt vmcnt(3)" : OPS); break;                                                        \
         case 4: asm volatile("s_waitcnt vmcnt(4)" : OPS); break;                                                        \
+        case 5: asm volatile("s_waitcnt vmcnt(5)" : OPS); break;                                                        \
+        case 7: asm volatile("s_waitcnt vmcnt(7)" : OPS); break;                                                        \
         case 6: asm volatile("s_waitcnt vmcnt(6)" : OPS); break;                                                        \
         case 9: asm volatile("s_waitcnt vmcnt(9)" : OPS); break;                                                        \
         default: asm volatile("s_waitcnt vmcnt(0)" : OPS); break;                                                       \
@@ -295,17 +297,16 @@ __device__ __forceinline__ uint32_t quad_bcast(uint32_t x) {          // lane U 
 
 // LG = lanes per posting list (8 for the long lists of a valued index, 1 for the short lists of the bag-of-token index),
 // RMAX = block capacity in documents
-template <int VM, int QT, int AM, int LG, int RMAX>
+template <int VM, int QT, int AM, int LG, int RMAX, int NB = kBpNB>
 __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
     static_assert(bp_acc_bytes<QT, AM, RMAX>() >= kBpSortBytes, "the accumulator area holds the 8192-slot entry sort");
     static_assert(VM != VM_BIN || RMAX == kBpRowsMaxBin, "pad postings of a binary list carry document id kBpRowsMaxBin");
-    static_assert(kBpNB % LG == 0 || LG % kBpNB == 0, "lane l of a group owns the directory pairs of lists l, l + LG, ... of a slot");
+    static_assert(NB % LG == 0 || LG % NB == 0, "lane l of a group owns the directory pairs of lists l, l + LG, ... of a slot");
     using acc_t = typename std::conditional<AM == AM_F64, double, int32_t>::type;
     constexpr int PITCH = QT + 1;                 // accumulator row pitch in elements: a document's row starts an odd number of words
                                                   // after its neighbour's, so the adds of a wave spread over all LDS banks
     constexpr uint32_t PITCHB = PITCH * sizeof(acc_t);
     constexpr int RS = bp_rec_bytes(VM);
-    constexpr int NB = kBpNB;
     constexpr int OWN = NB >= LG ? NB / LG : 1;   // directory pairs a lane owns per slot (lanes >= NB of a wide group own none)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     acc_t* acc = reinterpret_cast<acc_t*>(smem);                                            // [RMAX + 1][PITCH]
@@ -362,6 +363,25 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
         if (tid < QT) upper_sh[tid] = (a.upper && tid < nq) ? a.upper[q0 + tid] : ~0ull;
         __syncthreads();
 
+        // directory pairs of a block's first slot: fetched while the previous block is finished (they stay in flight across its epilogue)
+        uint32_t nlo[OWN], nhi[OWN];
+        auto first_pairs = [&](int64_t bb) {
+            const uint32_t* dirn = a.dir + (size_t)bb * dir_ld;
+#pragma unroll
+            for (int o = 0; o < OWN; ++o) {
+                const int e = gid + NG * ((LG >= NB ? (gl & (NB - 1)) : gl) + LG * o);       // LG >= NB: every quad of the group holds all NB pairs
+                nlo[o] = 0; nhi[o] = 0;
+                if (e < n_ent) {
+                    const uint32_t cc = ent[e].x & 0xFFFFu;
+                    nlo[o] = dirn[cc];
+                    nhi[o] = dirn[cc + 1];
+                }
+            }
+        };
+        // (short binary lists: one or two slots per block, the directory latency would be exposed once per block; with the long
+        //  lists of a valued index the pairs are fetched at block start -- holding them across the epilogue costs more than it hides)
+        constexpr bool kPairsAhead = LG == 1;
+        if (kPairsAhead && b0 < b1) first_pairs(b0);
         for (int64_t b = b0; b < b1 || b == b0; ++b) {
             const bool have = b < b1;
             const int rows_b = have ? (int)min((int64_t)a.rows, a.n_rows - b * a.rows) : 0;
@@ -377,17 +397,7 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
                 // list per round; the NB lists of a slot are loaded before any multiply-add.  Loads are unconditional (a lane past
                 // its list's end re-reads the record at the end: always inside the array) so that no loaded register is merged with
                 // an older value; only the adds are predicated.
-                uint32_t nlo[OWN], nhi[OWN];
-#pragma unroll
-                for (int o = 0; o < OWN; ++o) {
-                    const int e = gid + NG * ((LG >= NB ? (gl & (NB - 1)) : gl) + LG * o);       // LG >= NB: every quad of the group holds all NB pairs
-                    nlo[o] = 0; nhi[o] = 0;
-                    if (e < n_ent) {
-                        const uint32_t cc = ent[e].x & 0xFFFFu;
-                        nlo[o] = dirb[cc];
-                        nhi[o] = dirb[cc + 1];
-                    }
-                }
+                if (!kPairsAhead) first_pairs(b);
                 for (int j = 0; gid + NG * (NB * j) < n_ent; ++j) {
                     uint32_t clo[OWN], chi[OWN];
 #pragma unroll
@@ -409,7 +419,7 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
 #pragma unroll
                         for (int u = 0; u < NB; ++u) { blo[u] = clo[u]; bhi[u] = chi[u]; }
                     } else {
-                        static_assert(NB == 4 && OWN == 1, "quad broadcast of four pairs");
+                        static_assert(NB == 4 && OWN == 1, "quad broadcast of four pairs");      // (NB = 8 is the one-lane-per-list case)
                         blo[0] = quad_bcast<0>(clo[0]); blo[1] = quad_bcast<1>(clo[0]); blo[2] = quad_bcast<2>(clo[0]); blo[3] = quad_bcast<3>(clo[0]);
                         bhi[0] = quad_bcast<0>(chi[0]); bhi[1] = quad_bcast<1>(chi[0]); bhi[2] = quad_bcast<2>(chi[0]); bhi[3] = quad_bcast<3>(chi[0]);
                     }
@@ -477,6 +487,7 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
                         }
                     }
                 }
+                if (kPairsAhead && b + 1 < b1) first_pairs(b + 1);
             }
             __syncthreads();
             // epilogue: 1024 documents at a time, one per thread: its QT sums -> order keys -> candidates; prune when a buffer could overflow

@@ -749,7 +749,7 @@ int launch_bp_walk(const vs_index* idx, const BpArgs& a, int grid, int ent_cap, 
     void (*kern)(BpArgs) = nullptr;
     if (vm == VM_BIN) {
         if (AM != AM_FIX) return fail(VS_EUNSUPPORTED, "binary postings serve the filter walk only");
-        kern = bp_walk_topk<VM_BIN, kBpBinQT, AM_FIX, 1, kBpRowsMaxBin>;
+        kern = idx->bp_lanes == 4 ? bp_walk_topk<VM_BIN, kBpBinQT, AM_FIX, 1, kBpRowsMaxBin, 4> : bp_walk_topk<VM_BIN, kBpBinQT, AM_FIX, 1, kBpRowsMaxBin, 8>;
         lds = bp_lds_bytes<kBpBinQT, AM_FIX, kBpRowsMaxBin>(ent_cap);
     } else if (vm == VM_F32) {
         kern = idx->bp_lanes == 8 ? bp_walk_topk<VM_F32, QT, AM, 8, kBpRowsMax> : bp_walk_topk<VM_F32, QT, AM, 4, kBpRowsMax>;
