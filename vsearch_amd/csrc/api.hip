@@ -106,6 +106,12 @@ extern "C" int vs_index_set_option(vs_index* idx, const char* name, int value) {
         idx->bp_dir.release(); idx->bp_base.release(); idx->bp_rec.release(); idx->bp_ready = false; idx->bp_tried = false;
         return VS_OK;
     }
+    if (n == "postings_head") {
+        if (value < -1 || value > 0) return fail(VS_EINVAL, "postings_head: -1 = auto, 0 = no dense strips");
+        if (value != idx->bp_head_pref) { idx->bp_dir.release(); idx->bp_base.release(); idx->bp_rec.release(); idx->bp_ready = false; idx->bp_tried = false; }
+        idx->bp_head_pref = value;
+        return VS_OK;
+    }
     if (n == "postings_lanes") {
         if (value != 4 && value != 8) return fail(VS_EINVAL, "postings_lanes: 4 | 8");
         idx->bp_lanes = value;

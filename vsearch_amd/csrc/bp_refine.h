@@ -44,15 +44,20 @@ __global__ __launch_bounds__(256) void bp_vmax_kernel(const void* vals, int64_t 
 // goes straight to the exact pass.  One wave per query, fixed reduction order.
 template <int UNUSED>
 __global__ __launch_bounds__(256) void bp_qscale_kernel(const int64_t* qptr, const float* qvals, int32_t B, const uint32_t* vmax_bits, int binary, int quant,
-                                                        float* qscale, int32_t* qslack, float* qwsum) {
+                                                        float* qscale, int32_t* qslack, float* qwsum, const int32_t* qcols, const uint16_t* hmap) {
     const int lane = threadIdx.x & 63;
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= B) return;
     const int64_t e0 = qptr[q], e1 = qptr[q + 1];
     float sum = 0.f;
     bool neg = false;
-    for (int64_t e = e0 + lane; e < e1; e += 64) { sum += fabsf(qvals[e]); neg = neg || qvals[e] < 0.f; }
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    int heads = 0;                                                   // entries on head columns (dense strips, bp_walk.h)
+    for (int64_t e = e0 + lane; e < e1; e += 64) {
+        sum += fabsf(qvals[e]);
+        neg = neg || qvals[e] < 0.f;
+        if (hmap && hmap[qcols[e]] != 0xFFFFu) ++heads;
+    }
+    for (int o = 32; o > 0; o >>= 1) { sum += __shfl_xor(sum, o, 64); heads += __shfl_xor(heads, o, 64); }
     neg = __builtin_amdgcn_ballot_w64(neg) != 0ull;
     const float vmax = binary ? 1.f : __uint_as_float(vmax_bits[0]);
     const float bound = sum * vmax * 1.0001f;                        // the reduction above is not the walk's order: a hair of slack
@@ -75,7 +80,10 @@ __global__ __launch_bounds__(256) void bp_qscale_kernel(const int64_t* qptr, con
     if (lane == 0) {
         qscale[q] = S;
         qwsum[q] = sum * 1.0001f;
-        qslack[q] = (exact || e1 == e0) ? 0 : ((quant && neg) ? -1 : (int32_t)min((int64_t)1 << 20, e1 - e0 + 1));
+        // the dense part of a score: four fp32 partial sums over `heads` products in all (each rounding loses at most 2^-24 of a
+        // running sum below 2^30, i.e. < 64 units), each truncated once
+        const int64_t dense_slack = heads > 0 ? (int64_t)heads * 128 + 4 : 0;
+        qslack[q] = (exact || e1 == e0) ? 0 : (((quant || heads > 0) && neg) ? -1 : (int32_t)min((int64_t)1 << 24, e1 - e0 + 1 + dense_slack));
     }
 }
 

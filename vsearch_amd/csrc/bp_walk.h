@@ -54,7 +54,7 @@ __host__ __device__ constexpr int bp_rec_bytes(int vm) { return vm == VM_F32 ? 4
 template <int UNUSED>
 __global__ __launch_bounds__(kScanThreads) void bp_count_kernel(const uint32_t* pk_ptr, const uint4* cols, int64_t n_rows, int32_t n_cols, int32_t rows,
                                                                 uint32_t* dir, uint32_t* block_recs, unsigned long long* df_rec,
-                                                                unsigned long long* df_nnz) {
+                                                                unsigned long long* df_nnz, const uint16_t* hmap) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint32_t* cnt = reinterpret_cast<uint32_t*>(smem);                  // [n_cols + 1]
     __shared__ int scratch[32];
@@ -80,13 +80,15 @@ __global__ __launch_bounds__(kScanThreads) void bp_count_kernel(const uint32_t* 
         if (tid == 0) cnt[n_cols] = 0;
         __syncthreads();
         const int i0 = tid * seg, i1 = min(n_cols + 1, i0 + seg);
+        // (head columns -- hmap[c] != 0xFFFF -- live in the dense strips: no records, empty lists)
+        auto recs_of = [&](int i) -> uint32_t { return (hmap && i < n_cols && hmap[i] != 0xFFFFu) ? 0u : (cnt[i] + 7u) >> 3; };
         int mine = 0;
-        for (int i = i0; i < i1; ++i) mine += ((int)cnt[i] + 7) >> 3;
+        for (int i = i0; i < i1; ++i) mine += (int)recs_of(i);
         int tot = 0;
         int off = block_excl_scan(mine, scratch, tid, &tot);
         uint32_t* d = dir + (size_t)b * (n_cols + 1);
         for (int i = i0; i < i1; ++i) {
-            const uint32_t c = cnt[i], r = (c + 7) >> 3;
+            const uint32_t c = cnt[i], r = recs_of(i);
             d[i] = (uint32_t)off;
             off += (int)r;
             if (i < n_cols && c) {
@@ -96,6 +98,29 @@ __global__ __launch_bounds__(kScanThreads) void bp_count_kernel(const uint32_t* 
         }
         if (tid == 0) block_recs[b] = (uint32_t)tot;
     }
+}
+
+// Head columns: a column present in a large share of the documents (skewed vocabularies: the ~500 most popular columns of a
+// Zipf(1) corpus cover 3/4 of all non-zeros) is cheaper as a DENSE strip -- one fp16 value per document of the block, read
+// coalesced and multiply-added in registers at block end -- than as a 2048-posting list of scatter-adds (an LDS atomic costs
+// ~20 lane-cycles, a fused multiply-add 1/64 of an instruction).  hmap[c] = strip index of column c, 0xFFFF = ordinary column.
+constexpr int kBpHeadCap = 512;
+template <int UNUSED>
+__global__ __launch_bounds__(kScanThreads) void bp_head_select_kernel(const unsigned long long* df_nnz, int32_t n_cols, unsigned long long thresh, int32_t cap,
+                                                                      uint16_t* hmap, int32_t* n_head) {
+    __shared__ int cnt;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    for (int c = threadIdx.x; c < n_cols; c += kScanThreads) {
+        uint16_t h = 0xFFFFu;
+        if (df_nnz[c] >= thresh) {
+            const int i = atomicAdd(&cnt, 1);
+            if (i < cap) h = (uint16_t)i;
+        }
+        hmap[c] = h;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) n_head[0] = min(cnt, cap);
 }
 
 // pass 2: exclusive scan of the block totals -> base[b] (records), base[n_blocks] = all records.  One workgroup.
@@ -124,7 +149,7 @@ __global__ __launch_bounds__(kScanThreads) void bp_base_kernel(const uint32_t* b
 template <int VS, int VM>
 __global__ __launch_bounds__(kScanThreads) void bp_fill_kernel(const uint32_t* pk_ptr, const uint4* cols, const void* vals, int64_t n_rows,
                                                                int32_t n_cols, int32_t rows, const uint32_t* dir, const unsigned long long* base,
-                                                               char* rec) {
+                                                               char* rec, const uint16_t* hmap, __half* strip, int32_t n_head) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint32_t* cur = reinterpret_cast<uint32_t*>(smem);                  // [n_cols + 1] write cursors in postings
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -157,7 +182,10 @@ __global__ __launch_bounds__(kScanThreads) void bp_fill_kernel(const uint32_t* p
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const uint32_t c = (i & 1) ? (cwv[i >> 1] >> 16) : (cwv[i >> 1] & 0xFFFFu);
-                    if (c < (uint32_t)n_cols) {
+                    if (c < (uint32_t)n_cols && hmap && hmap[c] != 0xFFFFu) {
+                        // head column: strip[block][strip index][document]
+                        if constexpr (VM != VM_BIN) strip[((size_t)b * n_head + hmap[c]) * rows + dl] = __float2half_rn(v[i]);
+                    } else if (c < (uint32_t)n_cols) {
                         const uint32_t pos = atomicAdd(&cur[c], 1u);
                         char* rp = brec + (size_t)(pos >> 3) * RS;
                         reinterpret_cast<uint16_t*>(rp)[pos & 7u] = dl;
@@ -219,14 +247,17 @@ struct BpArgs {
     uint64_t* gcand;          // [grid, QT, kBpCap] scratch
     const uint64_t* upper;    // optional [B] exclusive upper bounds ("search after")
     const float* qscale;      // AM_FIX: [B] per-query power-of-two scale of the fixed-point sums
+    const uint16_t* hmap;     // head columns (dense strips), n_head > 0 only: [n_cols] strip index or 0xFFFF
+    const __half* strip;      // [n_blocks][n_head][rows] values of the head columns
+    int32_t n_head;
 };
 
 // accumulators [RMAX + 1][QT + 1]: the extra row absorbs the pad postings of a binary list (document id RMAX)
 template <int QT, int AM, int RMAX>
 __host__ __device__ constexpr size_t bp_acc_bytes() { return (((size_t)(RMAX + 1) * (QT + 1) * (AM == AM_F64 ? 8 : 4)) + 15) & ~(size_t)15; }
 template <int QT, int AM, int RMAX>
-__host__ __device__ inline size_t bp_lds_bytes(int ent_cap) {
-    return bp_acc_bytes<QT, AM, RMAX>() + (size_t)kBpCap * 8 + (size_t)QT * 16 + 64 * 4 + (size_t)ent_cap * 8;
+__host__ __device__ inline size_t bp_lds_bytes(int ent_cap, int n_head = 0) {
+    return bp_acc_bytes<QT, AM, RMAX>() + (size_t)kBpCap * 8 + (size_t)QT * 16 + 64 * 4 + (size_t)ent_cap * 8 + (size_t)n_head * QT * 4;
 }
 
 __device__ __forceinline__ uint64_t make_key_fix(int32_t a, uint32_t row) {
@@ -316,6 +347,7 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
     int* scratch = reinterpret_cast<int*>(upper_sh + QT);                                   // [48]
     unsigned int* ccnt = reinterpret_cast<unsigned int*>(scratch + 48);                     // [QT]
     uint2* ent = reinterpret_cast<uint2*>(scratch + 64);                                    // [ent_cap]: x = column | slot byte offset << 16, y = weight bits
+    float* hw = reinterpret_cast<float*>(ent + a.ent_cap);                                  // [n_head][QT] (scaled) weights of the tile on the head columns
 
     const int tid = threadIdx.x;
     const int gid = tid / LG, gl = tid % LG;
@@ -334,7 +366,10 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
         const int64_t b0 = (int64_t)c * a.blocks_per_chunk, b1 = min(n_blocks, b0 + a.blocks_per_chunk);
         __syncthreads();
         const int64_t e0 = a.qptr[q0], e1 = a.qptr[q0 + nq];
-        const int n_ent = (int)(e1 - e0);
+        int n_ent = (int)(e1 - e0);
+        const int n_head = AM == AM_FIX ? a.n_head : 0;
+        for (int i = tid; i < n_head * QT; i += kScanThreads) hw[i] = 0.f;
+        if (n_head > 0) __syncthreads();
         // Entries sorted by column (the accumulator area doubles as the sort buffer): neighbouring groups then read neighbouring
         // directory words and neighbouring posting lists -- the walk over the block's records is a forward sweep with gaps.
         {
@@ -347,11 +382,23 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
                     while (e >= a.qptr[q0 + qs + 1]) ++qs;
                     float w = a.qvals[e];
                     if constexpr (AM == AM_FIX) w *= a.qscale[q0 + qs];          // power of two: exact
-                    key = ((uint64_t)(uint32_t)a.qcols[e] << 40) | ((uint64_t)qs << 32) | (uint64_t)__float_as_uint(w);
+                    const uint32_t col = (uint32_t)a.qcols[e];
+                    const uint32_t hx = n_head > 0 ? a.hmap[col] : 0xFFFFu;
+                    if (hx != 0xFFFFu) hw[hx * QT + qs] = w;                      // a head column: its weight joins the dense part, no list to walk
+                    else key = ((uint64_t)col << 40) | ((uint64_t)qs << 32) | (uint64_t)__float_as_uint(w);
                 }
                 skey[i] = key;
             }
             wg_sort_desc<kScanThreads>(skey, 8192, tid);
+            if (n_head > 0) {                                   // entries left after the head columns: the non-zero keys (sorted first)
+                __shared__ int n_left;
+                if (tid == 0) n_left = 0;
+                __syncthreads();
+                for (int i = tid; i < n_ent; i += kScanThreads)
+                    if (skey[i] != 0ull && (i + 1 == 8192 || skey[i + 1] == 0ull)) n_left = i + 1;
+                __syncthreads();
+                n_ent = n_left;
+            }
             for (int i = tid; i < n_ent; i += kScanThreads) {
                 const uint64_t key = skey[i];
                 ent[i] = make_uint2((uint32_t)(key >> 40) | ((uint32_t)((key >> 32) & 0xFFu) * (uint32_t)sizeof(acc_t) << 16), (uint32_t)key);
@@ -490,6 +537,55 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
                 if (kPairsAhead && b + 1 < b1) first_pairs(b + 1);
             }
             __syncthreads();
+            if constexpr (AM == AM_FIX) {
+                if (n_head > 0 && have) {
+                    // Dense part: the block's values on the head columns x the tile's weights.  A thread takes 8 adjacent documents
+                    // (one 16-byte load of fp16 values per head column: a wave reads 1 KB contiguous) and a quarter of the head columns,
+                    // keeps 8 x QT fp32 sums in registers, truncates each once and adds it to the accumulators (4 partial sums per
+                    // (document, slot): the quarters).  8.4 M multiply-adds per block and tile run at FMA rate instead of the LDS atomic rate.
+                    const int g = tid & 255, hq = tid >> 8;
+                    const int h0 = hq * n_head / 4, h1 = (hq + 1) * n_head / 4;
+                    float ds[8][QT];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+#pragma unroll
+                        for (int q = 0; q < QT; ++q) ds[i][q] = 0.f;
+                    const uint4* sp = reinterpret_cast<const uint4*>(a.strip + (size_t)b * n_head * a.rows) + g;
+                    const int ldh = a.rows / 8;
+                    if (g * 8 < rows_b) {
+#pragma unroll 2
+                        for (int h = h0; h < h1; ++h) {
+                            const uint4 v8 = sp[(size_t)h * ldh];
+                            const float4 wa = *reinterpret_cast<const float4*>(hw + h * QT);
+                            float wv[QT];
+                            wv[0] = wa.x; wv[1] = wa.y; wv[2] = wa.z; wv[3] = wa.w;
+                            if constexpr (QT == 8) {
+                                const float4 wb = *reinterpret_cast<const float4*>(hw + h * QT + 4);
+                                wv[4] = wb.x; wv[5] = wb.y; wv[6] = wb.z; wv[7] = wb.w;
+                            }
+                            const uint32_t vw[4] = {v8.x, v8.y, v8.z, v8.w};
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const float2 f = __half22float2(*reinterpret_cast<const __half2*>(&vw[i]));
+#pragma unroll
+                                for (int q = 0; q < QT; ++q) {
+                                    ds[2 * i][q] = fmaf(wv[q], f.x, ds[2 * i][q]);
+                                    ds[2 * i + 1][q] = fmaf(wv[q], f.y, ds[2 * i + 1][q]);
+                                }
+                            }
+                        }
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const int d = g * 8 + i;
+                            if (d < rows_b) {
+#pragma unroll
+                                for (int q = 0; q < QT; ++q) atomicAdd(&acc[d * PITCH + q], (int32_t)ds[i][q]);
+                            }
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
             // epilogue: 1024 documents at a time, one per thread: its QT sums -> order keys -> candidates; prune when a buffer could overflow
             for (int d0 = 0; d0 < rows_b || d0 == 0; d0 += kScanThreads) {
                 const int d = d0 + tid;

@@ -481,7 +481,7 @@ extern "C" int vs_index_info(const vs_index* idx, vs_index_info_t* o) {
         VS_HIP(hipMemcpy(h.data(), idx->last_flags, h.size() * 4, hipMemcpyDeviceToHost));
         for (uint32_t f : h) o->last_fallbacks += f ? 1 : 0;
     }
-    o->aux_bytes = idx->bp_ready ? (int64_t)(idx->bp_dir.bytes + idx->bp_base.bytes + idx->bp_rec.bytes) : 0;
+    o->aux_bytes = idx->bp_ready ? (int64_t)(idx->bp_dir.bytes + idx->bp_base.bytes + idx->bp_rec.bytes + idx->bp_strip.bytes) : 0;
     if (idx->kind == VS_KIND_CSR) {
         o->bytes_per_pass = csr_bytes_per_pass(idx);
         o->device_bytes = (int64_t)(idx->pk_ptr.bytes + idx->cols.bytes + idx->vals.bytes);
@@ -737,6 +737,8 @@ inline int bp_record_vm(const vs_index* idx) {
 
 void bp_release(vs_index* idx) {
     idx->bp_dir.release(); idx->bp_base.release(); idx->bp_rec.release(); idx->bp_df.release(); idx->bp_vmax.release();
+    idx->bp_hmap.release(); idx->bp_strip.release();
+    idx->bp_n_head = 0;
     idx->bp_ready = false;
 }
 
@@ -745,7 +747,7 @@ void bp_release(vs_index* idx) {
 template <int QT, int AM>
 int launch_bp_walk(const vs_index* idx, const BpArgs& a, int grid, int ent_cap, hipStream_t s) {
     const int vm = bp_record_vm(idx);
-    size_t lds = bp_lds_bytes<QT, AM, kBpRowsMax>(ent_cap);
+    size_t lds = bp_lds_bytes<QT, AM, kBpRowsMax>(ent_cap, AM == AM_FIX ? a.n_head : 0);
     void (*kern)(BpArgs) = nullptr;
     if (vm == VM_BIN) {
         if (AM != AM_FIX) return fail(VS_EUNSUPPORTED, "binary postings serve the filter walk only");
@@ -798,11 +800,8 @@ int bp_build(vs_index* idx, hipStream_t s) {
     ProfScope prof("bp_build", s);
     VS_HIP(hipFuncSetAttribute((const void*)bp_count_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(bp_count_kernel<0>, dim3(grid), dim3(kScanThreads), lds, s, idx->pk_ptr.as<uint32_t>(), idx->cols.as<uint4>(), idx->n_rows, V, idx->bp_rows,
-                       idx->bp_dir.as<uint32_t>(), block_recs.as<uint32_t>(), df_rec, df_nnz);
+                       idx->bp_dir.as<uint32_t>(), block_recs.as<uint32_t>(), df_rec, df_nnz, (const uint16_t*)nullptr);
     VS_STAGE("bp_count", s);
-    hipLaunchKernelGGL(bp_base_kernel<0>, dim3(1), dim3(kScanThreads), 0, s, block_recs.as<uint32_t>(), n_blocks, idx->bp_base.as<unsigned long long>());
-    VS_HIP(hipGetLastError());
-    VS_STAGE("bp_base", s);
     // max |value| (bounds the products of the fixed-point walk) and "any value negative"; a binary index has no values
     uint32_t hv[2] = {0x3F800000u, 0u};
     if (idx->store_dtype != VS_NONE) {
@@ -815,15 +814,47 @@ int bp_build(vs_index* idx, hipStream_t s) {
         VS_HIP(hipGetLastError());
         VS_HIP(hipMemcpyAsync(hv, idx->bp_vmax.p, 8, hipMemcpyDeviceToHost, s));
     }
+    VS_HIP(hipStreamSynchronize(s));
+    float vmax_f;
+    memcpy(&vmax_f, &hv[0], 4);
+    const bool lossy_ok = hv[1] == 0u && vmax_f < 60000.f;       // fp16 copies of the values: non-negative, no overflow
+    // Head columns (skewed vocabularies): present in >= 1/4 of the documents -> dense strips instead of posting lists.  Valued
+    // indexes with the filter search only (the strips hold fp16 values: the fp64 walk cannot use them).
+    if (idx->store_dtype != VS_NONE && idx->bp_filter != 0 && idx->bp_head_pref != 0 && idx->n_rows >= 4096 && lossy_ok) {
+        DevBuf nh;
+        VS_TRY(nh.alloc(4));
+        VS_TRY(idx->bp_hmap.alloc((size_t)V * 2));
+        hipLaunchKernelGGL(bp_head_select_kernel<0>, dim3(1), dim3(kScanThreads), 0, s, df_nnz, V, (unsigned long long)((idx->n_rows + 3) / 4), kBpHeadCap,
+                           idx->bp_hmap.as<uint16_t>(), nh.as<int32_t>());
+        VS_HIP(hipGetLastError());
+        int32_t h_n = 0;
+        VS_HIP(hipMemcpyAsync(&h_n, nh.p, 4, hipMemcpyDeviceToHost, s));
+        VS_HIP(hipStreamSynchronize(s));
+        idx->bp_n_head = h_n;
+        if (h_n > 0) {
+            // the directory again, without the head columns' lists
+            VS_HIP(hipMemsetAsync(idx->bp_df.p, 0, (size_t)V * 16, s));
+            hipLaunchKernelGGL(bp_count_kernel<0>, dim3(grid), dim3(kScanThreads), lds, s, idx->pk_ptr.as<uint32_t>(), idx->cols.as<uint4>(), idx->n_rows, V,
+                               idx->bp_rows, idx->bp_dir.as<uint32_t>(), block_recs.as<uint32_t>(), df_rec, df_nnz, (const uint16_t*)idx->bp_hmap.as<uint16_t>());
+            VS_HIP(hipGetLastError());
+            const size_t b_strip = (size_t)n_blocks * h_n * idx->bp_rows * 2;
+            VS_HIP(hipMemGetInfo(&free_b, &total_b));
+            if (free_b < b_strip + margin || idx->bp_strip.alloc(b_strip) != VS_OK) return no_room(b_strip);
+            VS_HIP(hipMemsetAsync(idx->bp_strip.p, 0, b_strip, s));
+        } else {
+            idx->bp_hmap.release();
+        }
+    }
+    hipLaunchKernelGGL(bp_base_kernel<0>, dim3(1), dim3(kScanThreads), 0, s, block_recs.as<uint32_t>(), n_blocks, idx->bp_base.as<unsigned long long>());
+    VS_HIP(hipGetLastError());
+    VS_STAGE("bp_base", s);
     unsigned long long n_rec = 0;
     VS_HIP(hipMemcpyAsync(&n_rec, idx->bp_base.as<unsigned long long>() + n_blocks, 8, hipMemcpyDeviceToHost, s));
     VS_HIP(hipStreamSynchronize(s));
     VS_STAGE("bp_vmax", s);
     // Lossy filter copy of an fp32 index: values rounded to fp16 (4 instead of 6 bytes per posting); needs the filter-and-refine
     // search, non-negative values and no fp16 overflow
-    float vmax_f;
-    memcpy(&vmax_f, &hv[0], 4);
-    idx->bp_quant = idx->store_dtype == VS_F32 && idx->bp_filter != 0 && idx->bp_quant_pref != 0 && hv[1] == 0u && vmax_f < 60000.f;
+    idx->bp_quant = idx->store_dtype == VS_F32 && idx->bp_filter != 0 && idx->bp_quant_pref != 0 && lossy_ok;
     const int RS = bp_rec_bytes(bp_record_vm(idx));
     const size_t b_rec = ((size_t)n_rec + 1) * RS;                       // + one record: a lane past the last list's end re-reads "the record at the end"
     VS_HIP(hipMemGetInfo(&free_b, &total_b));
@@ -831,12 +862,13 @@ int bp_build(vs_index* idx, hipStream_t s) {
     idx->bp_records = (int64_t)n_rec;
     VS_HIP(hipMemsetAsync(idx->bp_rec.p, 0, b_rec, s));                  // pad postings: document 0, value 0
     {
-        void (*fill)(const uint32_t*, const uint4*, const void*, int64_t, int32_t, int32_t, const uint32_t*, const unsigned long long*, char*) =
+        void (*fill)(const uint32_t*, const uint4*, const void*, int64_t, int32_t, int32_t, const uint32_t*, const unsigned long long*, char*, const uint16_t*, __half*, int32_t) =
             idx->store_dtype == VS_F32 ? (idx->bp_quant ? bp_fill_kernel<VM_F32, VM_F16> : bp_fill_kernel<VM_F32, VM_F32>)
             : idx->store_dtype == VS_F16 ? bp_fill_kernel<VM_F16, VM_F16> : bp_fill_kernel<VM_BIN, VM_BIN>;
         VS_HIP(hipFuncSetAttribute((const void*)fill, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(fill, dim3(grid), dim3(kScanThreads), lds, s, idx->pk_ptr.as<uint32_t>(), idx->cols.as<uint4>(), (const void*)idx->vals.p, idx->n_rows, V,
-                           idx->bp_rows, idx->bp_dir.as<uint32_t>(), idx->bp_base.as<unsigned long long>(), idx->bp_rec.as<char>());
+                           idx->bp_rows, idx->bp_dir.as<uint32_t>(), idx->bp_base.as<unsigned long long>(), idx->bp_rec.as<char>(),
+                           idx->bp_n_head > 0 ? (const uint16_t*)idx->bp_hmap.as<uint16_t>() : (const uint16_t*)nullptr, idx->bp_strip.as<__half>(), idx->bp_n_head);
     }
     VS_HIP(hipGetLastError());
     VS_STAGE("bp_fill", s);
@@ -895,7 +927,8 @@ int bp_filter_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64
     const int V = idx->n_cols;
     const int kp = k + std::max(28, k / 4);
     const int qt = idx->store_dtype == VS_NONE ? kBpBinQT : kQT;
-    const int vals_cap = std::min(mq_vals_cap(idx), kBpEntCap);
+    // (dense strips: their weight matrix takes 16 KB of the LDS the entries would use)
+    const int vals_cap = std::min(mq_vals_cap(idx), idx->bp_n_head > 0 ? kBpEntCap - 512 : kBpEntCap);
     const int64_t qcap = (int64_t)B * vals_cap;                               // bound of the batch's (query, column) entries that enter a tile
     const int64_t n_blocks = ceil_div64(idx->n_rows, idx->bp_rows);
     if (idx->bp_rows > (idx->store_dtype == VS_NONE ? kBpRowsMaxBin : kBpRowsMax)) return fail(VS_EINVAL, "postings_rows beyond the walk's block capacity");
@@ -930,7 +963,8 @@ int bp_filter_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64
         hipLaunchKernelGGL(bp_walk_kernel<0>, dim3(1), dim3(kScanThreads), 0, s, colfreq, idx->bp_df.as<unsigned long long>(),
                            idx->bp_df.as<unsigned long long>() + V, V, dplan + 4);
     hipLaunchKernelGGL(bp_qscale_kernel<0>, dim3((unsigned)ceil_div(B, 4)), dim3(256), 0, s, qptr, qvals, B, idx->bp_vmax.as<uint32_t>(),
-                       idx->store_dtype == VS_NONE ? 1 : 0, idx->bp_quant ? 1 : 0, qscale, qslack, qwsum);
+                       idx->store_dtype == VS_NONE ? 1 : 0, (idx->bp_quant || idx->bp_n_head > 0) ? 1 : 0, qscale, qslack, qwsum, (const int32_t*)qcols,
+                       idx->bp_n_head > 0 ? (const uint16_t*)idx->bp_hmap.as<uint16_t>() : (const uint16_t*)nullptr);
     VS_HIP(hipGetLastError());
     VS_STAGE("sparsify", s);
     // 2. the walk.  Work items = (tile, chunk); the tile count lives on the device, the chunks follow its lower bound ceil(B / qt)
@@ -960,6 +994,9 @@ int bp_filter_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64
     a.cand = idx->ws_cand.as<uint64_t>();
     a.gcand = idx->ws_mq_cand.as<uint64_t>();
     a.qscale = qscale;
+    a.hmap = idx->bp_n_head > 0 ? idx->bp_hmap.as<uint16_t>() : nullptr;
+    a.strip = idx->bp_strip.as<__half>();
+    a.n_head = idx->bp_n_head;
     idx->last_path = 3;
     idx->last_plan_dev = dplan;
     idx->last_plan_rs = bp_rec_bytes(bp_record_vm(idx));
@@ -984,7 +1021,7 @@ int bp_filter_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64
     r.qscale = qscale;
     r.qslack = qslack;
     r.qwsum = qwsum;
-    r.quant = idx->bp_quant ? 1 : 0;
+    r.quant = (idx->bp_quant || idx->bp_n_head > 0) ? 1 : 0;       // fp16-rounded values in the records and / or the dense strips
     r.force_flag = idx->bp_force_fb ? 1 : 0;
     r.id_offset = id_offset;
     r.out_ids = d_ids;
@@ -1055,7 +1092,7 @@ int mq_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64_t id_o
     // kernel re-scores them exactly and proves the top k; unproven queries go through the fp64 walk.  Without it (option
     // "postings_filter" = 0, "search after" passes, k beyond the candidate buffers) every tile takes the fp64 walk.
     if (bp_filter_ok(idx, k, col0, upper)) return bp_filter_search(idx, dq, B, k, id_offset, d_ids, d_scores, plan, s, done, out_ld);
-    const bool filter_only = idx->bp_quant || idx->store_dtype == VS_NONE;    // lossy / binary records serve the filter only
+    const bool filter_only = idx->bp_quant || idx->store_dtype == VS_NONE || idx->bp_n_head > 0;    // lossy / binary records, dense strips: the filter only
     const bool use_bp = idx->bp_ready && !filter_only;                         // the fp64 walk over exact records
     const int qt_plan = use_bp ? kBpExactQT : kQT;
     const int bp_cap = kBpEntCap / 2;
@@ -1227,7 +1264,7 @@ int vs_csr_search(vs_index* idx, const void* q, int q_dtype, int64_t ldq, int32_
         // ranks one pass delivers: the whole k when the filter-and-refine search takes it (k + its margin within the candidate
         // buffers), else 1024 per pass of the fp64 postings walk (exact records only), else 512 per pass of the CSR scan
         const bool one_pass = idx->bp_ready && idx->bp_filter != 0 && k + std::max(28, k / 4) <= kBpMaxK;
-        const int max_k = one_pass ? k : (idx->bp_ready && !idx->bp_quant && idx->store_dtype != VS_NONE) ? kBpMaxK : kMaxKMq;
+        const int max_k = one_pass ? k : (idx->bp_ready && !idx->bp_quant && idx->store_dtype != VS_NONE && idx->bp_n_head == 0) ? kBpMaxK : kMaxKMq;
         const int mq_passes = ceil_div(k, max_k);
         const int kk_mq = std::min<int>(k, max_k);
         DevBuf mq_upper;
