@@ -86,7 +86,10 @@ typedef struct vs_index_info_t {
                               * (fp64 walk), 3 = blocked postings, fixed-point filter walk + exact refine               */
     int32_t last_fallbacks;  /* path 3: queries of the most recent search() whose top k the refine step could not prove from
                               * the filter's candidates and that were re-run on the exact walk (reading it synchronises)  */
-    int64_t last_walk_postings; /* postings (multiply-adds into the accumulators) the most recent walk visited          */
+    int64_t last_walk_postings; /* score terms (query weight x document value) the most recent walk accumulated: scatter-adds
+                              * of posting lists + multiply-adds on the dense head strips                                 */
+    int32_t head_columns;    /* columns of the blocked-postings copy kept as dense strips (option "postings_head")         */
+    int32_t reserved0;
 } vs_index_info_t;
 
 /* ---- library ------------------------------------------------------------------------------- */
@@ -171,6 +174,12 @@ VS_API int  vs_index_set_queries_per_pass(vs_index* index, int qt);
  *                       MI355X) and returns k + max(28, k/4) candidates per query, which are re-scored with the exact numerics
  *                       and PROVEN to contain the top k; unproven queries re-run on the fp64 walk.  Results are identical to
  *                       0 = fp64 walk only
+ *   "postings_quant"    1 (default) = an fp32 index keeps fp16-rounded values in the postings copy (the filter only ranks
+ *                       candidates; the refine step re-scores them from the fp32 CSR), 0 = fp32 values there too
+ *   "postings_head"     -1 = auto (4), 0 = off, N in 2..64: columns present in >= 1/N of the documents (at most 512, the most
+ *                       frequent first) leave the posting lists and are kept as dense fp16 strips [block][column][document];
+ *                       a query tile scores them with multiply-adds in registers (skewed vocabularies: a Zipf corpus has
+ *                       3/4 of its non-zeros there).  Valued, non-negative indexes with the filter search; results unchanged
  *   "mq_variant"        -1 = auto (from the batch's query overlap), 0 = plain, 1 = shared-column variant of the 8-query scan */
 VS_API int  vs_index_set_option(vs_index* index, const char* name, int value);
 

@@ -198,3 +198,51 @@ def test_skewed_columns_device_generator_and_search():
     ids, sc = _modes(idx, q, 100, want_quant=True)
     _, _, allsc = oracle.csr_search(o_ip, o_ix, o_d, V, q, 100, acc64=True, return_all=True)
     compare.check_topk_valid(allsc, ids, sc, rtol=RTOL)
+
+
+@pytest.mark.parametrize("store", [nat.VS_F32, nat.VS_F16], ids=["fp32", "fp16"])
+def test_dense_head_strips_keep_the_results(store):
+    """Option postings_head: the columns present in >= 1/N of the documents move from posting lists to dense fp16 strips that the
+    tile scores with multiply-adds in registers.  Whatever N, the results are the CSR scan's, bit for bit; more than 512
+    qualifying columns keep the 512 most frequent."""
+    n = 9000
+    idx = DeviceIndex.synthetic(0, 100, n, V, 768, synth.KIND_SKEW, 0, store)
+    ip, ix, d = idx.export_csr()
+    df = np.bincount(ix, minlength=V)
+    q = oracle.synth_queries(1, 19, kind=synth.KIND_SKEW)
+    heads_only = np.zeros((2, V), np.float32)                      # queries that touch head columns only / one ordinary column only
+    heads_only[0, np.nonzero(df >= n // 2)[0][:40]] = np.linspace(0.5, 2.0, 40, dtype=np.float32)
+    heads_only[1, np.nonzero((df > 0) & (df < n // 100))[0][:3]] = 1.25
+    q = np.concatenate([q, heads_only])
+    ref_ids, ref_sc, info = _search(idx, q, 100, blocked_postings=0)
+    assert info.last_path == 1
+    seen = {}
+    for head in (0, 2, -1, 8, 64):
+        ids, sc, info = _search(idx, q, 100, blocked_postings=1, postings_head=head)
+        assert info.last_path == 3, head
+        assert (ids == ref_ids).all() and (sc == ref_sc).all(), f"postings_head={head}: differs from the CSR scan"
+        seen[head] = info.head_columns
+    assert seen[0] == 0
+    assert seen[2] == int((df >= -(-n // 2)).sum()) and seen[-1] == int((df >= -(-n // 4)).sum())
+    assert seen[2] < seen[-1] <= seen[8] <= seen[64] == 512
+    _, _, allsc = oracle.csr_search(ip, ix, d.astype(np.float32), V, q, 100, acc64=True, return_all=True)
+    compare.check_topk_valid(allsc, ref_ids, ref_sc, rtol=RTOL)
+    # forced exact pass and the fp64 walk on the same index (the latter rebuilds the copy without strips)
+    for opts in (dict(postings_force_fallback=1), dict(postings_filter=0)):
+        ids, sc, info = _search(idx, q, 100, blocked_postings=1, postings_head=-1, **opts)
+        assert (ids == ref_ids).all() and (sc == ref_sc).all(), opts
+        idx.set_option("postings_force_fallback", 0)
+    assert info.last_path == 2 and info.head_columns == 0
+
+
+def test_signed_values_get_no_head_strips():
+    """The strips hold fp16 copies and the proof for them needs non-negative values: a signed index keeps every column in lists."""
+    n = 6000
+    ip, ix, d = oracle.synth_csr(0, 0, n, V, 768, synth.KIND_SKEW)
+    d = d * np.where(np.random.default_rng(3).random(len(d)) < 0.25, -1.0, 1.0).astype(np.float32)
+    idx = DeviceIndex.from_csr(ip, ix, d, V)
+    q = oracle.synth_queries(2, 11, kind=synth.KIND_SKEW)
+    ref_ids, ref_sc, _ = _search(idx, q, 50, blocked_postings=0)
+    ids, sc, info = _search(idx, q, 50, blocked_postings=1)
+    assert info.last_path == 3 and info.head_columns == 0
+    assert (ids == ref_ids).all() and (sc == ref_sc).all()

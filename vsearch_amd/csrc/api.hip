@@ -107,8 +107,12 @@ extern "C" int vs_index_set_option(vs_index* idx, const char* name, int value) {
         return VS_OK;
     }
     if (n == "postings_head") {
-        if (value < -1 || value > 0) return fail(VS_EINVAL, "postings_head: -1 = auto, 0 = no dense strips");
-        if (value != idx->bp_head_pref) { idx->bp_dir.release(); idx->bp_base.release(); idx->bp_rec.release(); idx->bp_ready = false; idx->bp_tried = false; }
+        if (value < -1 || value == 1 || value > 64)
+            return fail(VS_EINVAL, "postings_head: -1 = auto (4), 0 = no dense strips, N in 2..64 = columns present in >= 1/N of the documents");
+        if (value != idx->bp_head_pref) {
+            idx->bp_dir.release(); idx->bp_base.release(); idx->bp_rec.release(); idx->bp_strip.release(); idx->bp_hmap.release();
+            idx->bp_n_head = 0; idx->bp_ready = false; idx->bp_tried = false;
+        }
         idx->bp_head_pref = value;
         return VS_OK;
     }

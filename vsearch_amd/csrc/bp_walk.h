@@ -105,22 +105,48 @@ __global__ __launch_bounds__(kScanThreads) void bp_count_kernel(const uint32_t* 
 // coalesced and multiply-added in registers at block end -- than as a 2048-posting list of scatter-adds (an LDS atomic costs
 // ~20 lane-cycles, a fused multiply-add 1/64 of an instruction).  hmap[c] = strip index of column c, 0xFFFF = ordinary column.
 constexpr int kBpHeadCap = 512;
+// One workgroup.  Deterministic: when more than `cap` columns reach `thresh`, the threshold rises to the smallest document
+// count that leaves at most `cap` of them; strip indexes follow column order.
 template <int UNUSED>
 __global__ __launch_bounds__(kScanThreads) void bp_head_select_kernel(const unsigned long long* df_nnz, int32_t n_cols, unsigned long long thresh, int32_t cap,
                                                                       uint16_t* hmap, int32_t* n_head) {
     __shared__ int cnt;
-    if (threadIdx.x == 0) cnt = 0;
-    __syncthreads();
-    for (int c = threadIdx.x; c < n_cols; c += kScanThreads) {
-        uint16_t h = 0xFFFFu;
-        if (df_nnz[c] >= thresh) {
-            const int i = atomicAdd(&cnt, 1);
-            if (i < cap) h = (uint16_t)i;
+    __shared__ int part[kScanThreads];
+    const int tid = threadIdx.x;
+    const int per = (n_cols + kScanThreads - 1) / kScanThreads;
+    const int c0 = min(n_cols, tid * per), c1 = min(n_cols, c0 + per);
+    auto count_ge = [&](unsigned long long t) {
+        __syncthreads();
+        if (tid == 0) cnt = 0;
+        __syncthreads();
+        int n = 0;
+        for (int c = c0; c < c1; ++c) n += df_nnz[c] >= t ? 1 : 0;
+        if (n) atomicAdd(&cnt, n);
+        __syncthreads();
+        return cnt;
+    };
+    if (count_ge(thresh) > cap) {
+        // smallest t in (thresh, 2^63] with count_ge(t) <= cap
+        unsigned long long lo = thresh, hi = 1ull << 62;            // count_ge(lo) > cap, count_ge(hi) = 0
+        while (hi - lo > 1) {
+            const unsigned long long mid = lo + (hi - lo) / 2;
+            if (count_ge(mid) > cap) lo = mid; else hi = mid;
         }
-        hmap[c] = h;
+        thresh = hi;
+    }
+    int n = 0;
+    for (int c = c0; c < c1; ++c) n += df_nnz[c] >= thresh ? 1 : 0;
+    __syncthreads();
+    part[tid] = n;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int i = 0; i < kScanThreads; ++i) { const int v = part[i]; part[i] = run; run += v; }
+        n_head[0] = run;
     }
     __syncthreads();
-    if (threadIdx.x == 0) n_head[0] = min(cnt, cap);
+    int run = part[tid];
+    for (int c = c0; c < c1; ++c) hmap[c] = df_nnz[c] >= thresh ? (uint16_t)run++ : (uint16_t)0xFFFFu;
 }
 
 // pass 2: exclusive scan of the block totals -> base[b] (records), base[n_blocks] = all records.  One workgroup.
@@ -328,8 +354,10 @@ __device__ __forceinline__ uint32_t quad_bcast(uint32_t x) {          // lane U 
 
 // LG = lanes per posting list (8 for the long lists of a valued index, 1 for the short lists of the bag-of-token index),
 // RMAX = block capacity in documents
-template <int VM, int QT, int AM, int LG, int RMAX, int NB = kBpNB>
+// HD = 1: the index has head columns (dense strips); 0 compiles that path out.
+template <int VM, int QT, int AM, int LG, int RMAX, int NB = kBpNB, int HD = 0>
 __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
+    static_assert(!HD || (AM == AM_FIX && VM != VM_BIN), "dense strips: valued filter walk only");
     static_assert(bp_acc_bytes<QT, AM, RMAX>() >= kBpSortBytes, "the accumulator area holds the 8192-slot entry sort");
     static_assert(VM != VM_BIN || RMAX == kBpRowsMaxBin, "pad postings of a binary list carry document id kBpRowsMaxBin");
     static_assert(NB % LG == 0 || LG % NB == 0, "lane l of a group owns the directory pairs of lists l, l + LG, ... of a slot");
@@ -367,7 +395,7 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
         __syncthreads();
         const int64_t e0 = a.qptr[q0], e1 = a.qptr[q0 + nq];
         int n_ent = (int)(e1 - e0);
-        const int n_head = AM == AM_FIX ? a.n_head : 0;
+        const int n_head = HD ? a.n_head : 0;
         for (int i = tid; i < n_head * QT; i += kScanThreads) hw[i] = 0.f;
         if (n_head > 0) __syncthreads();
         // Entries sorted by column (the accumulator area doubles as the sort buffer): neighbouring groups then read neighbouring
@@ -537,7 +565,7 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
                 if (kPairsAhead && b + 1 < b1) first_pairs(b + 1);
             }
             __syncthreads();
-            if constexpr (AM == AM_FIX) {
+            if constexpr (HD != 0) {
                 if (n_head > 0 && have) {
                     // Dense part: the block's values on the head columns x the tile's weights.  A thread takes 8 adjacent documents
                     // (one 16-byte load of fp16 values per head column: a wave reads 1 KB contiguous) and a quarter of the head columns,

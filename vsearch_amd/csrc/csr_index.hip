@@ -466,6 +466,7 @@ extern "C" int vs_index_info(const vs_index* idx, vs_index_info_t* o) {
     o->last_scan_bytes = idx->last_scan_bytes;
     o->last_path = idx->last_path;
     o->last_walk_postings = idx->last_walk_postings;
+    o->head_columns = idx->bp_ready ? idx->bp_n_head : 0;
     if (idx->last_path == 3 && idx->last_plan_dev) {               // the filter search keeps its plan on the device: read it now
         int64_t hp[6] = {0, 0, 0, 0, 0, 0};
         VS_HIP(hipSetDevice(idx->device));
@@ -753,6 +754,11 @@ int launch_bp_walk(const vs_index* idx, const BpArgs& a, int grid, int ent_cap, 
         if (AM != AM_FIX) return fail(VS_EUNSUPPORTED, "binary postings serve the filter walk only");
         kern = idx->bp_lanes == 4 ? bp_walk_topk<VM_BIN, kBpBinQT, AM_FIX, 1, kBpRowsMaxBin, 4> : bp_walk_topk<VM_BIN, kBpBinQT, AM_FIX, 1, kBpRowsMaxBin, 8>;
         lds = bp_lds_bytes<kBpBinQT, AM_FIX, kBpRowsMaxBin>(ent_cap);
+    } else if (AM == AM_FIX && a.n_head > 0) {
+        if constexpr (AM == AM_FIX) {
+            if (vm == VM_F32) kern = idx->bp_lanes == 8 ? bp_walk_topk<VM_F32, QT, AM_FIX, 8, kBpRowsMax, kBpNB, 1> : bp_walk_topk<VM_F32, QT, AM_FIX, 4, kBpRowsMax, kBpNB, 1>;
+            else kern = idx->bp_lanes == 8 ? bp_walk_topk<VM_F16, QT, AM_FIX, 8, kBpRowsMax, kBpNB, 1> : bp_walk_topk<VM_F16, QT, AM_FIX, 4, kBpRowsMax, kBpNB, 1>;
+        }
     } else if (vm == VM_F32) {
         kern = idx->bp_lanes == 8 ? bp_walk_topk<VM_F32, QT, AM, 8, kBpRowsMax> : bp_walk_topk<VM_F32, QT, AM, 4, kBpRowsMax>;
     } else {
@@ -824,7 +830,7 @@ int bp_build(vs_index* idx, hipStream_t s) {
         DevBuf nh;
         VS_TRY(nh.alloc(4));
         VS_TRY(idx->bp_hmap.alloc((size_t)V * 2));
-        hipLaunchKernelGGL(bp_head_select_kernel<0>, dim3(1), dim3(kScanThreads), 0, s, df_nnz, V, (unsigned long long)((idx->n_rows + 3) / 4), kBpHeadCap,
+        hipLaunchKernelGGL(bp_head_select_kernel<0>, dim3(1), dim3(kScanThreads), 0, s, df_nnz, V, (unsigned long long)ceil_div64(idx->n_rows, idx->bp_head_pref > 0 ? idx->bp_head_pref : 4), kBpHeadCap,
                            idx->bp_hmap.as<uint16_t>(), nh.as<int32_t>());
         VS_HIP(hipGetLastError());
         int32_t h_n = 0;
