@@ -246,3 +246,19 @@ def test_signed_values_get_no_head_strips():
     ids, sc, info = _search(idx, q, 50, blocked_postings=1)
     assert info.last_path == 3 and info.head_columns == 0
     assert (ids == ref_ids).all() and (sc == ref_sc).all()
+
+
+@pytest.mark.parametrize("scale,heads", [(1.0 / 1024, False), (1.0 / 16, True), (900.0, True)], ids=["tiny", "small", "large"])
+def test_head_strips_across_value_ranges(scale, heads):
+    """The dense part runs on fp16 operands: weights are rescaled by powers of two from the index's largest value, so value ranges
+    far from 1 keep the proof (and the results); an index whose values sit near the fp16 subnormals keeps every column in lists."""
+    n = 6000
+    ip, ix, d = oracle.synth_csr(0, 0, n, V, 768, synth.KIND_SKEW)
+    d = (d * np.float32(scale)).astype(np.float32)
+    idx = DeviceIndex.from_csr(ip, ix, d, V)
+    q = oracle.synth_queries(2, 13, kind=synth.KIND_SKEW) * np.float32(3.0)
+    ref_ids, ref_sc, _ = _search(idx, q, 100, blocked_postings=0)
+    ids, sc, info = _search(idx, q, 100, blocked_postings=1)
+    assert info.last_path == 3 and (info.head_columns > 0) == heads
+    assert info.last_fallbacks == 0
+    assert (ids == ref_ids).all() and (sc == ref_sc).all()

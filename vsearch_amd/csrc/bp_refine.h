@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void bp_vmax_kernel(const void* vals, int64_t 
 // goes straight to the exact pass.  One wave per query, fixed reduction order.
 template <int UNUSED>
 __global__ __launch_bounds__(256) void bp_qscale_kernel(const int64_t* qptr, const float* qvals, int32_t B, const uint32_t* vmax_bits, int binary, int quant,
-                                                        float* qscale, int32_t* qslack, float* qwsum, const int32_t* qcols, const uint16_t* hmap) {
+                                                        float* qscale, int32_t* qslack, float* qwsum, const int32_t* qcols, const uint16_t* hmap, int32_t head_slack) {
     const int lane = threadIdx.x & 63;
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= B) return;
@@ -80,9 +80,8 @@ __global__ __launch_bounds__(256) void bp_qscale_kernel(const int64_t* qptr, con
     if (lane == 0) {
         qscale[q] = S;
         qwsum[q] = sum * 1.0001f;
-        // the dense part of a score: four fp32 partial sums over `heads` products in all (each rounding loses at most 2^-24 of a
-        // running sum below 2^30, i.e. < 64 units), each truncated once
-        const int64_t dense_slack = heads > 0 ? (int64_t)heads * 128 + 4 : 0;
+        // the dense part of a score (matrix cores, bp_walk.h): bp_head_slack
+        const int64_t dense_slack = heads > 0 ? (int64_t)head_slack : 0;
         qslack[q] = (exact || e1 == e0) ? 0 : (((quant || heads > 0) && neg) ? -1 : (int32_t)min((int64_t)1 << 24, e1 - e0 + 1 + dense_slack));
     }
 }

@@ -101,9 +101,11 @@ __global__ __launch_bounds__(kScanThreads) void bp_count_kernel(const uint32_t* 
 }
 
 // Head columns: a column present in a large share of the documents (skewed vocabularies: the ~500 most popular columns of a
-// Zipf(1) corpus cover 3/4 of all non-zeros) is cheaper as a DENSE strip -- one fp16 value per document of the block, read
-// coalesced and multiply-added in registers at block end -- than as a 2048-posting list of scatter-adds (an LDS atomic costs
-// ~20 lane-cycles, a fused multiply-add 1/64 of an instruction).  hmap[c] = strip index of column c, 0xFFFF = ordinary column.
+// Zipf(1) corpus cover 3/4 of all non-zeros) is cheaper as a DENSE strip -- one fp16 value per document of the block, and the
+// block's [documents x head columns] strip times the tile's [head columns x slots] weights is a small GEMM for the matrix
+// cores -- than as a 2048-posting list of scatter-adds (an LDS atomic costs ~20 lane-cycles).  Measured per block and tile:
+// ~95 clocks per head column (the strip streams from L2 at ~26 TB/s chip-wide) against 4 800 p^2 for a list of density p, so
+// the lists win below p ~ 1/7; the default threshold is 1/4.  hmap[c] = strip index of column c, 0xFFFF = ordinary column.
 constexpr int kBpHeadCap = 512;
 // One workgroup.  Deterministic: when more than `cap` columns reach `thresh`, the threshold rises to the smallest document
 // count that leaves at most `cap` of them; strip indexes follow column order.
@@ -170,6 +172,18 @@ __global__ __launch_bounds__(kScanThreads) void bp_base_kernel(const uint32_t* b
     for (int64_t i = i0; i < i1; ++i) { base[i] = run; run += block_recs[i]; }
 }
 
+// The dense strips, stored in the order v_mfma_f32_16x16x32_f16 wants its A operand (16 documents x 32 head columns per
+// instruction; lane l holds document l & 15, columns 8 * (l >> 4) .. + 7): 16-byte units
+//   [block][k-step = column / 32][document / 16][lane = (column % 32) / 8 * 16 + document % 16], 8 halves (column % 8) each,
+// so a wave reads one operand with ONE coalesced 1 KB load and the 8 operands of its 128 documents from 8 KB contiguous.
+// n_head rounds up to 32 columns (the pad columns are zero).
+__host__ __device__ inline int bp_head_pad(int n_head) { return (n_head + 31) & ~31; }
+__host__ __device__ inline size_t bp_strip_index(int64_t b, int h, int dl, int n_head, int rows) {
+    const size_t ks = (size_t)bp_head_pad(n_head) / 32, mb = (size_t)rows / 16;
+    const size_t unit = (((size_t)b * ks + (size_t)(h >> 5)) * mb + (size_t)(dl >> 4)) * 64 + (size_t)(((h & 31) >> 3) * 16 + (dl & 15));
+    return unit * 8 + (size_t)(h & 7);
+}
+
 // pass 3: scatter the non-zeros into their records (the array is zero-filled first: pad postings are document 0, value 0)
 // VS = value mode of the CSR packets, VM = value mode of the records (VS = fp32, VM = fp16: the lossy filter copy, see bp_refine.h)
 template <int VS, int VM>
@@ -209,8 +223,8 @@ __global__ __launch_bounds__(kScanThreads) void bp_fill_kernel(const uint32_t* p
                 for (int i = 0; i < 8; ++i) {
                     const uint32_t c = (i & 1) ? (cwv[i >> 1] >> 16) : (cwv[i >> 1] & 0xFFFFu);
                     if (c < (uint32_t)n_cols && hmap && hmap[c] != 0xFFFFu) {
-                        // head column: strip[block][strip index][document]
-                        if constexpr (VM != VM_BIN) strip[((size_t)b * n_head + hmap[c]) * rows + dl] = __float2half_rn(v[i]);
+                        // head column: the strip in MFMA A-operand order (bp_strip_index)
+                        if constexpr (VM != VM_BIN) strip[bp_strip_index(b, hmap[c], dl, n_head, rows)] = __float2half_rn(v[i]);
                     } else if (c < (uint32_t)n_cols) {
                         const uint32_t pos = atomicAdd(&cur[c], 1u);
                         char* rp = brec + (size_t)(pos >> 3) * RS;
@@ -274,16 +288,19 @@ struct BpArgs {
     const uint64_t* upper;    // optional [B] exclusive upper bounds ("search after")
     const float* qscale;      // AM_FIX: [B] per-query power-of-two scale of the fixed-point sums
     const uint16_t* hmap;     // head columns (dense strips), n_head > 0 only: [n_cols] strip index or 0xFFFF
-    const __half* strip;      // [n_blocks][n_head][rows] values of the head columns
+    const __half* strip;      // fp16 values of the head columns, MFMA operand order (bp_strip_index)
     int32_t n_head;
+    float head_pre, head_mul; // powers of two: weights enter the fp16 operand as w * scale * head_pre (< 2^15), the sums leave as C * head_mul
 };
 
 // accumulators [RMAX + 1][QT + 1]: the extra row absorbs the pad postings of a binary list (document id RMAX)
 template <int QT, int AM, int RMAX>
 __host__ __device__ constexpr size_t bp_acc_bytes() { return (((size_t)(RMAX + 1) * (QT + 1) * (AM == AM_F64 ? 8 : 4)) + 15) & ~(size_t)15; }
+// the tile's weights on the head columns as the MFMA B operand: [16 = slot + 8 * (hi | lo)][padded columns + 8] halves
+__host__ __device__ inline size_t bp_head_lds(int n_head) { return n_head > 0 ? (size_t)16 * (bp_head_pad(n_head) + 8) * 2 : 0; }
 template <int QT, int AM, int RMAX>
 __host__ __device__ inline size_t bp_lds_bytes(int ent_cap, int n_head = 0) {
-    return bp_acc_bytes<QT, AM, RMAX>() + (size_t)kBpCap * 8 + (size_t)QT * 16 + 64 * 4 + (size_t)ent_cap * 8 + (size_t)n_head * QT * 4;
+    return bp_acc_bytes<QT, AM, RMAX>() + (size_t)kBpCap * 8 + (size_t)QT * 16 + 64 * 4 + (size_t)ent_cap * 8 + bp_head_lds(n_head);
 }
 
 __device__ __forceinline__ uint64_t make_key_fix(int32_t a, uint32_t row) {
@@ -375,7 +392,7 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
     int* scratch = reinterpret_cast<int*>(upper_sh + QT);                                   // [48]
     unsigned int* ccnt = reinterpret_cast<unsigned int*>(scratch + 48);                     // [QT]
     uint2* ent = reinterpret_cast<uint2*>(scratch + 64);                                    // [ent_cap]: x = column | slot byte offset << 16, y = weight bits
-    float* hw = reinterpret_cast<float*>(ent + a.ent_cap);                                  // [n_head][QT] (scaled) weights of the tile on the head columns
+    _Float16* hw = reinterpret_cast<_Float16*>(ent + a.ent_cap);                            // [16][ldb] the tile's weights on the head columns (bp_head_lds)
 
     const int tid = threadIdx.x;
     const int gid = tid / LG, gl = tid % LG;
@@ -396,8 +413,12 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
         const int64_t e0 = a.qptr[q0], e1 = a.qptr[q0 + nq];
         int n_ent = (int)(e1 - e0);
         const int n_head = HD ? a.n_head : 0;
-        for (int i = tid; i < n_head * QT; i += kScanThreads) hw[i] = 0.f;
-        if (n_head > 0) __syncthreads();
+        const int ldb = bp_head_pad(n_head) + 8;                 // + 8 halves: the 16 rows a b128 operand read touches fall in different banks
+        if (n_head > 0) {
+            uint32_t* z = reinterpret_cast<uint32_t*>(hw);
+            for (int i = tid; i < 16 * ldb / 2; i += kScanThreads) z[i] = 0u;
+            __syncthreads();
+        }
         // Entries sorted by column (the accumulator area doubles as the sort buffer): neighbouring groups then read neighbouring
         // directory words and neighbouring posting lists -- the walk over the block's records is a forward sweep with gaps.
         {
@@ -412,7 +433,13 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
                     if constexpr (AM == AM_FIX) w *= a.qscale[q0 + qs];          // power of two: exact
                     const uint32_t col = (uint32_t)a.qcols[e];
                     const uint32_t hx = n_head > 0 ? a.hmap[col] : 0xFFFFu;
-                    if (hx != 0xFFFFu) hw[hx * QT + qs] = w;                      // a head column: its weight joins the dense part, no list to walk
+                    if (hx != 0xFFFFu) {
+                        // a head column: no list to walk, its weight joins the dense part as two fp16 numbers hi + lo (22 bits)
+                        const float ws = w * a.head_pre;
+                        const _Float16 hi = (_Float16)ws;
+                        hw[qs * ldb + hx] = hi;
+                        hw[(8 + qs) * ldb + hx] = (_Float16)(ws - (float)hi);
+                    }
                     else key = ((uint64_t)col << 40) | ((uint64_t)qs << 32) | (uint64_t)__float_as_uint(w);
                 }
                 skey[i] = key;
@@ -566,48 +593,57 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
             }
             __syncthreads();
             if constexpr (HD != 0) {
+                static_assert(QT == 8 && RMAX == 16 * 128, "dense part: 8 slots x (hi, lo) = the 16 columns of the MFMA; a wave takes 128 documents");
                 if (n_head > 0 && have) {
-                    // Dense part: the block's values on the head columns x the tile's weights.  A thread takes 8 adjacent documents
-                    // (one 16-byte load of fp16 values per head column: a wave reads 1 KB contiguous) and a quarter of the head columns,
-                    // keeps 8 x QT fp32 sums in registers, truncates each once and adds it to the accumulators (4 partial sums per
-                    // (document, slot): the quarters).  8.4 M multiply-adds per block and tile run at FMA rate instead of the LDS atomic rate.
-                    const int g = tid & 255, hq = tid >> 8;
-                    const int h0 = hq * n_head / 4, h1 = (hq + 1) * n_head / 4;
-                    float ds[8][QT];
+                    // Dense part: [documents of the block] x [head columns] (fp16 strip) times [head columns] x [8 slots x (hi, lo)]
+                    // (the tile's weights) on the matrix cores -- v_mfma_f32_16x16x32_f16, fp32 accumulate.  Wave w takes documents
+                    // 128 w .. + 127 (8 operand rows of 16), all columns; the strip streams from L2 / Infinity Cache with the next
+                    // k-step's 8 KB in flight while this one multiplies.  Each sum is scaled back (power of two), truncated once and
+                    // added to the accumulators (hi and lo parts separately).
+                    using h8 = __attribute__((ext_vector_type(8))) _Float16;
+                    using f4 = __attribute__((ext_vector_type(4))) float;
+                    const int wv = tid >> 6, ln = tid & 63;
+                    const int ks = bp_head_pad(n_head) / 32, mbk = a.rows / 16;
+                    const _Float16* bp = hw + (ln & 15) * ldb + 8 * (ln >> 4);
+                    const int slot = ln & 7;
+#pragma unroll 1
+                    for (int p = 0; p < 2; ++p) {                           // 64 documents = 4 operand rows at a time
+                        const int d0 = wv * 128 + p * 64;
+                        if (d0 >= rows_b) break;
+                        const uint4* sp = reinterpret_cast<const uint4*>(a.strip) + ((size_t)b * ks * mbk + (size_t)(d0 >> 4)) * 64 + ln;
+                        f4 c[4];
 #pragma unroll
-                    for (int i = 0; i < 8; ++i)
+                        for (int m = 0; m < 4; ++m) c[m] = f4{0.f, 0.f, 0.f, 0.f};
+                        uint4 s0[4], s1[4], s2[4];                           // k-steps j, j + 1, j + 2: two steps (8 KB a wave) in flight
 #pragma unroll
-                        for (int q = 0; q < QT; ++q) ds[i][q] = 0.f;
-                    const uint4* sp = reinterpret_cast<const uint4*>(a.strip + (size_t)b * n_head * a.rows) + g;
-                    const int ldh = a.rows / 8;
-                    if (g * 8 < rows_b) {
-#pragma unroll 2
-                        for (int h = h0; h < h1; ++h) {
-                            const uint4 v8 = sp[(size_t)h * ldh];
-                            const float4 wa = *reinterpret_cast<const float4*>(hw + h * QT);
-                            float wv[QT];
-                            wv[0] = wa.x; wv[1] = wa.y; wv[2] = wa.z; wv[3] = wa.w;
-                            if constexpr (QT == 8) {
-                                const float4 wb = *reinterpret_cast<const float4*>(hw + h * QT + 4);
-                                wv[4] = wb.x; wv[5] = wb.y; wv[6] = wb.z; wv[7] = wb.w;
+                        for (int m = 0; m < 4; ++m) { s0[m] = sp[(size_t)m * 64]; s1[m] = s0[m]; s2[m] = s0[m]; }
+                        if (ks > 1) {
+#pragma unroll
+                            for (int m = 0; m < 4; ++m) s1[m] = sp[((size_t)mbk + m) * 64];
+                        }
+#pragma unroll 1
+                        for (int j = 0; j < ks; ++j) {
+                            if (j + 2 < ks) {
+#pragma unroll
+                                for (int m = 0; m < 4; ++m) s2[m] = sp[((size_t)(j + 2) * mbk + m) * 64];
                             }
-                            const uint32_t vw[4] = {v8.x, v8.y, v8.z, v8.w};
+                            const h8 bf = *reinterpret_cast<const h8*>(bp + 32 * j);
+#pragma unroll
+                            for (int m = 0; m < 4; ++m) {
+                                h8 af;
+                                __builtin_memcpy(&af, &s0[m], 16);
+                                c[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, c[m], 0, 0, 0);
+                            }
+#pragma unroll
+                            for (int m = 0; m < 4; ++m) { s0[m] = s1[m]; s1[m] = s2[m]; }
+                        }
+                        // C: lane holds rows 4 * (ln >> 4) + i, column ln & 15 = slot + 8 * (hi | lo)
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) {
 #pragma unroll
                             for (int i = 0; i < 4; ++i) {
-                                const float2 f = __half22float2(*reinterpret_cast<const __half2*>(&vw[i]));
-#pragma unroll
-                                for (int q = 0; q < QT; ++q) {
-                                    ds[2 * i][q] = fmaf(wv[q], f.x, ds[2 * i][q]);
-                                    ds[2 * i + 1][q] = fmaf(wv[q], f.y, ds[2 * i + 1][q]);
-                                }
-                            }
-                        }
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            const int d = g * 8 + i;
-                            if (d < rows_b) {
-#pragma unroll
-                                for (int q = 0; q < QT; ++q) atomicAdd(&acc[d * PITCH + q], (int32_t)ds[i][q]);
+                                const int d = d0 + m * 16 + 4 * (ln >> 4) + i;
+                                atomicAdd(&acc[d * PITCH + slot], (int32_t)(c[m][i] * a.head_mul));
                             }
                         }
                     }

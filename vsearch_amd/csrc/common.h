@@ -212,6 +212,7 @@ struct vs_index {
     vs::DevBuf bp_hmap;  // uint16 [n_cols]: strip index of a head column (dense strip), 0xFFFF otherwise; valid when bp_n_head > 0
     vs::DevBuf bp_strip; // fp16 [n_blocks][bp_n_head][bp_rows]: values of the head columns
     int bp_n_head = 0;
+    float bp_vmax_f = 1.f;   // max |value| of the index (bp_build)
     int bp_head_pref = -1;   // option "postings_head": -1 auto (columns present in >= 1/4 of the documents, at most 512), 0 = none, N = share 1/N
     vs::DevBuf bp_vmax;  // [2] uint32: float bits of max |value| (bounds the fixed-point walk's products), any-value-negative flag
     int bp_lanes = 8;    // option "postings_lanes": lanes per posting list of a valued index (4 | 8)

@@ -826,7 +826,9 @@ int bp_build(vs_index* idx, hipStream_t s) {
     const bool lossy_ok = hv[1] == 0u && vmax_f < 60000.f;       // fp16 copies of the values: non-negative, no overflow
     // Head columns (skewed vocabularies): present in >= 1/4 of the documents -> dense strips instead of posting lists.  Valued
     // indexes with the filter search only (the strips hold fp16 values: the fp64 walk cannot use them).
-    if (idx->store_dtype != VS_NONE && idx->bp_filter != 0 && idx->bp_head_pref != 0 && idx->n_rows >= 4096 && lossy_ok) {
+    idx->bp_vmax_f = vmax_f;
+    if (idx->store_dtype != VS_NONE && idx->bp_filter != 0 && idx->bp_head_pref != 0 && idx->n_rows >= 4096 && lossy_ok && idx->bp_rows % 128 == 0 &&
+        vmax_f >= 1.f / 64.f) {
         DevBuf nh;
         VS_TRY(nh.alloc(4));
         VS_TRY(idx->bp_hmap.alloc((size_t)V * 2));
@@ -843,7 +845,7 @@ int bp_build(vs_index* idx, hipStream_t s) {
             hipLaunchKernelGGL(bp_count_kernel<0>, dim3(grid), dim3(kScanThreads), lds, s, idx->pk_ptr.as<uint32_t>(), idx->cols.as<uint4>(), idx->n_rows, V,
                                idx->bp_rows, idx->bp_dir.as<uint32_t>(), block_recs.as<uint32_t>(), df_rec, df_nnz, (const uint16_t*)idx->bp_hmap.as<uint16_t>());
             VS_HIP(hipGetLastError());
-            const size_t b_strip = (size_t)n_blocks * h_n * idx->bp_rows * 2;
+            const size_t b_strip = (size_t)n_blocks * bp_head_pad(h_n) * idx->bp_rows * 2;
             VS_HIP(hipMemGetInfo(&free_b, &total_b));
             if (free_b < b_strip + margin || idx->bp_strip.alloc(b_strip) != VS_OK) return no_room(b_strip);
             VS_HIP(hipMemsetAsync(idx->bp_strip.p, 0, b_strip, s));
@@ -893,6 +895,19 @@ int bp_build(vs_index* idx, hipStream_t s) {
     }
     idx->bp_ready = true;
     return VS_OK;
+}
+
+// Error bound, in units of the fixed-point sums, of the dense (matrix-core) part of a filter score against the real sum of
+// weight * scale * fp16 strip value over the head columns (all terms >= 0, the sum < 2^30):
+//   weights split in two fp16 numbers: hi + lo misses <= 2^-22 of each weight                            -> 2^8
+//   lo below the fp16 normal range (taken as flushed to zero): <= 2^-14 of an operand unit, x 2^16       -> 4 per column
+//   strip values below the fp16 normal range (taken as flushed): value < 2^-14, weights sum < 2^30 / max -> 2^16 / max value
+//   fp32 accumulation: 33 additions per k-step of 32 columns, each off by <= one ulp of a sum < 2^30     -> 33 * 128 per k-step
+//   the lo column's own sums are 2^-11 of that; two truncations                                          -> 64 + 2
+int32_t bp_head_slack(const vs_index* idx) {
+    if (idx->bp_n_head <= 0) return 0;
+    const int hp = bp_head_pad(idx->bp_n_head);
+    return 256 + 4 * hp + (int32_t)ceilf(65536.f / idx->bp_vmax_f) + 33 * 128 * (hp / 32) + 66;
 }
 
 // chunks of the postings walk for `n_tiles` query tiles (see bp_filter_search)
@@ -970,7 +985,7 @@ int bp_filter_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64
                            idx->bp_df.as<unsigned long long>() + V, V, dplan + 4);
     hipLaunchKernelGGL(bp_qscale_kernel<0>, dim3((unsigned)ceil_div(B, 4)), dim3(256), 0, s, qptr, qvals, B, idx->bp_vmax.as<uint32_t>(),
                        idx->store_dtype == VS_NONE ? 1 : 0, (idx->bp_quant || idx->bp_n_head > 0) ? 1 : 0, qscale, qslack, qwsum, (const int32_t*)qcols,
-                       idx->bp_n_head > 0 ? (const uint16_t*)idx->bp_hmap.as<uint16_t>() : (const uint16_t*)nullptr);
+                       idx->bp_n_head > 0 ? (const uint16_t*)idx->bp_hmap.as<uint16_t>() : (const uint16_t*)nullptr, bp_head_slack(idx));
     VS_HIP(hipGetLastError());
     VS_STAGE("sparsify", s);
     // 2. the walk.  Work items = (tile, chunk); the tile count lives on the device, the chunks follow its lower bound ceil(B / qt)
@@ -1003,6 +1018,12 @@ int bp_filter_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64
     a.hmap = idx->bp_n_head > 0 ? idx->bp_hmap.as<uint16_t>() : nullptr;
     a.strip = idx->bp_strip.as<__half>();
     a.n_head = idx->bp_n_head;
+    if (a.n_head > 0) {
+        int ve;
+        (void)frexpf(idx->bp_vmax_f, &ve);                          // max value < 2^ve
+        a.head_pre = ldexpf(1.f, ve - 16);                          // weight * scale < 2^30 / max value  ->  * 2^ve / 2^16 < 2^15: an fp16 number
+        a.head_mul = ldexpf(1.f, 16 - ve);
+    }
     idx->last_path = 3;
     idx->last_plan_dev = dplan;
     idx->last_plan_rs = bp_rec_bytes(bp_record_vm(idx));
