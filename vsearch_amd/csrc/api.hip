@@ -117,7 +117,7 @@ extern "C" int vs_index_set_option(vs_index* idx, const char* name, int value) {
         return VS_OK;
     }
     if (n == "postings_lanes") {
-        if (value != 4 && value != 8) return fail(VS_EINVAL, "postings_lanes: 4 | 8");
+        if (value != 0 && value != 4 && value != 8) return fail(VS_EINVAL, "postings_lanes: 0 = auto | 4 | 8");
         idx->bp_lanes = value;
         return VS_OK;
     }

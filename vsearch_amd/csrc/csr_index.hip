@@ -752,17 +752,18 @@ int launch_bp_walk(const vs_index* idx, const BpArgs& a, int grid, int ent_cap, 
     void (*kern)(BpArgs) = nullptr;
     if (vm == VM_BIN) {
         if (AM != AM_FIX) return fail(VS_EUNSUPPORTED, "binary postings serve the filter walk only");
-        kern = idx->bp_lanes == 4 ? bp_walk_topk<VM_BIN, kBpBinQT, AM_FIX, 1, kBpRowsMaxBin, 4> : bp_walk_topk<VM_BIN, kBpBinQT, AM_FIX, 1, kBpRowsMaxBin, 8>;
+        // one lane per list; the option picks the records in flight per lane (4: 15.5 k q/s on the Wiki21M shape, 8: 14.7 k)
+        kern = idx->bp_lanes == 8 ? bp_walk_topk<VM_BIN, kBpBinQT, AM_FIX, 1, kBpRowsMaxBin, 8> : bp_walk_topk<VM_BIN, kBpBinQT, AM_FIX, 1, kBpRowsMaxBin, 4>;
         lds = bp_lds_bytes<kBpBinQT, AM_FIX, kBpRowsMaxBin>(ent_cap);
     } else if (AM == AM_FIX && a.n_head > 0) {
         if constexpr (AM == AM_FIX) {
-            if (vm == VM_F32) kern = idx->bp_lanes == 8 ? bp_walk_topk<VM_F32, QT, AM_FIX, 8, kBpRowsMax, kBpNB, 1> : bp_walk_topk<VM_F32, QT, AM_FIX, 4, kBpRowsMax, kBpNB, 1>;
-            else kern = idx->bp_lanes == 8 ? bp_walk_topk<VM_F16, QT, AM_FIX, 8, kBpRowsMax, kBpNB, 1> : bp_walk_topk<VM_F16, QT, AM_FIX, 4, kBpRowsMax, kBpNB, 1>;
+            if (vm == VM_F32) kern = idx->bp_lanes != 4 ? bp_walk_topk<VM_F32, QT, AM_FIX, 8, kBpRowsMax, kBpNB, 1> : bp_walk_topk<VM_F32, QT, AM_FIX, 4, kBpRowsMax, kBpNB, 1>;
+            else kern = idx->bp_lanes != 4 ? bp_walk_topk<VM_F16, QT, AM_FIX, 8, kBpRowsMax, kBpNB, 1> : bp_walk_topk<VM_F16, QT, AM_FIX, 4, kBpRowsMax, kBpNB, 1>;
         }
     } else if (vm == VM_F32) {
-        kern = idx->bp_lanes == 8 ? bp_walk_topk<VM_F32, QT, AM, 8, kBpRowsMax> : bp_walk_topk<VM_F32, QT, AM, 4, kBpRowsMax>;
+        kern = idx->bp_lanes != 4 ? bp_walk_topk<VM_F32, QT, AM, 8, kBpRowsMax> : bp_walk_topk<VM_F32, QT, AM, 4, kBpRowsMax>;
     } else {
-        kern = idx->bp_lanes == 8 ? bp_walk_topk<VM_F16, QT, AM, 8, kBpRowsMax> : bp_walk_topk<VM_F16, QT, AM, 4, kBpRowsMax>;
+        kern = idx->bp_lanes != 4 ? bp_walk_topk<VM_F16, QT, AM, 8, kBpRowsMax> : bp_walk_topk<VM_F16, QT, AM, 4, kBpRowsMax>;
     }
     if (lds > 160 * 1024) return fail(VS_EUNSUPPORTED, "postings walk needs %zu B of LDS", lds);
     VS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -915,12 +916,14 @@ int bp_choose_chunks(const vs_index* idx, int n_tiles, int64_t n_blocks, int pla
     int nchunk = (int)std::min<int64_t>(choose_chunks(idx, n_tiles, plan_nchunk), n_blocks);
     // Big index, enough tiles: as FEW chunks as give every CU two work items.  Every tile sweeps its chunk's blocks in the same
     // order at the same pace, so with few chunks all tiles are within a few blocks of each other and each block is fetched from
-    // HBM once for all of them (Infinity Cache): 21 M docs, 1024 queries: 4 chunks 300 ms, 8: 333, 16: 399, 64: 561, 2 (one item
-    // per CU, no second round to even out): 419.
+    // HBM once for all of them (Infinity Cache): 21 M docs, 1024 queries, walk time: 2 chunks 203 .. 233 ms (one item per CU,
+    // no second round to even out), 4: 207, 8: 227.  The binary index (short lists, request-bound) is steady at one item per
+    // CU: 2 chunks 63.5 ms, 4: 64.9, 8: 68.1.
     if (idx->n_rows >= (2 << 20) && (int64_t)n_tiles * 4 >= idx->cu_count) {
         int best = 1;
         double best_eff = 0.0;
-        const int c0 = (int)std::max<int64_t>(1, ceil_div64(2 * (int64_t)idx->cu_count, n_tiles));
+        const int per_cu = idx->store_dtype == VS_NONE ? 1 : 2;
+        const int c0 = (int)std::max<int64_t>(1, ceil_div64(per_cu * (int64_t)idx->cu_count, n_tiles));
         for (int c = c0; c <= c0 + 3; ++c) {
             const int64_t it = (int64_t)n_tiles * c;
             const double eff = (double)it / (double)(ceil_div64(it, idx->cu_count) * idx->cu_count);
