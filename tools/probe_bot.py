@@ -11,7 +11,7 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 21_015_324
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 rows_l = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [0]
 chunks_l = [int(x) for x in sys.argv[4].split(",")] if len(sys.argv) > 4 else [0]
-lanes_l = [int(x) for x in sys.argv[5].split(",")] if len(sys.argv) > 5 else [8]
+lanes_l = [int(x) for x in sys.argv[5].split(",")] if len(sys.argv) > 5 else [0]
 idx = DeviceIndex.synthetic(0, 0, N, 29523, 86, 1, 0, nat.VS_NONE)
 q = torch.from_numpy(oracle.synth_queries(1, B, 29523, 776, 1)).cuda()
 first = None

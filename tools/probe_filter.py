@@ -1,4 +1,4 @@
-"""Filter-and-refine postings search vs the fp64 walk and the CSR scan: python tools/probe_filter.py [N] [B] [k] [store]
+"""Filter-and-refine postings search vs the fp64 walk and the CSR scan: python tools/probe_filter.py [N] [B] [k] [store] [modes] [chunks] [lanes] [align]
 Checks that the three paths return identical ids and bit-identical scores and prints their rates."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,11 +13,13 @@ k = int(sys.argv[3]) if len(sys.argv) > 3 else 100
 store = nat.VS_F16 if len(sys.argv) > 4 and sys.argv[4] == "fp16" else nat.VS_F32
 modes = sys.argv[5].split(",") if len(sys.argv) > 5 else ["filter", "f64", "csr"]
 chunk_list = [int(x) for x in sys.argv[6].split(",")] if len(sys.argv) > 6 else [0]
-lanes = int(sys.argv[7]) if len(sys.argv) > 7 else 8
+lanes = int(sys.argv[7]) if len(sys.argv) > 7 else 0
+align = int(sys.argv[8]) if len(sys.argv) > 8 else -1
 idx = DeviceIndex.synthetic(0, 0, N, 29523, 768, 0, 0, store)
 q = torch.from_numpy(oracle.synth_queries(1, B)).cuda()
 res = {}
 idx.set_option("postings_lanes", lanes)
+idx.set_option("postings_align", align)
 for mode, chunks in [(m, c) for m in modes for c in (chunk_list if m != "csr" else [0])]:
     idx.set_option("postings_chunks", chunks)
     idx.set_option("blocked_postings", 0 if mode == "csr" else 1)

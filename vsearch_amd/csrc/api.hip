@@ -96,6 +96,12 @@ extern "C" int vs_index_set_option(vs_index* idx, const char* name, int value) {
         idx->bp_filter = value;
         return VS_OK;
     }
+    if (n == "postings_align") {
+        if (value < -1 || value > 1) return fail(VS_EINVAL, "postings_align: -1 = auto (lists start on 128-byte lines), 0 = packed");
+        if (value != idx->bp_align_pref) { idx->bp_dir.release(); idx->bp_base.release(); idx->bp_rec.release(); idx->bp_ready = false; idx->bp_tried = false; }
+        idx->bp_align_pref = value;
+        return VS_OK;
+    }
     if (n == "postings_force_fallback") {          // tests: the refine step flags every query, so the exact pass decides all results
         idx->bp_force_fb = value != 0;
         return VS_OK;

@@ -8,8 +8,10 @@
 //
 // Layout ("records", all 16-byte aligned): a list is a run of RECORDS of 8 postings -- 8 uint16 document-in-block ids (16 B)
 // followed by their 8 values (fp32: 32 B, fp16: 16 B, binary index: none) -- the last record zero-padded (document 0, value 0:
-// adds nothing).  dir[b][c] = first record of column c in block b (record units, relative to the block), base[b] = first
-// record of block b.  A lane takes whole records (one 16-byte load of ids + one/two of values, no per-posting bounds), a group
+// adds nothing).  dir[b][c] = ONE word per list: (first record of column c in block b, in units of `align` records, relative
+// to the block) << 12 | records of the list; base[b] = first record of block b.  Lists start on a multiple of `align` records
+// (fp16 values: 4 x 32 B = one 128-byte line, so the 7 records of an average list are exactly two lines instead of 2.5 -- the
+// walk is bound by the lines a CU can pull through its L1).  A lane takes whole records (one 16-byte load of ids + one/two of values, no per-posting bounds), a group
 // of LG lanes takes consecutive records of one list, so a list of n postings is ~6 n contiguous bytes: with 128-byte cache
 // lines that is what decides how many of the fetched bytes are used (rocprofv3, 21 M docs: the round-1 layout -- ids and values
 // in separate arrays, 832-document blocks, 22-posting lists -- moved 6.7 TB through L2->L1 for 2.8 TB of postings and held the
@@ -47,6 +49,11 @@ constexpr int kBpNB = 4;              // posting lists whose loads are in flight
 constexpr size_t kBpSortBytes = (size_t)8192 * 8;   // the entry sort of a tile (8192 slots) borrows the accumulator area
 
 __host__ __device__ constexpr int bp_rec_bytes(int vm) { return vm == VM_F32 ? 48 : (vm == VM_F16 ? 32 : 16); }
+// lists start on a multiple of 2^shift records: 4 x 32 B = one 128-byte line, 8 x 48 B = three; the one-record lists of a binary index stay packed
+__host__ __device__ constexpr int bp_align_shift(int vm) { return vm == VM_F32 ? 3 : (vm == VM_F16 ? 2 : 0); }
+// directory word of a list: first record (in alignment units, relative to the block) << 12 | records
+constexpr uint32_t kBpDirRecMask = 0xFFFu, kBpDirUnitMax = 0xFFFFFu;
+__host__ __device__ inline uint32_t bp_dir_pack(uint32_t unit, uint32_t recs) { return (unit << 12) | (recs & kBpDirRecMask); }
 
 // ---- builder ------------------------------------------------------------------------------------------------------
 // pass 1: one workgroup per block: postings per column -> records per column -> directory (record offsets) + block total;
@@ -54,7 +61,7 @@ __host__ __device__ constexpr int bp_rec_bytes(int vm) { return vm == VM_F32 ? 4
 template <int UNUSED>
 __global__ __launch_bounds__(kScanThreads) void bp_count_kernel(const uint32_t* pk_ptr, const uint4* cols, int64_t n_rows, int32_t n_cols, int32_t rows,
                                                                 uint32_t* dir, uint32_t* block_recs, unsigned long long* df_rec,
-                                                                unsigned long long* df_nnz, const uint16_t* hmap) {
+                                                                unsigned long long* df_nnz, const uint16_t* hmap, int32_t al_shift, int32_t* overflow) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint32_t* cnt = reinterpret_cast<uint32_t*>(smem);                  // [n_cols + 1]
     __shared__ int scratch[32];
@@ -82,21 +89,24 @@ __global__ __launch_bounds__(kScanThreads) void bp_count_kernel(const uint32_t* 
         const int i0 = tid * seg, i1 = min(n_cols + 1, i0 + seg);
         // (head columns -- hmap[c] != 0xFFFF -- live in the dense strips: no records, empty lists)
         auto recs_of = [&](int i) -> uint32_t { return (hmap && i < n_cols && hmap[i] != 0xFFFFu) ? 0u : (cnt[i] + 7u) >> 3; };
+        // a list starts on a multiple of 2^al_shift records: the scan runs in those units
+        const uint32_t al_mask = (1u << al_shift) - 1u;
         int mine = 0;
-        for (int i = i0; i < i1; ++i) mine += (int)recs_of(i);
+        for (int i = i0; i < i1; ++i) mine += (int)((recs_of(i) + al_mask) >> al_shift);
         int tot = 0;
         int off = block_excl_scan(mine, scratch, tid, &tot);
         uint32_t* d = dir + (size_t)b * (n_cols + 1);
         for (int i = i0; i < i1; ++i) {
             const uint32_t c = cnt[i], r = recs_of(i);
-            d[i] = (uint32_t)off;
-            off += (int)r;
+            d[i] = bp_dir_pack((uint32_t)off, r);
+            if (r > kBpDirRecMask || (uint32_t)off > kBpDirUnitMax) overflow[0] = 1;
+            off += (int)((r + al_mask) >> al_shift);
             if (i < n_cols && c) {
                 atomicAdd(&df_rec[i], (unsigned long long)r);
                 atomicAdd(&df_nnz[i], (unsigned long long)c);
             }
         }
-        if (tid == 0) block_recs[b] = (uint32_t)tot;
+        if (tid == 0) block_recs[b] = (uint32_t)tot << al_shift;
     }
 }
 
@@ -189,7 +199,7 @@ __host__ __device__ inline size_t bp_strip_index(int64_t b, int h, int dl, int n
 template <int VS, int VM>
 __global__ __launch_bounds__(kScanThreads) void bp_fill_kernel(const uint32_t* pk_ptr, const uint4* cols, const void* vals, int64_t n_rows,
                                                                int32_t n_cols, int32_t rows, const uint32_t* dir, const unsigned long long* base,
-                                                               char* rec, const uint16_t* hmap, __half* strip, int32_t n_head) {
+                                                               char* rec, const uint16_t* hmap, __half* strip, int32_t n_head, int32_t al_shift) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint32_t* cur = reinterpret_cast<uint32_t*>(smem);                  // [n_cols + 1] write cursors in postings
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -199,7 +209,7 @@ __global__ __launch_bounds__(kScanThreads) void bp_fill_kernel(const uint32_t* p
         const int64_t r0 = b * rows, r1 = min(n_rows, r0 + rows);
         const uint32_t* d = dir + (size_t)b * (n_cols + 1);
         __syncthreads();
-        for (int i = tid; i <= n_cols; i += kScanThreads) cur[i] = d[i] * 8u;
+        for (int i = tid; i <= n_cols; i += kScanThreads) cur[i] = ((d[i] >> 12) << al_shift) * 8u;
         __syncthreads();
         char* brec = rec + (size_t)base[b] * RS;
         for (int64_t r = r0 + w; r < r1; r += kScanWaves) {
@@ -240,7 +250,7 @@ __global__ __launch_bounds__(kScanThreads) void bp_fill_kernel(const uint32_t* p
             // the accumulators (document id = the block capacity), whatever they add is never read
             __syncthreads();
             for (int i = tid; i < n_cols; i += kScanThreads) {
-                const uint32_t lim = d[i + 1] * 8u;
+                const uint32_t lim = (((d[i] >> 12) << al_shift) + (d[i] & kBpDirRecMask)) * 8u;
                 for (uint32_t pos = cur[i]; pos < lim; ++pos) reinterpret_cast<uint16_t*>(brec + (size_t)(pos >> 3) * RS)[pos & 7u] = (uint16_t)kBpRowsMaxBin;
             }
         }
@@ -268,7 +278,8 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_kernel(const uint32_t* c
 // ---- walk ---------------------------------------------------------------------------------------------------------
 struct BpArgs {
     int32_t rows;             // documents per block (<= the kernel's RMAX)
-    const uint32_t* dir;      // [n_blocks, n_cols + 1] record offsets inside the block
+    const uint32_t* dir;      // [n_blocks, n_cols + 1] one word per list (bp_dir_pack)
+    int32_t al_shift;         // lists start on a multiple of 2^al_shift records
     const unsigned long long* base;   // [n_blocks + 1] first record of a block
     const char* rec;          // records
     int64_t n_rows;
@@ -291,6 +302,8 @@ struct BpArgs {
     const __half* strip;      // fp16 values of the head columns, MFMA operand order (bp_strip_index)
     int32_t n_head;
     float head_pre, head_mul; // powers of two: weights enter the fp16 operand as w * scale * head_pre (< 2^15), the sums leave as C * head_mul
+    unsigned long long* timing;   // optional (VS_BP_TIMING=1): [8] wave-cycles per phase, summed over waves: 0 item prologue, 1 list walk,
+                                  // 2 wait at the barrier after the walk, 3 dense part, 4 epilogue; [5] = blocks x waves
 };
 
 // accumulators [RMAX + 1][QT + 1]: the extra row absorbs the pad postings of a binary list (document id RMAX)
@@ -396,7 +409,6 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
 
     const int tid = threadIdx.x;
     const int gid = tid / LG, gl = tid % LG;
-    constexpr int NG = kScanThreads / LG;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;     // LDS address of the accumulators
     const int K = a.k;
     uint64_t* my_gcand = a.gcand + (size_t)blockIdx.x * QT * kBpCap;
@@ -408,6 +420,15 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
     for (int64_t item = blockIdx.x; item < items; item += gridDim.x) {
         const int tile = (int)(item / a.nchunk), c = (int)(item % a.nchunk);
         const int q0 = a.tiles[tile].x, nq = a.tiles[tile].y;
+        long long tm = a.timing ? (long long)__builtin_readcyclecounter() : 0;
+        uint32_t tacc[6] = {0u, 0u, 0u, 0u, 0u, 0u};              // (flushed once per item: 6 atomics per wave)
+        auto lap = [&](int phase) {
+            if (a.timing) {
+                const long long now = (long long)__builtin_readcyclecounter();
+                tacc[phase] += (uint32_t)(now - tm);
+                tm = now;
+            }
+        };
         const int64_t b0 = (int64_t)c * a.blocks_per_chunk, b1 = min(n_blocks, b0 + a.blocks_per_chunk);
         __syncthreads();
         const int64_t e0 = a.qptr[q0], e1 = a.qptr[q0 + nq];
@@ -463,26 +484,36 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
         for (int i = tid; i < RMAX * PITCH; i += kScanThreads) acc[i] = (acc_t)0;
         if (tid < QT) { tau[tid] = 0ull; ccnt[tid] = 0u; }
         if (tid < QT) upper_sh[tid] = (a.upper && tid < nq) ? a.upper[q0 + tid] : ~0ull;
+        if (tid < 2) scratch[40 + tid] = 0;                   // chunk counters of even / odd blocks (below)
         __syncthreads();
 
+        // Entries are dealt to the waves in CHUNKS of CW = (groups per wave) x NB consecutive entries -- one slot of a wave.  A wave's
+        // first chunk of a block is its own number; the following ones it takes from a counter in LDS as it goes (one atomic per
+        // slot, fetched a slot ahead), so the waves reach the block's barrier within one slot of each other whatever their lists'
+        // lengths (static dealing left 11 % of the wave-cycles of the valued walk, 18 % of the binary one, waiting there).
+        constexpr int GPW = 64 / LG, CW = GPW * NB, NW = kScanThreads / 64;
+        const int wv_id = tid >> 6, gw = gid & (GPW - 1);
+        int* chunk_cnt = scratch + 40;
+        auto grab = [&](int par) {
+            int v = 0;
+            if ((tid & 63) == 0) v = atomicAdd(&chunk_cnt[par], 1);
+            return NW + __builtin_amdgcn_readfirstlane(v);
+        };
         // directory pairs of a block's first slot: fetched while the previous block is finished (they stay in flight across its epilogue)
-        uint32_t nlo[OWN], nhi[OWN];
+        uint32_t nd[OWN];
         auto first_pairs = [&](int64_t bb) {
             const uint32_t* dirn = a.dir + (size_t)bb * dir_ld;
 #pragma unroll
             for (int o = 0; o < OWN; ++o) {
-                const int e = gid + NG * ((LG >= NB ? (gl & (NB - 1)) : gl) + LG * o);       // LG >= NB: every quad of the group holds all NB pairs
-                nlo[o] = 0; nhi[o] = 0;
-                if (e < n_ent) {
-                    const uint32_t cc = ent[e].x & 0xFFFFu;
-                    nlo[o] = dirn[cc];
-                    nhi[o] = dirn[cc + 1];
-                }
+                const int e = wv_id * CW + ((LG >= NB ? (gl & (NB - 1)) : gl) + LG * o) * GPW + gw;   // LG >= NB: every quad of the group holds all NB words
+                nd[o] = 0;
+                if (e < n_ent) nd[o] = dirn[ent[e].x & 0xFFFFu];
             }
         };
         // (short binary lists: one or two slots per block, the directory latency would be exposed once per block; with the long
         //  lists of a valued index the pairs are fetched at block start -- holding them across the epilogue costs more than it hides)
         constexpr bool kPairsAhead = LG == 1;
+        lap(0);
         if (kPairsAhead && b0 < b1) first_pairs(b0);
         for (int64_t b = b0; b < b1 || b == b0; ++b) {
             const bool have = b < b1;
@@ -500,98 +531,128 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
                 // its list's end re-reads the record at the end: always inside the array) so that no loaded register is merged with
                 // an older value; only the adds are predicated.
                 if (!kPairsAhead) first_pairs(b);
-                for (int j = 0; gid + NG * (NB * j) < n_ent; ++j) {
-                    uint32_t clo[OWN], chi[OWN];
+                const int par = (int)(b & 1);
+                int cur = wv_id, nxt = grab(par);
+                while (cur * CW < n_ent) {
+                    uint32_t cd[OWN];
 #pragma unroll
                     for (int o = 0; o < OWN; ++o) {
-                        clo[o] = nlo[o]; chi[o] = nhi[o];
-                        nlo[o] = 0; nhi[o] = 0;
-                        const int e = gid + NG * ((LG >= NB ? (gl & (NB - 1)) : gl) + LG * o + NB * (j + 1));
-                        if (e < n_ent) {
-                            const uint32_t cc = ent[e].x & 0xFFFFu;
-                            nlo[o] = dirb[cc];
-                            nhi[o] = dirb[cc + 1];
-                        }
+                        cd[o] = nd[o];
+                        nd[o] = 0;
+                        const int e = nxt * CW + ((LG >= NB ? (gl & (NB - 1)) : gl) + LG * o) * GPW + gw;
+                        if (e < n_ent) nd[o] = dirb[ent[e].x & 0xFFFFu];
                     }
+                    const int cbase = cur * CW;
+                    cur = nxt;
+                    nxt = grab(par);
                     uint32_t rec[NB], end[NB];
                     uint2 en[NB];
                     bool more = false;
-                    uint32_t blo[NB], bhi[NB];                      // list u of the slot: its pair sits in lane u of every quad (LG >= 4) / in register u
+                    uint32_t bd[NB];                                // list u of the slot: its directory word sits in lane u of every quad (LG >= 4) / in register u
                     if constexpr (LG == 1) {
 #pragma unroll
-                        for (int u = 0; u < NB; ++u) { blo[u] = clo[u]; bhi[u] = chi[u]; }
+                        for (int u = 0; u < NB; ++u) bd[u] = cd[u];
                     } else {
-                        static_assert(NB == 4 && OWN == 1, "quad broadcast of four pairs");      // (NB = 8 is the one-lane-per-list case)
-                        blo[0] = quad_bcast<0>(clo[0]); blo[1] = quad_bcast<1>(clo[0]); blo[2] = quad_bcast<2>(clo[0]); blo[3] = quad_bcast<3>(clo[0]);
-                        bhi[0] = quad_bcast<0>(chi[0]); bhi[1] = quad_bcast<1>(chi[0]); bhi[2] = quad_bcast<2>(chi[0]); bhi[3] = quad_bcast<3>(chi[0]);
+                        static_assert(NB == 4 && OWN == 1, "quad broadcast of four words");      // (NB = 8 is the one-lane-per-list case)
+                        bd[0] = quad_bcast<0>(cd[0]); bd[1] = quad_bcast<1>(cd[0]); bd[2] = quad_bcast<2>(cd[0]); bd[3] = quad_bcast<3>(cd[0]);
                     }
 #pragma unroll
                     for (int u = 0; u < NB; ++u) {
-                        const uint32_t lo = blo[u], hi = bhi[u];
+                        const uint32_t lo = (bd[u] >> 12) << a.al_shift, hi = lo + (bd[u] & kBpDirRecMask);
                         rec[u] = lo + gl; end[u] = hi;
                         more = more || (rec[u] < end[u]);
-                        en[u] = ent[min(gid + NG * (u + NB * j), n_ent - 1)];       // (column | slot offset << 16, weight): LDS broadcast per group
+                        en[u] = ent[min(cbase + u * GPW + gw, n_ent - 1)];          // (column | slot offset << 16, weight): LDS broadcast per group
                     }
+                    // the 8 postings of one record into the accumulators of slot / weight `e`
+                    auto add_record = [&](const u32x4& idv, const u32x4& vav, const u32x4& vbv, const uint2 e) {
+                        const float wq = __uint_as_float(e.y);
+                        const uint32_t so = (e.x >> 16) + lds0;                     // LDS byte address of [document 0][slot]
+                        const uint32_t dw[4] = {idv.x, idv.y, idv.z, idv.w};
+                        float vv[8];
+                        if constexpr (VM == VM_F32) {
+                            vv[0] = __uint_as_float(vav.x); vv[1] = __uint_as_float(vav.y); vv[2] = __uint_as_float(vav.z);
+                            vv[3] = __uint_as_float(vav.w); vv[4] = __uint_as_float(vbv.x); vv[5] = __uint_as_float(vbv.y);
+                            vv[6] = __uint_as_float(vbv.z); vv[7] = __uint_as_float(vbv.w);
+                        } else if constexpr (VM == VM_F16) {
+                            const uint32_t hw2[4] = {vav.x, vav.y, vav.z, vav.w};
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) {
+                                const float2 f = __half22float2(*reinterpret_cast<const __half2*>(&hw2[t]));
+                                vv[2 * t] = f.x; vv[2 * t + 1] = f.y;
+                            }
+                        }
+                        [[maybe_unused]] int32_t wi = 0;
+                        [[maybe_unused]] double wd = 0.0;
+                        if constexpr (VM == VM_BIN && AM == AM_FIX) wi = (int32_t)wq;
+                        if constexpr (VM == VM_BIN && AM == AM_F64) wd = (double)wq;
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) {
+                            const uint32_t off = (t & 1) ? acc_off_hi(dw[t >> 1], PITCHB, so) : acc_off_lo(dw[t >> 1], PITCHB, so);
+                            if constexpr (VM == VM_BIN) {
+                                // (pad postings of a binary list carry document id RMAX: the scratch row behind the accumulators)
+                                if constexpr (AM == AM_FIX) lds_add(off, wi);
+                                else lds_add(off, wd);
+                            } else {
+                                const float prod = wq * vv[t];
+                                if constexpr (AM == AM_FIX) lds_add(off, (int32_t)prod);
+                                else lds_add(off, (double)prod);
+                            }
+                        }
+                    };
+                    // A list longer than the group's LG records per round (64 postings: 1 list in 15 at 53 postings a list) would cost
+                    // the whole wave a second round of loads for a handful of lanes -- 9 slots in 10 have such a list somewhere in the
+                    // wave, and the walk is bound by exactly that latency.  So a lane also loads, in the SAME round, the second record
+                    // it owes to the first of its lists that has one (kTail): second rounds become rare (two long lists in one group's
+                    // slot, or a list beyond 128 postings).
+                    constexpr bool kTail = LG > 1 && VM != VM_BIN;
                     while (__builtin_amdgcn_ballot_w64(more)) {
-                        // 12 loads per lane (fp32 records) are issued back to back -- hand-written: the compiler sinks plain loads into
-                        // the predicated blocks below and then waits for each list separately -- and each list waits only for its own.
+                        // The loads of a round are issued back to back -- hand-written: the compiler sinks plain loads into the
+                        // predicated blocks below and then waits for each list separately -- and each list waits only for its own.
                         u32x4 ids[NB], va[NB], vb[NB];
+                        [[maybe_unused]] u32x4 tid_r, tva_r, tvb_r = u32x4{0u, 0u, 0u, 0u};
+                        [[maybe_unused]] uint32_t trec = 0, tend = 0;
+                        [[maybe_unused]] uint2 ten = en[0];
+                        [[maybe_unused]] int tu = -1;
 #pragma unroll
                         for (int u = 0; u < NB; ++u) {
                             const uint32_t off = __umul24(min(rec[u], end[u]), (uint32_t)RS);
                             if constexpr (VM == VM_F32) load_rec48(ids[u], va[u], vb[u], off, brec);
                             else if constexpr (VM == VM_F16) load_rec32(ids[u], va[u], off, brec);
                             else load_rec16(ids[u], off, brec);
+                            if constexpr (kTail) {
+                                if (tu < 0 && rec[u] + LG < end[u]) { tu = u; trec = rec[u] + LG; tend = end[u]; ten = en[u]; }
+                            }
                         }
+                        if constexpr (kTail) {
+                            const uint32_t off = __umul24(min(trec, tend), (uint32_t)RS);      // (no tail: record 0 of the block, not added)
+                            if constexpr (VM == VM_F32) load_rec48(tid_r, tva_r, tvb_r, off, brec);
+                            else load_rec32(tid_r, tva_r, off, brec);
+                        }
+                        constexpr int kPer = VM == VM_F32 ? 3 : (VM == VM_F16 ? 2 : 1);       // loads per record
+                        constexpr int kAfter = kTail ? kPer : 0;                                // issued after the lists' own
                         more = false;
 #pragma unroll
                         for (int u = 0; u < NB; ++u) {
-                            if constexpr (VM == VM_F32) wait_loads((NB - 1 - u) * 3, ids[u], va[u], vb[u]);
-                            else if constexpr (VM == VM_F16) wait_loads((NB - 1 - u) * 2, ids[u], va[u]);
+                            if constexpr (VM == VM_F32) wait_loads((NB - 1 - u) * 3 + kAfter, ids[u], va[u], vb[u]);
+                            else if constexpr (VM == VM_F16) wait_loads((NB - 1 - u) * 2 + kAfter, ids[u], va[u]);
                             else wait_loads(NB - 1 - u, ids[u]);
-                            if (rec[u] < end[u]) {
-                                const float wq = __uint_as_float(en[u].y);
-                                const uint32_t so = (en[u].x >> 16) + lds0;         // LDS byte address of [document 0][slot]
-                                const uint32_t dw[4] = {ids[u].x, ids[u].y, ids[u].z, ids[u].w};
-                                float vv[8];
-                                if constexpr (VM == VM_F32) {
-                                    vv[0] = __uint_as_float(va[u].x); vv[1] = __uint_as_float(va[u].y); vv[2] = __uint_as_float(va[u].z);
-                                    vv[3] = __uint_as_float(va[u].w); vv[4] = __uint_as_float(vb[u].x); vv[5] = __uint_as_float(vb[u].y);
-                                    vv[6] = __uint_as_float(vb[u].z); vv[7] = __uint_as_float(vb[u].w);
-                                } else if constexpr (VM == VM_F16) {
-                                    const uint32_t hw[4] = {va[u].x, va[u].y, va[u].z, va[u].w};
-#pragma unroll
-                                    for (int t = 0; t < 4; ++t) {
-                                        const float2 f = __half22float2(*reinterpret_cast<const __half2*>(&hw[t]));
-                                        vv[2 * t] = f.x; vv[2 * t + 1] = f.y;
-                                    }
-                                }
-                                [[maybe_unused]] int32_t wi = 0;
-                                [[maybe_unused]] double wd = 0.0;
-                                if constexpr (VM == VM_BIN && AM == AM_FIX) wi = (int32_t)wq;
-                                if constexpr (VM == VM_BIN && AM == AM_F64) wd = (double)wq;
-#pragma unroll
-                                for (int t = 0; t < 8; ++t) {
-                                    const uint32_t off = (t & 1) ? acc_off_hi(dw[t >> 1], PITCHB, so) : acc_off_lo(dw[t >> 1], PITCHB, so);
-                                    if constexpr (VM == VM_BIN) {
-                                        // (pad postings of a binary list carry document id RMAX: the scratch row behind the accumulators)
-                                        if constexpr (AM == AM_FIX) lds_add(off, wi);
-                                        else lds_add(off, wd);
-                                    } else {
-                                        const float prod = wq * vv[t];
-                                        if constexpr (AM == AM_FIX) lds_add(off, (int32_t)prod);
-                                        else lds_add(off, (double)prod);
-                                    }
-                                }
-                            }
-                            rec[u] += LG;
+                            if (rec[u] < end[u]) add_record(ids[u], va[u], vb[u], en[u]);
+                            rec[u] += (kTail && tu == u) ? 2 * LG : LG;
                             more = more || (rec[u] < end[u]);
+                        }
+                        if constexpr (kTail) {
+                            if constexpr (VM == VM_F32) wait_loads(0, tid_r, tva_r, tvb_r);
+                            else wait_loads(0, tid_r, tva_r);
+                            if (trec < tend) add_record(tid_r, tva_r, tvb_r, ten);
                         }
                     }
                 }
                 if (kPairsAhead && b + 1 < b1) first_pairs(b + 1);
             }
+            lap(1);
             __syncthreads();
+            if (tid == 0) scratch[40 + (int)((b + 1) & 1)] = 0;     // the next block's chunk counter (its last user was block b - 1)
+            lap(2);
             if constexpr (HD != 0) {
                 static_assert(QT == 8 && RMAX == 16 * 128, "dense part: 8 slots x (hi, lo) = the 16 columns of the MFMA; a wave takes 128 documents");
                 if (n_head > 0 && have) {
@@ -650,22 +711,33 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
                     __syncthreads();
                 }
             }
+            lap(3);
             // epilogue: 1024 documents at a time, one per thread: its QT sums -> order keys -> candidates; prune when a buffer could overflow
             for (int d0 = 0; d0 < rows_b || d0 == 0; d0 += kScanThreads) {
                 const int d = d0 + tid;
+                // the score halves of the thresholds, once per round: nearly every (document, slot) ends at ONE 32-bit compare
+                uint32_t thi[QT];
+#pragma unroll
+                for (int q = 0; q < QT; ++q) thi[q] = (uint32_t)(tau[q] >> 32);
                 if (d < rows_b) {
                     const int64_t row = b * a.rows + d;
                     acc_t* pa = acc + (size_t)d * PITCH;
-#pragma unroll 1
-                    for (int q = 0; q < nq; ++q) {                        // (slots >= nq are never written: a ragged tile skips them;
-                        const acc_t sum = pa[q];                          //  not unrolled: hoisted candidate-buffer addresses spill into the walk)
-                        pa[q] = (acc_t)0;
-                        uint64_t key;
-                        if constexpr (AM == AM_F64) key = make_key((float)sum, (uint32_t)row);
-                        else key = make_key_fix(sum, (uint32_t)row);
-                        if (key > tau[q] && key < upper_sh[q]) {
-                            const uint32_t pos = atomicAdd(&ccnt[q], 1u);
-                            my_gcand[(size_t)q * kBpCap + pos] = key;
+                    acc_t sums[QT];
+#pragma unroll
+                    for (int q = 0; q < QT; ++q) sums[q] = pa[q];         // independent reads, in flight together
+#pragma unroll
+                    for (int q = 0; q < QT; ++q) pa[q] = (acc_t)0;
+#pragma unroll
+                    for (int q = 0; q < QT; ++q) {                        // (slots >= nq are never written: a ragged tile skips them)
+                        uint32_t hi;
+                        if constexpr (AM == AM_F64) hi = flip_f32((float)sums[q]);
+                        else hi = (uint32_t)sums[q] ^ 0x80000000u;
+                        if (q < nq && hi >= thi[q]) {
+                            const uint64_t key = ((uint64_t)hi << 32) | (uint32_t)(~(uint32_t)row);
+                            if (key > tau[q] && key < upper_sh[q]) {
+                                const uint32_t pos = atomicAdd(&ccnt[q], 1u);
+                                my_gcand[(size_t)q * kBpCap + pos] = key;
+                            }
                         }
                     }
                 }
@@ -690,7 +762,13 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
                     }
                 }
             }
+            lap(4);
+            tacc[5] += 1u;
             if (b + 1 >= b1) break;
+        }
+        if (a.timing && (tid & 63) == 0) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) atomicAdd(a.timing + i, (unsigned long long)tacc[i]);
         }
     }
 }

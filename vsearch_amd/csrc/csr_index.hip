@@ -472,7 +472,7 @@ extern "C" int vs_index_info(const vs_index* idx, vs_index_info_t* o) {
         VS_HIP(hipSetDevice(idx->device));
         VS_HIP(hipDeviceSynchronize());
         VS_HIP(hipMemcpy(hp, idx->last_plan_dev, sizeof(hp), hipMemcpyDeviceToHost));
-        o->last_scan_bytes = hp[4] * idx->last_plan_rs + hp[2] * idx->last_plan_blocks * 8;
+        o->last_scan_bytes = hp[4] * idx->last_plan_rs + hp[2] * idx->last_plan_blocks * 4;      // records + one directory word per (entry, block)
         o->last_walk_postings = hp[5];
     }
     if (idx->last_path == 3 && idx->last_flags && idx->last_flags_n > 0) {
@@ -805,10 +805,6 @@ int bp_build(vs_index* idx, hipStream_t s) {
     const size_t lds = ((size_t)V + 1) * 4;
     const int grid = (int)std::min<int64_t>(n_blocks, (int64_t)idx->cu_count * 8);
     ProfScope prof("bp_build", s);
-    VS_HIP(hipFuncSetAttribute((const void*)bp_count_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(bp_count_kernel<0>, dim3(grid), dim3(kScanThreads), lds, s, idx->pk_ptr.as<uint32_t>(), idx->cols.as<uint4>(), idx->n_rows, V, idx->bp_rows,
-                       idx->bp_dir.as<uint32_t>(), block_recs.as<uint32_t>(), df_rec, df_nnz, (const uint16_t*)nullptr);
-    VS_STAGE("bp_count", s);
     // max |value| (bounds the products of the fixed-point walk) and "any value negative"; a binary index has no values
     uint32_t hv[2] = {0x3F800000u, 0u};
     if (idx->store_dtype != VS_NONE) {
@@ -825,6 +821,18 @@ int bp_build(vs_index* idx, hipStream_t s) {
     float vmax_f;
     memcpy(&vmax_f, &hv[0], 4);
     const bool lossy_ok = hv[1] == 0u && vmax_f < 60000.f;       // fp16 copies of the values: non-negative, no overflow
+    // Lossy filter copy of an fp32 index: values rounded to fp16 (4 instead of 6 bytes per posting); needs the filter-and-refine
+    // search, non-negative values and no fp16 overflow
+    idx->bp_quant = idx->store_dtype == VS_F32 && idx->bp_filter != 0 && idx->bp_quant_pref != 0 && lossy_ok;
+    // lists start on whole 128-byte lines (option "postings_align" = 0: packed)
+    idx->bp_al_shift = idx->bp_align_pref != 0 ? bp_align_shift(bp_record_vm(idx)) : 0;
+    DevBuf ovf;
+    VS_TRY(ovf.alloc(4));
+    VS_HIP(hipMemsetAsync(ovf.p, 0, 4, s));
+    VS_HIP(hipFuncSetAttribute((const void*)bp_count_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(bp_count_kernel<0>, dim3(grid), dim3(kScanThreads), lds, s, idx->pk_ptr.as<uint32_t>(), idx->cols.as<uint4>(), idx->n_rows, V, idx->bp_rows,
+                       idx->bp_dir.as<uint32_t>(), block_recs.as<uint32_t>(), df_rec, df_nnz, (const uint16_t*)nullptr, idx->bp_al_shift, ovf.as<int32_t>());
+    VS_STAGE("bp_count", s);
     // Head columns (skewed vocabularies): present in >= 1/4 of the documents -> dense strips instead of posting lists.  Valued
     // indexes with the filter search only (the strips hold fp16 values: the fp64 walk cannot use them).
     idx->bp_vmax_f = vmax_f;
@@ -844,7 +852,8 @@ int bp_build(vs_index* idx, hipStream_t s) {
             // the directory again, without the head columns' lists
             VS_HIP(hipMemsetAsync(idx->bp_df.p, 0, (size_t)V * 16, s));
             hipLaunchKernelGGL(bp_count_kernel<0>, dim3(grid), dim3(kScanThreads), lds, s, idx->pk_ptr.as<uint32_t>(), idx->cols.as<uint4>(), idx->n_rows, V,
-                               idx->bp_rows, idx->bp_dir.as<uint32_t>(), block_recs.as<uint32_t>(), df_rec, df_nnz, (const uint16_t*)idx->bp_hmap.as<uint16_t>());
+                               idx->bp_rows, idx->bp_dir.as<uint32_t>(), block_recs.as<uint32_t>(), df_rec, df_nnz, (const uint16_t*)idx->bp_hmap.as<uint16_t>(),
+                               idx->bp_al_shift, ovf.as<int32_t>());
             VS_HIP(hipGetLastError());
             const size_t b_strip = (size_t)n_blocks * bp_head_pad(h_n) * idx->bp_rows * 2;
             VS_HIP(hipMemGetInfo(&free_b, &total_b));
@@ -858,12 +867,16 @@ int bp_build(vs_index* idx, hipStream_t s) {
     VS_HIP(hipGetLastError());
     VS_STAGE("bp_base", s);
     unsigned long long n_rec = 0;
+    int32_t h_ovf = 0;
     VS_HIP(hipMemcpyAsync(&n_rec, idx->bp_base.as<unsigned long long>() + n_blocks, 8, hipMemcpyDeviceToHost, s));
+    VS_HIP(hipMemcpyAsync(&h_ovf, ovf.p, 4, hipMemcpyDeviceToHost, s));
     VS_HIP(hipStreamSynchronize(s));
+    if (h_ovf) {                                                        // (2048 documents x 29 523 columns, all present, would do it)
+        fprintf(stderr, "[vsearch_hip] blocked-postings copy not built: a block holds more records than a directory word addresses -- sparse queries use the CSR scan\n");
+        bp_release(idx);
+        return VS_OK;
+    }
     VS_STAGE("bp_vmax", s);
-    // Lossy filter copy of an fp32 index: values rounded to fp16 (4 instead of 6 bytes per posting); needs the filter-and-refine
-    // search, non-negative values and no fp16 overflow
-    idx->bp_quant = idx->store_dtype == VS_F32 && idx->bp_filter != 0 && idx->bp_quant_pref != 0 && lossy_ok;
     const int RS = bp_rec_bytes(bp_record_vm(idx));
     const size_t b_rec = ((size_t)n_rec + 1) * RS;                       // + one record: a lane past the last list's end re-reads "the record at the end"
     VS_HIP(hipMemGetInfo(&free_b, &total_b));
@@ -871,13 +884,14 @@ int bp_build(vs_index* idx, hipStream_t s) {
     idx->bp_records = (int64_t)n_rec;
     VS_HIP(hipMemsetAsync(idx->bp_rec.p, 0, b_rec, s));                  // pad postings: document 0, value 0
     {
-        void (*fill)(const uint32_t*, const uint4*, const void*, int64_t, int32_t, int32_t, const uint32_t*, const unsigned long long*, char*, const uint16_t*, __half*, int32_t) =
+        void (*fill)(const uint32_t*, const uint4*, const void*, int64_t, int32_t, int32_t, const uint32_t*, const unsigned long long*, char*, const uint16_t*, __half*, int32_t, int32_t) =
             idx->store_dtype == VS_F32 ? (idx->bp_quant ? bp_fill_kernel<VM_F32, VM_F16> : bp_fill_kernel<VM_F32, VM_F32>)
             : idx->store_dtype == VS_F16 ? bp_fill_kernel<VM_F16, VM_F16> : bp_fill_kernel<VM_BIN, VM_BIN>;
         VS_HIP(hipFuncSetAttribute((const void*)fill, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(fill, dim3(grid), dim3(kScanThreads), lds, s, idx->pk_ptr.as<uint32_t>(), idx->cols.as<uint4>(), (const void*)idx->vals.p, idx->n_rows, V,
                            idx->bp_rows, idx->bp_dir.as<uint32_t>(), idx->bp_base.as<unsigned long long>(), idx->bp_rec.as<char>(),
-                           idx->bp_n_head > 0 ? (const uint16_t*)idx->bp_hmap.as<uint16_t>() : (const uint16_t*)nullptr, idx->bp_strip.as<__half>(), idx->bp_n_head);
+                           idx->bp_n_head > 0 ? (const uint16_t*)idx->bp_hmap.as<uint16_t>() : (const uint16_t*)nullptr, idx->bp_strip.as<__half>(), idx->bp_n_head,
+                           idx->bp_al_shift);
     }
     VS_HIP(hipGetLastError());
     VS_STAGE("bp_fill", s);
@@ -890,9 +904,9 @@ int bp_build(vs_index* idx, hipStream_t s) {
         bool mono = true;
         for (size_t i = 0; i + 1 < hb.size(); ++i) mono = mono && hb[i] <= hb[i + 1];
         bool dmono = true;
-        for (size_t i = 0; i + 1 < hd.size(); ++i) dmono = dmono && hd[i] <= hd[i + 1];
+        for (size_t i = 0; i + 2 < hd.size(); ++i) dmono = dmono && (hd[i] >> 12) <= (hd[i + 1] >> 12);
         fprintf(stderr, "[vsearch_hip] bp: rows %d blocks %lld records %llu base[1] %llu base[last] %llu monotone %d; last block dir end %u (block holds %llu) monotone %d\n",
-                idx->bp_rows, (long long)n_blocks, n_rec, hb.size() > 1 ? hb[1] : 0ull, hb[n_blocks], (int)mono, hd[V], hb[n_blocks] - hb[n_blocks - 1], (int)dmono);
+                idx->bp_rows, (long long)n_blocks, n_rec, hb.size() > 1 ? hb[1] : 0ull, hb[n_blocks], (int)mono, (hd[V - 1] >> 12) << idx->bp_al_shift, hb[n_blocks] - hb[n_blocks - 1], (int)dmono);
     }
     idx->bp_ready = true;
     return VS_OK;
@@ -1001,6 +1015,7 @@ int bp_filter_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64
     BpArgs a{};
     a.rows = idx->bp_rows;
     a.dir = idx->bp_dir.as<uint32_t>();
+    a.al_shift = idx->bp_al_shift;
     a.base = idx->bp_base.as<unsigned long long>();
     a.rec = idx->bp_rec.as<char>();
     a.n_rows = idx->n_rows;
@@ -1031,9 +1046,26 @@ int bp_filter_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64
     idx->last_plan_dev = dplan;
     idx->last_plan_rs = bp_rec_bytes(bp_record_vm(idx));
     idx->last_plan_blocks = n_blocks;
+    static const bool timing_on = getenv("VS_BP_TIMING") != nullptr;            // developer aid: where the walk's wave-cycles go
+    DevBuf timing;
+    if (timing_on) {
+        VS_TRY(timing.alloc(64));
+        VS_HIP(hipMemsetAsync(timing.p, 0, 64, s));
+        a.timing = timing.as<unsigned long long>();
+    }
     {
         ProfScope prof("csr_scan_topk", s);
         VS_TRY((launch_bp_walk<kQT, AM_FIX>(idx, a, grid, vals_cap, s)));
+    }
+    if (timing_on) {
+        unsigned long long h[8] = {0};
+        VS_HIP(hipMemcpyAsync(h, timing.p, 64, hipMemcpyDeviceToHost, s));
+        VS_HIP(hipStreamSynchronize(s));
+        const double tot = (double)(h[0] + h[1] + h[2] + h[3] + h[4]);
+        fprintf(stderr, "[vsearch_hip] walk wave-cycles: prologue %.1f %%, list walk %.1f %%, barrier wait %.1f %%, dense %.1f %%, epilogue %.1f %%; per block and wave: "
+                        "walk %.0f wait %.0f dense %.0f epilogue %.0f cycles\n", 100.0 * h[0] / tot, 100.0 * h[1] / tot, 100.0 * h[2] / tot, 100.0 * h[3] / tot, 100.0 * h[4] / tot,
+                (double)h[1] / (double)std::max<unsigned long long>(1, h[5]), (double)h[2] / (double)std::max<unsigned long long>(1, h[5]),
+                (double)h[3] / (double)std::max<unsigned long long>(1, h[5]), (double)h[4] / (double)std::max<unsigned long long>(1, h[5]));
     }
     VS_STAGE("filter walk", s);
     // 3. refine: exact scores of the K' candidates, the proof, the flags
@@ -1176,6 +1208,8 @@ int mq_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64_t id_o
         BpArgs a{};
         a.rows = idx->bp_rows;
         a.dir = idx->bp_dir.as<uint32_t>();
+        a.al_shift = idx->bp_al_shift;
+    a.al_shift = idx->bp_al_shift;
         a.base = idx->bp_base.as<unsigned long long>();
         a.rec = idx->bp_rec.as<char>();
         a.n_rows = idx->n_rows;
@@ -1193,7 +1227,7 @@ int mq_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64_t id_o
         a.gcand = idx->ws_mq_cand.as<uint64_t>();
         a.upper = col0 > 0 ? upper : nullptr;
         // what this launch has to read: the records of the batch's (query, column) entries + one directory pair per entry and block
-        idx->last_scan_bytes += hplan[4] * RS + qnnz * n_blocks * 8;
+        idx->last_scan_bytes += hplan[4] * RS + qnnz * n_blocks * 4;
         idx->last_walk_postings += hplan[5];
         idx->last_path = 2;
         ProfScope prof("csr_scan_topk", s);
