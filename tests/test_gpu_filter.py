@@ -262,3 +262,30 @@ def test_head_strips_across_value_ranges(scale, heads):
     assert info.last_path == 3 and (info.head_columns > 0) == heads
     assert info.last_fallbacks == 0
     assert (ids == ref_ids).all() and (sc == ref_sc).all()
+
+
+@pytest.mark.parametrize("store", [nat.VS_F32, nat.VS_F16, nat.VS_NONE], ids=["fp32", "fp16", "binary"])
+def test_record_layout_options_keep_the_results(store):
+    """postings_align (lists start on whole 128-byte lines), postings_lanes and postings_rows only move postings around: every
+    combination returns the CSR scan's ids and scores bit for bit.  Rows 700 .. 720 get a column in common so that its list in
+    one block is longer than one round of 8 lanes x 8 postings (the second record a lane takes in the same load round)."""
+    n = 9000
+    if store == nat.VS_NONE:
+        idx = DeviceIndex.synthetic(0, 0, 70000, V, 86, synth.KIND_BOT, 0, store)
+        q = oracle.synth_queries(1, 11, V, 776, synth.VAL_DYADIC)
+    else:
+        ip, ix, d = oracle.synth_csr(0, 0, n)
+        ix = ix.copy()
+        for r in range(600, 900):                                    # 300 documents of one block share column 77
+            if 77 not in ix[ip[r]:ip[r + 1]]:
+                ix[ip[r]] = 77
+                ix[ip[r]:ip[r + 1]].sort()
+        idx = DeviceIndex.from_csr(ip, ix, d, V, store_dtype=store)
+        q = oracle.synth_queries(1, 11)
+        q[:, 77] = np.float32(1.5)
+    ref_ids, ref_sc, info = _search(idx, q, 100, blocked_postings=0)
+    assert info.last_path == 1
+    for align, lanes, rows in [(0, 0, 0), (1, 0, 0), (1, 4, 0), (0, 4, 0), (1, 8, 1024), (0, 8, 256)]:
+        ids, sc, info = _search(idx, q, 100, blocked_postings=1, postings_align=align, postings_lanes=lanes, postings_rows=rows)
+        assert info.last_path == 3, (align, lanes, rows)
+        assert (ids == ref_ids).all() and (sc == ref_sc).all(), f"align={align} lanes={lanes} rows={rows}: differs from the CSR scan"

@@ -97,7 +97,7 @@ extern "C" int vs_index_set_option(vs_index* idx, const char* name, int value) {
         return VS_OK;
     }
     if (n == "postings_align") {
-        if (value < -1 || value > 1) return fail(VS_EINVAL, "postings_align: -1 = auto (lists start on 128-byte lines), 0 = packed");
+        if (value < -1 || value > 1) return fail(VS_EINVAL, "postings_align: -1 = auto (packed), 0 = packed, 1 = lists start on 128-byte lines");
         if (value != idx->bp_align_pref) { idx->bp_dir.release(); idx->bp_base.release(); idx->bp_rec.release(); idx->bp_ready = false; idx->bp_tried = false; }
         idx->bp_align_pref = value;
         return VS_OK;

@@ -218,7 +218,7 @@ struct vs_index {
     int bp_lanes = 0;    // option "postings_lanes": lanes per posting list of a valued index (4 | 8, auto = 8); binary index: records in flight per lane (auto = 4)
     bool bp_force_fb = false;   // option "postings_force_fallback" (tests)
     int bp_al_shift = 0;     // lists of the copy start on a multiple of 2^bp_al_shift records (bp_walk.h)
-    int bp_align_pref = -1;  // option "postings_align": -1 auto (whole 128-byte lines), 0 = packed lists
+    int bp_align_pref = -1;  // option "postings_align": -1 auto (= 0), 0 = packed lists, 1 = lists start on whole 128-byte lines
     bool bp_quant = false;   // the records of this fp32 index hold fp16-rounded values (lossy filter copy, bp_refine.h)
     int bp_quant_pref = -1;  // option "postings_quant": -1 auto (on when the data allow it), 0 = keep fp32 values in the records
     int bp_filter = 1;   // option "postings_filter": 1 = int32 fixed-point walk + exact refine (default), 0 = fp64 walk only
