@@ -47,6 +47,7 @@ constexpr int kBpCap = 2048;          // candidate slots per (workgroup, query s
 constexpr int kBpMaxK = kBpCap - kScanThreads;
 constexpr int kBpEntCap = 7168;       // (query, column) entries per tile: 56 KB of LDS, and the 8192-slot entry sort must hold them
 constexpr int kBpNB = 4;              // posting lists whose loads are in flight together per lane group
+constexpr int kBpNBWide = 6;          // ... for 32-byte records on 8-lane groups (the filter walk of a valued index): 6 x 8 + 8 registers of records
 constexpr size_t kBpSortBytes = (size_t)8192 * 8;   // the entry sort of a tile (8192 slots) borrows the accumulator area
 
 __host__ __device__ constexpr int bp_rec_bytes(int vm) { return vm == VM_F32 ? 48 : (vm == VM_F16 ? 32 : 16); }
@@ -350,14 +351,30 @@ __device__ __forceinline__ void load_rec16(u32x4& a, uint32_t off, unsigned long
 // (one overload per register count: naming the same variable twice in one asm makes the compiler copy it BEFORE the wait)
 #define VS_WAIT_CASES(OPS)                                                                                              \
     switch (n) {                                                                                                        \
-        case 1: asm volatile("s_waitcnt vmcnt(1)" : OPS); break;                                                        \
-        case 2: asm volatile("s_waitcnt vmcnt(2)" : OPS); break;                                                        \
-        case 3: asm volatile("s_waitcnt vmcnt(3)" : OPS); break;                                                        \
-        case 4: asm volatile("s_waitcnt vmcnt(4)" : OPS); break;                                                        \
-        case 5: asm volatile("s_waitcnt vmcnt(5)" : OPS); break;                                                        \
-        case 7: asm volatile("s_waitcnt vmcnt(7)" : OPS); break;                                                        \
-        case 6: asm volatile("s_waitcnt vmcnt(6)" : OPS); break;                                                        \
-        case 9: asm volatile("s_waitcnt vmcnt(9)" : OPS); break;                                                        \
+        case 1: asm volatile("s_waitcnt vmcnt(1)" : OPS); break;                                                      \
+        case 2: asm volatile("s_waitcnt vmcnt(2)" : OPS); break;                                                      \
+        case 3: asm volatile("s_waitcnt vmcnt(3)" : OPS); break;                                                      \
+        case 4: asm volatile("s_waitcnt vmcnt(4)" : OPS); break;                                                      \
+        case 5: asm volatile("s_waitcnt vmcnt(5)" : OPS); break;                                                      \
+        case 6: asm volatile("s_waitcnt vmcnt(6)" : OPS); break;                                                      \
+        case 7: asm volatile("s_waitcnt vmcnt(7)" : OPS); break;                                                      \
+        case 8: asm volatile("s_waitcnt vmcnt(8)" : OPS); break;                                                      \
+        case 9: asm volatile("s_waitcnt vmcnt(9)" : OPS); break;                                                      \
+        case 10: asm volatile("s_waitcnt vmcnt(10)" : OPS); break;                                                    \
+        case 11: asm volatile("s_waitcnt vmcnt(11)" : OPS); break;                                                    \
+        case 12: asm volatile("s_waitcnt vmcnt(12)" : OPS); break;                                                    \
+        case 13: asm volatile("s_waitcnt vmcnt(13)" : OPS); break;                                                    \
+        case 14: asm volatile("s_waitcnt vmcnt(14)" : OPS); break;                                                    \
+        case 15: asm volatile("s_waitcnt vmcnt(15)" : OPS); break;                                                    \
+        case 16: asm volatile("s_waitcnt vmcnt(16)" : OPS); break;                                                    \
+        case 17: asm volatile("s_waitcnt vmcnt(17)" : OPS); break;                                                    \
+        case 18: asm volatile("s_waitcnt vmcnt(18)" : OPS); break;                                                    \
+        case 19: asm volatile("s_waitcnt vmcnt(19)" : OPS); break;                                                    \
+        case 20: asm volatile("s_waitcnt vmcnt(20)" : OPS); break;                                                    \
+        case 21: asm volatile("s_waitcnt vmcnt(21)" : OPS); break;                                                    \
+        case 22: asm volatile("s_waitcnt vmcnt(22)" : OPS); break;                                                    \
+        case 23: asm volatile("s_waitcnt vmcnt(23)" : OPS); break;                                                    \
+        case 24: asm volatile("s_waitcnt vmcnt(24)" : OPS); break;                                                    \
         default: asm volatile("s_waitcnt vmcnt(0)" : OPS); break;                                                       \
     }
 #define VS_OPS3 "+v"(a), "+v"(b), "+v"(c)
@@ -391,13 +408,14 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
     static_assert(!HD || (AM == AM_FIX && VM != VM_BIN), "dense strips: valued filter walk only");
     static_assert(bp_acc_bytes<QT, AM, RMAX>() >= kBpSortBytes, "the accumulator area holds the 8192-slot entry sort");
     static_assert(VM != VM_BIN || RMAX == kBpRowsMaxBin, "pad postings of a binary list carry document id kBpRowsMaxBin");
-    static_assert(NB % LG == 0 || LG % NB == 0, "lane l of a group owns the directory pairs of lists l, l + LG, ... of a slot");
+    static_assert(NB % LG == 0 || LG % NB == 0 || (LG == 8 && NB <= 8), "lane l of a group owns the directory words of lists l, l + LG, ... of a slot");
     using acc_t = typename std::conditional<AM == AM_F64, double, int32_t>::type;
     constexpr int PITCH = QT + 1;                 // accumulator row pitch in elements: a document's row starts an odd number of words
                                                   // after its neighbour's, so the adds of a wave spread over all LDS banks
     constexpr uint32_t PITCHB = PITCH * sizeof(acc_t);
     constexpr int RS = bp_rec_bytes(VM);
-    constexpr int OWN = NB >= LG ? NB / LG : 1;   // directory pairs a lane owns per slot (lanes >= NB of a wide group own none)
+    constexpr int OWN = NB >= LG ? NB / LG : 1;   // directory words a lane owns per slot (lanes >= NB of a wide group own none)
+    constexpr bool kWide = LG == 8 && NB > 4;     // 8-lane groups, 5 .. 8 lists per slot: lane l owns list l's word (else: every quad holds all NB)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     acc_t* acc = reinterpret_cast<acc_t*>(smem);                                            // [RMAX + 1][PITCH]
     uint64_t* sortbuf = reinterpret_cast<uint64_t*>(smem + bp_acc_bytes<QT, AM, RMAX>());   // [kBpCap]
@@ -506,9 +524,10 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
             const uint32_t* dirn = a.dir + (size_t)bb * dir_ld;
 #pragma unroll
             for (int o = 0; o < OWN; ++o) {
-                const int e = wv_id * CW + ((LG >= NB ? (gl & (NB - 1)) : gl) + LG * o) * GPW + gw;   // LG >= NB: every quad of the group holds all NB words
+                const int lu = kWide ? gl : ((LG >= NB ? (gl & (NB - 1)) : gl) + LG * o);       // LG >= NB, not wide: every quad of the group holds all NB words
+                const int e = wv_id * CW + lu * GPW + gw;
                 nd[o] = 0;
-                if (e < n_ent) nd[o] = dirn[ent[e].x & 0xFFFFu];
+                if (lu < NB && e < n_ent) nd[o] = dirn[ent[e].x & 0xFFFFu];
             }
         };
         // (short binary lists: one or two slots per block, the directory latency would be exposed once per block; with the long
@@ -540,8 +559,9 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
                     for (int o = 0; o < OWN; ++o) {
                         cd[o] = nd[o];
                         nd[o] = 0;
-                        const int e = nxt * CW + ((LG >= NB ? (gl & (NB - 1)) : gl) + LG * o) * GPW + gw;
-                        if (e < n_ent) nd[o] = dirb[ent[e].x & 0xFFFFu];
+                        const int lu = kWide ? gl : ((LG >= NB ? (gl & (NB - 1)) : gl) + LG * o);
+                        const int e = nxt * CW + lu * GPW + gw;
+                        if (lu < NB && e < n_ent) nd[o] = dirb[ent[e].x & 0xFFFFu];
                     }
                     const int cbase = cur * CW;
                     cur = nxt;
@@ -553,8 +573,18 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
                     if constexpr (LG == 1) {
 #pragma unroll
                         for (int u = 0; u < NB; ++u) bd[u] = cd[u];
+                    } else if constexpr (kWide) {
+                        // lane l of the 8-lane group holds list l's word: the other quad's four come over with a row shift, then quad broadcasts
+                        const uint32_t up = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cd[0], 0x104, 0xF, 0xF, false);      // row_shl:4: lane i <- lane i + 4
+                        const uint32_t dn = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cd[0], 0x114, 0xF, 0xF, false);      // row_shr:4: lane i <- lane i - 4
+                        const bool upper = (gl & 4) != 0;
+                        const uint32_t oth = upper ? dn : up;
+                        const uint32_t own4[4] = {quad_bcast<0>(cd[0]), quad_bcast<1>(cd[0]), quad_bcast<2>(cd[0]), quad_bcast<3>(cd[0])};
+                        const uint32_t oth4[4] = {quad_bcast<0>(oth), quad_bcast<1>(oth), quad_bcast<2>(oth), quad_bcast<3>(oth)};
+#pragma unroll
+                        for (int u = 0; u < NB; ++u) bd[u] = (u < 4) == upper ? oth4[u & 3] : own4[u & 3];
                     } else {
-                        static_assert(NB == 4 && OWN == 1, "quad broadcast of four words");      // (NB = 8 is the one-lane-per-list case)
+                        static_assert(NB == 4 && OWN == 1, "quad broadcast of four words");
                         bd[0] = quad_bcast<0>(cd[0]); bd[1] = quad_bcast<1>(cd[0]); bd[2] = quad_bcast<2>(cd[0]); bd[3] = quad_bcast<3>(cd[0]);
                     }
 #pragma unroll
