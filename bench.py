@@ -226,7 +226,7 @@ def main():
         hbm_frac = (traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS) if traffic else None
         adds_per_s = info.last_walk_postings / launches_per_step / avg_launch_s if info.last_path >= 2 else None
         if info.last_path >= 2:
-            bound = "hbm" if (hbm_frac or 0.0) > 0.5 else "on-chip: L2->L1 line fill per CU (outstanding-line limit) + LDS scatter-adds"
+            bound = "hbm" if (hbm_frac or 0.0) > 0.5 else "on-chip: LDS scatter-adds into random document slots (bank conflicts; ds_add_u32) + the L2->L1 record loads they overlap with"
         else:
             bound = "hbm"
         # `achieved` / `frac`: the HBM rate the counters evidence when a matching PMC profile exists (the honest HBM fraction);
