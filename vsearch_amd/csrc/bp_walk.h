@@ -520,21 +520,21 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
         };
         // directory pairs of a block's first slot: fetched while the previous block is finished (they stay in flight across its epilogue)
         uint32_t nd[OWN];
-        auto first_pairs = [&](int64_t bb) {
+        auto first_pairs = [&](int64_t bb, int li0) {
             const uint32_t* dirn = a.dir + (size_t)bb * dir_ld;
 #pragma unroll
             for (int o = 0; o < OWN; ++o) {
                 const int lu = kWide ? gl : ((LG >= NB ? (gl & (NB - 1)) : gl) + LG * o);       // LG >= NB, not wide: every quad of the group holds all NB words
-                const int e = wv_id * CW + lu * GPW + gw;
+                const int e = li0 * CW + lu * GPW + gw;
                 nd[o] = 0;
-                if (lu < NB && e < n_ent) nd[o] = dirn[ent[e].x & 0xFFFFu];
+                if (li0 >= 0 && lu < NB && e < n_ent) nd[o] = dirn[ent[e].x & 0xFFFFu];
             }
         };
         // (short binary lists: one or two slots per block, the directory latency would be exposed once per block; with the long
         //  lists of a valued index the pairs are fetched at block start -- holding them across the epilogue costs more than it hides)
         constexpr bool kPairsAhead = LG == 1;
         lap(0);
-        if (kPairsAhead && b0 < b1) first_pairs(b0);
+        if (kPairsAhead && b0 < b1) first_pairs(b0, wv_id);          // (binary index: no dense chunks, chunk = list chunk)
         for (int64_t b = b0; b < b1 || b == b0; ++b) {
             const bool have = b < b1;
             const int rows_b = have ? (int)min((int64_t)a.rows, a.n_rows - b * a.rows) : 0;
@@ -550,20 +550,90 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
                 // list per round; the NB lists of a slot are loaded before any multiply-add.  Loads are unconditional (a lane past
                 // its list's end re-reads the record at the end: always inside the array) so that no loaded register is merged with
                 // an older value; only the adds are predicated.
-                if (!kPairsAhead) first_pairs(b);
+                // Chunks of a block = list chunks (CW entries each) and, with head columns, dense chunks (64 documents x all head
+                // columns on the matrix cores) INTERLEAVED in one queue: both add into the same accumulators, no barrier between
+                // them, and a wave streaming a strip from L2 runs next to waves whose time goes into LDS adds.
+                const int n_lc = (n_ent + CW - 1) / CW;
+                constexpr int kDenseDocs = 64;                      // documents of a dense chunk (4 operand rows; 32: re-reads the weights twice as often and streams worse -- 489 vs 370 ms at 21 M docs)
+                const int n_dc = (HD && n_head > 0) ? (rows_b + kDenseDocs - 1) / kDenseDocs : 0;
+                const int n_ch = n_lc + n_dc;
+                // chunk c is dense iff floor((c + 1) n_dc / n_ch) > floor(c n_dc / n_ch); floor(c n_dc / n_ch) dense chunks precede it
+                auto dense_before = [&](int c) { return (int)(((uint32_t)c * (uint32_t)n_dc) / (uint32_t)max(n_ch, 1)); };
+                auto list_index = [&](int c) { return (c < n_ch && dense_before(c + 1) == dense_before(c)) ? c - dense_before(c) : -1; };
+                [[maybe_unused]] auto dense_chunk = [&](int dj) {
+                    if constexpr (HD != 0) {
+                        static_assert(QT == 8 && RMAX == 16 * 128, "dense part: 8 slots x (hi, lo) = the 16 columns of the MFMA");
+                        // [64 documents] x [head columns] (fp16 strip, MFMA A-operand order) times [head columns] x [8 slots x (hi, lo)]
+                        // (the tile's weights) -- v_mfma_f32_16x16x32_f16, fp32 accumulate; the strip streams from L2 / Infinity
+                        // Cache with the next two k-steps (8 KB a wave) in flight.  Each sum is scaled back (power of two), truncated
+                        // once and added to the accumulators (hi and lo parts separately).
+                        using h8 = __attribute__((ext_vector_type(8))) _Float16;
+                        using f4 = __attribute__((ext_vector_type(4))) float;
+                        const int ln = tid & 63;
+                        const int ks = bp_head_pad(n_head) / 32, mbk = a.rows / 16;
+                        const _Float16* bp = hw + (ln & 15) * ldb + 8 * (ln >> 4);
+                        const int slot = ln & 7;
+                        constexpr int MR = kDenseDocs / 16;                 // operand rows of the chunk
+                        const int d0 = dj * kDenseDocs;
+                        const uint4* sp = reinterpret_cast<const uint4*>(a.strip) + ((size_t)b * ks * mbk + (size_t)(d0 >> 4)) * 64 + ln;
+                        f4 c[MR];
+#pragma unroll
+                        for (int m = 0; m < MR; ++m) c[m] = f4{0.f, 0.f, 0.f, 0.f};
+                        uint4 s0[MR], s1[MR], s2[MR];                       // k-steps j, j + 1, j + 2
+#pragma unroll
+                        for (int m = 0; m < MR; ++m) { s0[m] = sp[(size_t)m * 64]; s1[m] = s0[m]; s2[m] = s0[m]; }
+                        if (ks > 1) {
+#pragma unroll
+                            for (int m = 0; m < MR; ++m) s1[m] = sp[((size_t)mbk + m) * 64];
+                        }
+#pragma unroll 1
+                        for (int j = 0; j < ks; ++j) {
+                            if (j + 2 < ks) {
+#pragma unroll
+                                for (int m = 0; m < MR; ++m) s2[m] = sp[((size_t)(j + 2) * mbk + m) * 64];
+                            }
+                            const h8 bf = *reinterpret_cast<const h8*>(bp + 32 * j);
+#pragma unroll
+                            for (int m = 0; m < MR; ++m) {
+                                h8 af;
+                                __builtin_memcpy(&af, &s0[m], 16);
+                                c[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, c[m], 0, 0, 0);
+                            }
+#pragma unroll
+                            for (int m = 0; m < MR; ++m) { s0[m] = s1[m]; s1[m] = s2[m]; }
+                        }
+                        // C: lane holds rows 4 * (ln >> 4) + i, column ln & 15 = slot + 8 * (hi | lo)
+#pragma unroll
+                        for (int m = 0; m < MR; ++m) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const int d = d0 + m * 16 + 4 * (ln >> 4) + i;
+                                atomicAdd(&acc[d * PITCH + slot], (int32_t)(c[m][i] * a.head_mul));
+                            }
+                        }
+                    }
+                };
                 const int par = (int)(b & 1);
                 int cur = wv_id, nxt = grab(par);
-                while (cur * CW < n_ent) {
+                if (!kPairsAhead) first_pairs(b, list_index(cur));
+                while (cur < n_ch) {
+                    const int li = list_index(cur), li_n = list_index(nxt);
                     uint32_t cd[OWN];
 #pragma unroll
                     for (int o = 0; o < OWN; ++o) {
                         cd[o] = nd[o];
                         nd[o] = 0;
                         const int lu = kWide ? gl : ((LG >= NB ? (gl & (NB - 1)) : gl) + LG * o);
-                        const int e = nxt * CW + lu * GPW + gw;
-                        if (lu < NB && e < n_ent) nd[o] = dirb[ent[e].x & 0xFFFFu];
+                        const int e = li_n * CW + lu * GPW + gw;
+                        if (li_n >= 0 && lu < NB && e < n_ent) nd[o] = dirb[ent[e].x & 0xFFFFu];
                     }
-                    const int cbase = cur * CW;
+                    if (li < 0) {                                   // a dense chunk (the words fetched above wait in nd for the next list chunk)
+                        dense_chunk(dense_before(cur));
+                        cur = nxt;
+                        nxt = grab(par);
+                        continue;
+                    }
+                    const int cbase = li * CW;
                     cur = nxt;
                     nxt = grab(par);
                     uint32_t rec[NB], end[NB];
@@ -678,70 +748,12 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
                         }
                     }
                 }
-                if (kPairsAhead && b + 1 < b1) first_pairs(b + 1);
+                if (kPairsAhead && b + 1 < b1) first_pairs(b + 1, wv_id);
             }
             lap(1);
             __syncthreads();
             if (tid == 0) scratch[40 + (int)((b + 1) & 1)] = 0;     // the next block's chunk counter (its last user was block b - 1)
             lap(2);
-            if constexpr (HD != 0) {
-                static_assert(QT == 8 && RMAX == 16 * 128, "dense part: 8 slots x (hi, lo) = the 16 columns of the MFMA; a wave takes 128 documents");
-                if (n_head > 0 && have) {
-                    // Dense part: [documents of the block] x [head columns] (fp16 strip) times [head columns] x [8 slots x (hi, lo)]
-                    // (the tile's weights) on the matrix cores -- v_mfma_f32_16x16x32_f16, fp32 accumulate.  Wave w takes documents
-                    // 128 w .. + 127 (8 operand rows of 16), all columns; the strip streams from L2 / Infinity Cache with the next
-                    // k-step's 8 KB in flight while this one multiplies.  Each sum is scaled back (power of two), truncated once and
-                    // added to the accumulators (hi and lo parts separately).
-                    using h8 = __attribute__((ext_vector_type(8))) _Float16;
-                    using f4 = __attribute__((ext_vector_type(4))) float;
-                    const int wv = tid >> 6, ln = tid & 63;
-                    const int ks = bp_head_pad(n_head) / 32, mbk = a.rows / 16;
-                    const _Float16* bp = hw + (ln & 15) * ldb + 8 * (ln >> 4);
-                    const int slot = ln & 7;
-#pragma unroll 1
-                    for (int p = 0; p < 2; ++p) {                           // 64 documents = 4 operand rows at a time
-                        const int d0 = wv * 128 + p * 64;
-                        if (d0 >= rows_b) break;
-                        const uint4* sp = reinterpret_cast<const uint4*>(a.strip) + ((size_t)b * ks * mbk + (size_t)(d0 >> 4)) * 64 + ln;
-                        f4 c[4];
-#pragma unroll
-                        for (int m = 0; m < 4; ++m) c[m] = f4{0.f, 0.f, 0.f, 0.f};
-                        uint4 s0[4], s1[4], s2[4];                           // k-steps j, j + 1, j + 2: two steps (8 KB a wave) in flight
-#pragma unroll
-                        for (int m = 0; m < 4; ++m) { s0[m] = sp[(size_t)m * 64]; s1[m] = s0[m]; s2[m] = s0[m]; }
-                        if (ks > 1) {
-#pragma unroll
-                            for (int m = 0; m < 4; ++m) s1[m] = sp[((size_t)mbk + m) * 64];
-                        }
-#pragma unroll 1
-                        for (int j = 0; j < ks; ++j) {
-                            if (j + 2 < ks) {
-#pragma unroll
-                                for (int m = 0; m < 4; ++m) s2[m] = sp[((size_t)(j + 2) * mbk + m) * 64];
-                            }
-                            const h8 bf = *reinterpret_cast<const h8*>(bp + 32 * j);
-#pragma unroll
-                            for (int m = 0; m < 4; ++m) {
-                                h8 af;
-                                __builtin_memcpy(&af, &s0[m], 16);
-                                c[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, c[m], 0, 0, 0);
-                            }
-#pragma unroll
-                            for (int m = 0; m < 4; ++m) { s0[m] = s1[m]; s1[m] = s2[m]; }
-                        }
-                        // C: lane holds rows 4 * (ln >> 4) + i, column ln & 15 = slot + 8 * (hi | lo)
-#pragma unroll
-                        for (int m = 0; m < 4; ++m) {
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                const int d = d0 + m * 16 + 4 * (ln >> 4) + i;
-                                atomicAdd(&acc[d * PITCH + slot], (int32_t)(c[m][i] * a.head_mul));
-                            }
-                        }
-                    }
-                    __syncthreads();
-                }
-            }
             lap(3);
             // epilogue: 1024 documents at a time, one per thread: its QT sums -> order keys -> candidates; prune when a buffer could overflow
             for (int d0 = 0; d0 < rows_b || d0 == 0; d0 += kScanThreads) {

@@ -758,7 +758,7 @@ int launch_bp_walk(const vs_index* idx, const BpArgs& a, int grid, int ent_cap, 
     } else if (AM == AM_FIX && a.n_head > 0) {
         if constexpr (AM == AM_FIX) {
             if (vm == VM_F32) kern = idx->bp_lanes != 4 ? bp_walk_topk<VM_F32, QT, AM_FIX, 8, kBpRowsMax, kBpNB, 1> : bp_walk_topk<VM_F32, QT, AM_FIX, 4, kBpRowsMax, kBpNB, 1>;
-            else kern = idx->bp_lanes != 4 ? bp_walk_topk<VM_F16, QT, AM_FIX, 8, kBpRowsMax, kBpNBWide, 1> : bp_walk_topk<VM_F16, QT, AM_FIX, 4, kBpRowsMax, kBpNB, 1>;
+            else kern = idx->bp_lanes != 4 ? bp_walk_topk<VM_F16, QT, AM_FIX, 8, kBpRowsMax, kBpNB, 1> : bp_walk_topk<VM_F16, QT, AM_FIX, 4, kBpRowsMax, kBpNB, 1>;
         }
     } else if (vm == VM_F32) {
         kern = idx->bp_lanes != 4 ? bp_walk_topk<VM_F32, QT, AM, 8, kBpRowsMax> : bp_walk_topk<VM_F32, QT, AM, 4, kBpRowsMax>;
