@@ -176,7 +176,7 @@ VS_API int  vs_index_set_queries_per_pass(vs_index* index, int qt);
  *                       0 = fp64 walk only
  *   "postings_quant"    1 (default) = an fp32 index keeps fp16-rounded values in the postings copy (the filter only ranks
  *                       candidates; the refine step re-scores them from the fp32 CSR), 0 = fp32 values there too
- *   "postings_lanes"    0 = auto; valued index: lanes per posting list (4 | 8, auto 8); binary index: records in flight per lane (4 | 8, auto 4)
+ *   "postings_lanes"    0 = auto; valued index: lanes per posting list (4 | 8, auto 8); binary index: records in flight per lane (4 | 8, auto 8)
  *   "postings_align"    1 = posting lists start on whole 128-byte lines (16 % more bytes, ~2 % less walk time); 0 / -1 = packed
  *   "postings_head"     -1 = auto (4), 0 = off, N in 2..64: columns present in >= 1/N of the documents (at most 512, the most
  *                       frequent first) leave the posting lists and are kept as dense fp16 strips [block][column][document];

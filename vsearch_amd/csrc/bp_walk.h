@@ -559,7 +559,10 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
                 const int n_ch = n_lc + n_dc;
                 // chunk c is dense iff floor((c + 1) n_dc / n_ch) > floor(c n_dc / n_ch); floor(c n_dc / n_ch) dense chunks precede it
                 auto dense_before = [&](int c) { return (int)(((uint32_t)c * (uint32_t)n_dc) / (uint32_t)max(n_ch, 1)); };
-                auto list_index = [&](int c) { return (c < n_ch && dense_before(c + 1) == dense_before(c)) ? c - dense_before(c) : -1; };
+                auto list_index = [&](int c) {
+                    if constexpr (HD == 0) return c < n_ch ? c : -1;              // (no dense chunks: no division in the headless kernels)
+                    else return (c < n_ch && dense_before(c + 1) == dense_before(c)) ? c - dense_before(c) : -1;
+                };
                 [[maybe_unused]] auto dense_chunk = [&](int dj) {
                     if constexpr (HD != 0) {
                         static_assert(QT == 8 && RMAX == 16 * 128, "dense part: 8 slots x (hi, lo) = the 16 columns of the MFMA");
@@ -786,6 +789,14 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
                 }
                 __syncthreads();
                 const bool last = b + 1 >= b1 && d0 + kScanThreads >= rows_b;
+                // (the QT counters in one round of reads, then register compares: 8 dependent read-and-branch steps cost 1.7 k cycles here)
+                uint32_t cnts[QT];
+#pragma unroll
+                for (int q = 0; q < QT; ++q) cnts[q] = ccnt[q];
+                bool any = last;
+#pragma unroll
+                for (int q = 0; q < QT; ++q) any = any || cnts[q] > (uint32_t)(kBpCap - kScanThreads);
+                if (any)
                 for (int qs = 0; qs < nq; ++qs) {
                     const uint32_t cnt = ccnt[qs];
                     if (last || cnt > (uint32_t)(kBpCap - kScanThreads)) {

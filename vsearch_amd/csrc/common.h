@@ -215,7 +215,7 @@ struct vs_index {
     float bp_vmax_f = 1.f;   // max |value| of the index (bp_build)
     int bp_head_pref = -1;   // option "postings_head": -1 auto (columns present in >= 1/4 of the documents, at most 512), 0 = none, N = share 1/N
     vs::DevBuf bp_vmax;  // [2] uint32: float bits of max |value| (bounds the fixed-point walk's products), any-value-negative flag
-    int bp_lanes = 0;    // option "postings_lanes": lanes per posting list of a valued index (4 | 8, auto = 8); binary index: records in flight per lane (auto = 4)
+    int bp_lanes = 0;    // option "postings_lanes": lanes per posting list of a valued index (4 | 8, auto = 8); binary index: records in flight per lane (auto = 8)
     bool bp_force_fb = false;   // option "postings_force_fallback" (tests)
     int bp_al_shift = 0;     // lists of the copy start on a multiple of 2^bp_al_shift records (bp_walk.h)
     int bp_align_pref = -1;  // option "postings_align": -1 auto (= 0), 0 = packed lists, 1 = lists start on whole 128-byte lines

@@ -752,8 +752,9 @@ int launch_bp_walk(const vs_index* idx, const BpArgs& a, int grid, int ent_cap, 
     void (*kern)(BpArgs) = nullptr;
     if (vm == VM_BIN) {
         if (AM != AM_FIX) return fail(VS_EUNSUPPORTED, "binary postings serve the filter walk only");
-        // one lane per list; the option picks the records in flight per lane (4: 15.5 k q/s on the Wiki21M shape, 8: 14.7 k)
-        kern = idx->bp_lanes == 8 ? bp_walk_topk<VM_BIN, kBpBinQT, AM_FIX, 1, kBpRowsMaxBin, 8> : bp_walk_topk<VM_BIN, kBpBinQT, AM_FIX, 1, kBpRowsMaxBin, 4>;
+        // one lane per list; the option picks the records in flight per lane = the size of the chunks dealt to the waves (8: 512
+        // entries, 13 chunks a block on the Wiki21M shape, 16.4 k q/s; 4: 25 chunks for 16 waves, 13.0 k)
+        kern = idx->bp_lanes == 4 ? bp_walk_topk<VM_BIN, kBpBinQT, AM_FIX, 1, kBpRowsMaxBin, 4> : bp_walk_topk<VM_BIN, kBpBinQT, AM_FIX, 1, kBpRowsMaxBin, 8>;
         lds = bp_lds_bytes<kBpBinQT, AM_FIX, kBpRowsMaxBin>(ent_cap);
     } else if (AM == AM_FIX && a.n_head > 0) {
         if constexpr (AM == AM_FIX) {
