@@ -289,3 +289,31 @@ def test_record_layout_options_keep_the_results(store):
         ids, sc, info = _search(idx, q, 100, blocked_postings=1, postings_align=align, postings_lanes=lanes, postings_rows=rows)
         assert info.last_path == 3, (align, lanes, rows)
         assert (ids == ref_ids).all() and (sc == ref_sc).all(), f"align={align} lanes={lanes} rows={rows}: differs from the CSR scan"
+
+
+def test_baseline_sized_bag_of_token_index():
+    """C5 at full size: 21 015 324 docs, ~86 binary non-zeros each, dyadic query weights -- the postings walk returns the oracle's
+    integer-exact scores: bit-equal to the CSR scan, canonical ids, a valid top-k of the score matrix."""
+    n = 21_015_324
+    idx = DeviceIndex.synthetic(0, 0, n, V, 86, synth.KIND_BOT, 0, nat.VS_NONE)
+    q = oracle.synth_queries(1, 8, V, 776, synth.VAL_DYADIC)
+    ids, sc, info = _search(idx, q, 100, blocked_postings=-1)
+    assert info.last_path == 3 and info.last_fallbacks == 0
+    ref_ids, ref_sc, info = _search(idx, q, 100, blocked_postings=0)
+    assert info.last_path == 1
+    assert (ids == ref_ids).all() and (sc == ref_sc).all()
+    allsc = idx.scores(q[:4])
+    compare.check_topk_valid(allsc, ids[:4], sc[:4], rtol=RTOL, exact=True, canonical=True)
+
+
+def test_baseline_sized_skewed_index_with_head_strips():
+    """C3's secondary column law at C4's size: 21 015 324 docs x 768 nnz with Zipf column popularity; 511 head columns become dense
+    strips scored on the matrix cores.  Bit-equal to the CSR scan on a batch slice, no query falls back."""
+    n = 21_015_324
+    idx = DeviceIndex.synthetic(0, 0, n, V, 768, synth.KIND_SKEW, 0, nat.VS_F32)
+    q = oracle.synth_queries(1, 64, kind=synth.KIND_SKEW)
+    ids, sc, info = _search(idx, q, 100, blocked_postings=-1)
+    assert info.last_path == 3 and info.last_fallbacks == 0 and info.head_columns >= 500
+    ref_ids, ref_sc, info = _search(idx, q[20:28], 100, blocked_postings=0)
+    assert info.last_path == 1
+    assert (ids[20:28] == ref_ids).all() and (sc[20:28] == ref_sc).all()
