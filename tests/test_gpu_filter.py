@@ -317,3 +317,29 @@ def test_baseline_sized_skewed_index_with_head_strips():
     ref_ids, ref_sc, info = _search(idx, q[20:28], 100, blocked_postings=0)
     assert info.last_path == 1
     assert (ids[20:28] == ref_ids).all() and (sc[20:28] == ref_sc).all()
+
+
+def test_head_strips_edge_cases_empty_queries_and_append():
+    """Dense strips with queries that have no entries at all / entries on head columns only / a single entry, in one ragged batch;
+    appending rows drops the strips with the rest of the copy and the next search rebuilds them."""
+    n = 12000
+    ip, ix, d = oracle.synth_csr(0, 0, n, V, 768, synth.KIND_SKEW)
+    cut = int(ip[9000])
+    idx = DeviceIndex.reserved(n, len(ix), V, nat.VS_F32)
+    idx.append_csr(ip[:9001], ix[:cut], d[:cut])
+    df = np.bincount(ix[:cut], minlength=V)
+    q = oracle.synth_queries(3, 12, kind=synth.KIND_SKEW)
+    q[1] = 0.0                                                        # no entries
+    q[5] = 0.0
+    q[5, np.nonzero(df >= 9000 // 2)[0][:9]] = 2.0                   # head columns only
+    q[7] = 0.0
+    q[7, int(np.nonzero((df > 3) & (df < 40))[0][0])] = 0.75          # one ordinary column
+    q[11] = 0.0                                                       # the batch ends on an empty query
+    for stage in ("9000 rows", "12000 rows"):
+        ref_ids, ref_sc, info = _search(idx, q, 50, blocked_postings=0)
+        ids, sc, info = _search(idx, q, 50, blocked_postings=1)
+        assert info.last_path == 3 and info.head_columns > 100, stage
+        assert (ids == ref_ids).all() and (sc == ref_sc).all(), stage
+        if stage == "9000 rows":
+            idx.append_csr(ip[9000:] - ip[9000], ix[cut:], d[cut:])
+            assert idx.info().head_columns == 0                       # the copy (lists and strips) is gone until the next search
