@@ -678,11 +678,13 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
                             vv[3] = __uint_as_float(vav.w); vv[4] = __uint_as_float(vbv.x); vv[5] = __uint_as_float(vbv.y);
                             vv[6] = __uint_as_float(vbv.z); vv[7] = __uint_as_float(vbv.w);
                         } else if constexpr (VM == VM_F16) {
+                            // weight x fp16 value in ONE instruction (v_fma_mix_f32 converts the selected half on the way in; + 0: the
+                            // product is rounded once, exactly as convert-then-multiply): the walk is bound by VALU issue (77 % busy)
                             const uint32_t hw2[4] = {vav.x, vav.y, vav.z, vav.w};
 #pragma unroll
                             for (int t = 0; t < 4; ++t) {
-                                const float2 f = __half22float2(*reinterpret_cast<const __half2*>(&hw2[t]));
-                                vv[2 * t] = f.x; vv[2 * t + 1] = f.y;
+                                asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,1,0]" : "=v"(vv[2 * t]) : "v"(wq), "v"(hw2[t]));
+                                asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "=v"(vv[2 * t + 1]) : "v"(wq), "v"(hw2[t]));
                             }
                         }
                         [[maybe_unused]] int32_t wi = 0;
@@ -697,7 +699,7 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
                                 if constexpr (AM == AM_FIX) lds_add(off, wi);
                                 else lds_add(off, wd);
                             } else {
-                                const float prod = wq * vv[t];
+                                const float prod = VM == VM_F16 ? vv[t] : wq * vv[t];     // (fp16 records: already the product)
                                 if constexpr (AM == AM_FIX) lds_add(off, (int32_t)prod);
                                 else lds_add(off, (double)prod);
                             }
