@@ -994,9 +994,8 @@ int bp_filter_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64
     float* qvals = reinterpret_cast<float*>(qcols + qcap);
     // 1. sparsify the batch and plan the tiles, all on the device
     VS_HIP(hipMemsetAsync(colfreq, 0, (size_t)(V + 4) * 4 + 8, s));
-    hipLaunchKernelGGL(count_nz_kernel<0>, dim3(std::min(B, 2048)), dim3(kSpThreads), 0, s, dq, (int64_t)V, B, V, counts);
-    hipLaunchKernelGGL(mq_colfreq_kernel<0>, dim3(std::min(B, 2048)), dim3(kSpThreads), 0, s, dq, (int64_t)V, B, V, colfreq);
-    hipLaunchKernelGGL(bp_plan_kernel<0>, dim3(1), dim3(64), 0, s, counts, B, qt, vals_cap, qptr, tiles, dplan, flags);
+    hipLaunchKernelGGL(bp_count_colfreq_kernel<0>, dim3(std::min(B, 2048)), dim3(256), 0, s, dq, (int64_t)V, B, V, counts, colfreq);
+    hipLaunchKernelGGL(bp_plan_kernel<0>, dim3(1), dim3(256), 0, s, counts, B, qt, vals_cap, qptr, tiles, dplan, flags);
     hipLaunchKernelGGL(fill_csr_kernel<0>, dim3(std::min(B, 2048)), dim3(kSpThreads), 0, s, dq, (int64_t)V, B, V, qptr, qcols, qvals, qcap);
     if (idx->bp_df.p)
         hipLaunchKernelGGL(bp_walk_kernel<0>, dim3(1), dim3(kScanThreads), 0, s, colfreq, idx->bp_df.as<unsigned long long>(),
