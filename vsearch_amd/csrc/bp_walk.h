@@ -299,6 +299,8 @@ struct BpArgs {
     uint64_t* cand;           // [B, nchunk, k] output keys, sorted descending
     uint64_t* gcand;          // [grid, QT, kBpCap] scratch
     const uint64_t* upper;    // optional [B] exclusive upper bounds ("search after")
+    unsigned long long* gtau; // optional [B], zeroed per search: the best K-th key any (tile, chunk) item has established for the query --
+                              // a lower bound of the K-th best over all chunks, shared so that no item starts (or stays) cold
     const float* qscale;      // AM_FIX: [B] per-query power-of-two scale of the fixed-point sums
     const uint16_t* hmap;     // head columns (dense strips), n_head > 0 only: [n_cols] strip index or 0xFFFF
     const __half* strip;      // fp16 values of the head columns, MFMA operand order (bp_strip_index)
@@ -755,6 +757,8 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
                 }
                 if (kPairsAhead && b + 1 < b1) first_pairs(b + 1, wv_id);
             }
+            // thresholds other items of the same queries have published meanwhile (read before the barrier: the latency hides in it)
+            if (a.gtau && tid < nq) { const unsigned long long g = a.gtau[q0 + tid]; if (g > tau[tid]) tau[tid] = g; }
             lap(1);
             __syncthreads();
             if (tid == 0) scratch[40 + (int)((b + 1) & 1)] = 0;     // the next block's chunk counter (its last user was block b - 1)
@@ -810,7 +814,9 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
                         } else if (cnt > (uint32_t)K) {
                             for (int i = tid; i < K; i += kScanThreads) my_gcand[(size_t)qs * kBpCap + i] = sortbuf[i];
                             if (tid == 0) {
-                                tau[qs] = sortbuf[K - 1];
+                                const unsigned long long kth = sortbuf[K - 1];
+                                if (kth > tau[qs]) tau[qs] = kth;
+                                if (a.gtau && kth != 0ull) atomicMax(a.gtau + q0 + qs, kth);
                                 ccnt[qs] = (uint32_t)K;
                             }
                         }

@@ -975,9 +975,10 @@ int bp_filter_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64
     const size_t off_counts = 0, off_qptr = off_counts + (size_t)B * 8, off_plan = off_qptr + (size_t)(B + 1) * 8, off_tiles = off_plan + 64,
                  off_fb = off_tiles + (size_t)B * 8, off_scale = off_fb + (size_t)B * 8, off_slack = off_scale + (size_t)B * 4,
                  off_wsum = off_slack + (size_t)B * 4, off_flags = off_wsum + (size_t)B * 4, off_nfb = off_flags + (size_t)B * 4,
-                 off_freq = (off_nfb + 64 + 15) & ~(size_t)15;
+                 off_gtau = (off_nfb + 64 + 15) & ~(size_t)15, off_freq = (off_gtau + (size_t)B * 8 + 15) & ~(size_t)15;
     VS_TRY(idx->ws_mq_meta.reserve(off_freq + (size_t)(V + 4) * 4 + 8));
     char* meta = idx->ws_mq_meta.as<char>();
+    unsigned long long* gtau = (unsigned long long*)(meta + off_gtau);
     int64_t* counts = (int64_t*)(meta + off_counts);
     int64_t* qptr = (int64_t*)(meta + off_qptr);
     int64_t* dplan = (int64_t*)(meta + off_plan);
@@ -993,7 +994,7 @@ int bp_filter_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64
     int32_t* qcols = idx->ws_mq_q.as<int32_t>();
     float* qvals = reinterpret_cast<float*>(qcols + qcap);
     // 1. sparsify the batch and plan the tiles, all on the device
-    VS_HIP(hipMemsetAsync(colfreq, 0, (size_t)(V + 4) * 4 + 8, s));
+    VS_HIP(hipMemsetAsync(gtau, 0, (size_t)(off_freq - off_gtau) + (size_t)(V + 4) * 4 + 8, s));      // thresholds + column frequencies (adjacent)
     hipLaunchKernelGGL(bp_count_colfreq_kernel<0>, dim3(std::min(B, 2048)), dim3(256), 0, s, dq, (int64_t)V, B, V, counts, colfreq);
     hipLaunchKernelGGL(bp_plan_kernel<0>, dim3(1), dim3(256), 0, s, counts, B, qt, vals_cap, qptr, tiles, dplan, flags);
     hipLaunchKernelGGL(fill_csr_kernel<0>, dim3(std::min(B, 2048)), dim3(kSpThreads), 0, s, dq, (int64_t)V, B, V, qptr, qcols, qvals, qcap);
@@ -1033,6 +1034,7 @@ int bp_filter_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64
     a.cand = idx->ws_cand.as<uint64_t>();
     a.gcand = idx->ws_mq_cand.as<uint64_t>();
     a.qscale = qscale;
+    a.gtau = gtau;
     a.hmap = idx->bp_n_head > 0 ? idx->bp_hmap.as<uint16_t>() : nullptr;
     a.strip = idx->bp_strip.as<__half>();
     a.n_head = idx->bp_n_head;
