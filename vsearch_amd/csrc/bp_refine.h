@@ -109,19 +109,33 @@ struct RefineArgs {
     uint32_t* flags;          // [B] in: 2 = the query entered no tile; out: 1 = the top k could not be proven from K' candidates
 };
 
-template <int VM>
+// IMG = 1: the query's dense fp32 row sits in LDS for the re-scoring (118 KB at V = 29 523: with the candidate buffers 159 KB, one
+// workgroup per CU).  The 98 k weight look-ups of a query's 128 candidates are random 4-byte reads: from L2 they ran at the CU's
+// ~0.13 lines per clock (outstanding-miss limit) and made the kernel 0.63 ms per 1024 queries; from LDS they are a few microseconds.
+// IMG = 0 (wider vocabularies): global look-ups.
+__host__ __device__ inline size_t refine_lds_bytes(int32_t n_cols, int img) {
+    return (img ? scan_img_bytes(n_cols) : 0) + (size_t)kWgCap * 8 + (size_t)kBpMaxK * 8 + 16;
+}
+template <int VM, int IMG>
 __global__ __launch_bounds__(kScanThreads) void refine_topk_kernel(RefineArgs a) {
-    __shared__ uint64_t buf[kWgCap];
-    __shared__ uint64_t ex[kBpMaxK];
-    __shared__ int cnt_sh;
+    extern __shared__ __attribute__((aligned(16))) char smem_r[];
+    float* img = reinterpret_cast<float*>(smem_r);
+    uint64_t* buf = reinterpret_cast<uint64_t*>(smem_r + (IMG ? scan_img_bytes(a.n_cols) : 0));      // [kWgCap]
+    uint64_t* ex = buf + kWgCap;                                                                       // [kBpMaxK]
+    int* cnt_ptr = reinterpret_cast<int*>(ex + kBpMaxK);
+    int& cnt_sh = *cnt_ptr;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int K = a.k, KP = a.kp;
     for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
         if (a.flags[b] == 2u) continue;                             // too dense for a tile: no candidates exist, the exact pass takes it
+        const float* qrow = a.q + (size_t)b * a.n_cols;
+        if constexpr (IMG != 0) {
+            __syncthreads();                                          // (the previous query's look-ups are done)
+            for (int i = tid; i <= a.n_cols; i += kScanThreads) img[i] = i < a.n_cols ? qrow[i] : 0.f;      // pad columns (id n_cols) carry no weight
+        }
         merge_select(a.cand + (size_t)b * a.n_cand, a.n_cand, a.run_len, KP, nullptr, buf, &cnt_sh, tid);
         __syncthreads();
         const uint64_t cut_key = buf[KP - 1];                         // 0: fewer than K' documents exist -> every document is a candidate
-        const float* qrow = a.q + (size_t)b * a.n_cols;
         int pow2 = 64;
         while (pow2 < KP) pow2 <<= 1;
         for (int i = KP + tid; i < pow2; i += kScanThreads) ex[i] = 0ull;
@@ -131,8 +145,10 @@ __global__ __launch_bounds__(kScanThreads) void refine_topk_kernel(RefineArgs a)
             uint64_t out = 0ull;
             if (key != 0ull) {
                 const uint32_t row = key_row(key);
-                const double sum = row_sum_f64<VM>(a.pk_ptr, a.cols, a.vals, row, lane,
-                                                   [&](uint32_t col) { return col < (uint32_t)a.n_cols ? qrow[col] : 0.f; });   // pad columns (id n_cols) carry no weight
+                const double sum = row_sum_f64<VM>(a.pk_ptr, a.cols, a.vals, row, lane, [&](uint32_t col) {
+                    if constexpr (IMG != 0) return img[col];
+                    else return col < (uint32_t)a.n_cols ? qrow[col] : 0.f;                                   // pad columns (id n_cols) carry no weight
+                });
                 out = make_key((float)sum, row);
             }
             if (lane == 0) ex[i] = out;

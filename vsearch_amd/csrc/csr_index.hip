@@ -1094,10 +1094,15 @@ int bp_filter_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64
     r.flags = flags;
     {
         ProfScope prof("refine_topk", s);
-        const int rgrid = std::min(B, idx->cu_count * 2);
-        if (idx->store_dtype == VS_F32) hipLaunchKernelGGL(refine_topk_kernel<VM_F32>, dim3(rgrid), dim3(kScanThreads), 0, s, r);
-        else if (idx->store_dtype == VS_F16) hipLaunchKernelGGL(refine_topk_kernel<VM_F16>, dim3(rgrid), dim3(kScanThreads), 0, s, r);
-        else hipLaunchKernelGGL(refine_topk_kernel<VM_BIN>, dim3(rgrid), dim3(kScanThreads), 0, s, r);
+        // the query's dense row in LDS when it fits beside the candidate buffers (V <= ~30 k): one workgroup per CU then
+        const bool img = refine_lds_bytes(V, 1) <= (size_t)160 * 1024;
+        const size_t rlds = refine_lds_bytes(V, img ? 1 : 0);
+        const int rgrid = std::min(B, idx->cu_count * (img ? 1 : 2));
+        void (*rk)(RefineArgs) = idx->store_dtype == VS_F32 ? (img ? refine_topk_kernel<VM_F32, 1> : refine_topk_kernel<VM_F32, 0>)
+                               : idx->store_dtype == VS_F16 ? (img ? refine_topk_kernel<VM_F16, 1> : refine_topk_kernel<VM_F16, 0>)
+                                                            : (img ? refine_topk_kernel<VM_BIN, 1> : refine_topk_kernel<VM_BIN, 0>);
+        VS_HIP(hipFuncSetAttribute((const void*)rk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));
+        hipLaunchKernelGGL(rk, dim3(rgrid), dim3(kScanThreads), rlds, s, r);
         VS_HIP(hipGetLastError());
     }
     VS_STAGE("refine", s);
