@@ -234,6 +234,70 @@ __global__ __launch_bounds__(64) void bp_plan_kernel(const int64_t* counts, int3
     }
 }
 
+// The same plan for batches of up to kPlanFast queries (34 KB of LDS) in ~20 us: the counts, their running sums and, for every query, where a
+// tile STARTING there would end (a jump pointer: at most qt look-aheads, all queries in parallel) are computed by the whole
+// workgroup; only the walk along the jump pointers -- one step per TILE, not per query -- is sequential.
+constexpr int kPlanFast = 4096;
+template <int UNUSED>
+__global__ __launch_bounds__(256) void bp_plan_fast_kernel(const int64_t* counts, int32_t B, int32_t qt, int32_t vals_cap, int64_t* qptr, int2* tiles,
+                                                           int64_t* plan, uint32_t* flags) {
+    __shared__ int32_t c_sh[kPlanFast];             // count, or -1 for a query too dense for a tile
+    __shared__ int32_t nx_sh[kPlanFast];            // first query after the tile that starts here
+    __shared__ long long seg_sh[256];
+    __shared__ int mx_sh;
+    if (blockIdx.x != 0) return;
+    const int tid = threadIdx.x;
+    if (tid == 0) mx_sh = 0;
+    __syncthreads();
+    int mx = 0;
+    for (int b = tid; b < B; b += 256) {
+        const int64_t c64 = counts[b];
+        const int32_t c = (int32_t)min(c64, (int64_t)0x7FFFFFFF);
+        mx = max(mx, c);
+        const bool dense = c > vals_cap;
+        c_sh[b] = dense ? -1 : c;
+        flags[b] = dense ? 2u : 0u;
+    }
+    atomicMax(&mx_sh, mx);
+    __syncthreads();
+    // running sums of the counts that enter tiles: a contiguous segment per thread, then a scan of the 256 segment totals
+    const int seg = (B + 255) / 256;
+    const int i0 = min(B, tid * seg), i1 = min(B, i0 + seg);
+    long long mine = 0;
+    for (int i = i0; i < i1; ++i) mine += max(c_sh[i], 0);
+    seg_sh[tid] = mine;
+    __syncthreads();
+    if (tid == 0) {
+        long long run = 0;
+        for (int i = 0; i < 256; ++i) { const long long v = seg_sh[i]; seg_sh[i] = run; run += v; }
+        qptr[0] = 0;
+        plan[1] = mx_sh;
+        plan[2] = run;
+        plan[3] = 0;
+    }
+    __syncthreads();
+    long long run = seg_sh[tid];
+    for (int i = i0; i < i1; ++i) { run += max(c_sh[i], 0); qptr[i + 1] = run; }
+    // jump pointers
+    for (int b = tid; b < B; b += 256) {
+        int j = b, cnt = 0;
+        long long nz = 0;
+        while (j < B && cnt < qt && c_sh[j] >= 0 && nz + c_sh[j] <= vals_cap) { nz += c_sh[j]; ++cnt; ++j; }
+        nx_sh[b] = max(j, b + 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int nt = 0;
+        for (int b = 0; b < B;) {
+            if (c_sh[b] < 0) { ++b; continue; }
+            const int j = nx_sh[b];
+            tiles[nt++] = make_int2(b, j - b);
+            b = j;
+        }
+        plan[0] = nt;
+    }
+}
+
 // non-zeros per dense query row AND the batch's column frequencies (what the walk accounting needs) in one pass over the batch
 template <int UNUSED>
 __global__ __launch_bounds__(256) void bp_count_colfreq_kernel(const float* x, int64_t ld, int32_t B, int32_t V, int64_t* counts, uint32_t* colfreq) {

@@ -996,7 +996,8 @@ int bp_filter_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64
     // 1. sparsify the batch and plan the tiles, all on the device
     VS_HIP(hipMemsetAsync(gtau, 0, (size_t)(off_freq - off_gtau) + (size_t)(V + 4) * 4 + 8, s));      // thresholds + column frequencies (adjacent)
     hipLaunchKernelGGL(bp_count_colfreq_kernel<0>, dim3(std::min(B, 2048)), dim3(256), 0, s, dq, (int64_t)V, B, V, counts, colfreq);
-    hipLaunchKernelGGL(bp_plan_kernel<0>, dim3(1), dim3(64), 0, s, counts, B, qt, vals_cap, qptr, tiles, dplan, flags);
+    if (B <= kPlanFast) hipLaunchKernelGGL(bp_plan_fast_kernel<0>, dim3(1), dim3(256), 0, s, counts, B, qt, vals_cap, qptr, tiles, dplan, flags);
+    else hipLaunchKernelGGL(bp_plan_kernel<0>, dim3(1), dim3(64), 0, s, counts, B, qt, vals_cap, qptr, tiles, dplan, flags);
     hipLaunchKernelGGL(fill_csr_kernel<0>, dim3(std::min(B, 2048)), dim3(kSpThreads), 0, s, dq, (int64_t)V, B, V, qptr, qcols, qvals, qcap);
     if (idx->bp_df.p)
         hipLaunchKernelGGL(bp_walk_kernel<0>, dim3(1), dim3(kScanThreads), 0, s, colfreq, idx->bp_df.as<unsigned long long>(),
