@@ -660,8 +660,12 @@ int prep_queries(vs_index* idx, const void* q, int q_dtype, int64_t ldq, int B, 
         VS_HIP(hipMemcpyAsync(idx->ws_misc.p, q, bytes, hipMemcpyHostToDevice, s));
         dq = idx->ws_misc.p;
     }
-    VS_TRY(idx->ws_q.reserve((size_t)B * idx->n_cols * 4));
     const int round_f16 = idx->store_dtype == VS_F16;
+    if (q_dtype == VS_F32 && !round_f16 && ldq == idx->n_cols) {          // already what the kernels read: contiguous fp32 rows on the device
+        *out = (const float*)dq;
+        return VS_OK;
+    }
+    VS_TRY(idx->ws_q.reserve((size_t)B * idx->n_cols * 4));
     const int64_t n = (int64_t)B * idx->n_cols;
     const unsigned grid = (unsigned)std::min<int64_t>(ceil_div64(n, 256), 4096);
     if (q_dtype == VS_F32)
