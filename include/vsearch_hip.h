@@ -121,6 +121,16 @@ VS_API int vs_index_append_csr(vs_index* index, const void* rowptr, int rowptr_d
 /* Native shard files (".vsx"): the device format written / read verbatim.  SparseIndex.init_index re-parses,
  * slices and vstacks scipy .npz shards on every load (index.py:172-176); a .vsx file is a header + the three
  * device arrays, so a 97 GB index loads at storage speed.                                                */
+/* scipy.sparse.save_npz shards read natively (SparseIndex.init_index: load_npz(f)[:, shift:] per shard, then
+ * vstack, index.py:172-175).  A .npz is a ZIP archive (stored or deflated members, ZIP64 for members beyond 4 GB) of .npy arrays
+ * indptr / indices / data / shape / format; only format "csr" is read (anything else: VS_EUNSUPPORTED -- the Python facade then
+ * falls back to scipy).  No GPU is touched by vs_npz_inspect.
+ *   vs_npz_inspect: shape of the shard and what remains after the column shift -- columns below `shift` are dropped, n_cols
+ *     is reported after the shift; `packets` = 8-nnz packets of the device format (what vs_index_create_reserved needs).
+ *   vs_index_append_npz: appends the shard's rows to a reserved CSR index (columns shifted and sorted within a row; a binary
+ *     index -- store VS_NONE -- requires every stored value == 1).                                                            */
+VS_API int vs_npz_inspect(const char* path, int32_t shift, int64_t* n_rows, int64_t* n_cols, int64_t* nnz, int64_t* packets);
+VS_API int vs_index_append_npz(vs_index* index, const char* path, int32_t shift);
 VS_API int vs_index_save_native(const vs_index* index, const char* path);
 VS_API int vs_index_load_native(const char* path, int device, vs_index** out);
 

@@ -1,0 +1,93 @@
+"""The library's own reader of scipy.sparse.save_npz shards (csrc/npz.hip) against scipy: stored and deflated archives, int32 and
+int64 indices, fp32 / fp64 / fp16-widened values, unsorted rows, the column shift (SparseIndex.init_index: `load_npz(f)[:, shift:]`,
+reference index.py:172).  vs_npz_inspect needs no GPU; the append path is checked on the GPU."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from vsearch_amd import _native as nat
+from vsearch_amd.device_index import DeviceIndex, npz_inspect
+
+
+def _random_csr(rng, n, m, density, dtype=np.float32, index_dtype=np.int32, sort=True):
+    mat = sp.random(n, m, density=density, format="csr", random_state=rng, dtype=np.float64)
+    mat.data = (0.25 + rng.random(mat.nnz)).astype(dtype)
+    mat = sp.csr_matrix((mat.data, mat.indices.astype(index_dtype), mat.indptr.astype(index_dtype)), shape=(n, m))
+    if not sort:                                                       # reverse every row's column order
+        for r in range(n):
+            a, b = mat.indptr[r], mat.indptr[r + 1]
+            mat.indices[a:b] = mat.indices[a:b][::-1].copy()
+            mat.data[a:b] = mat.data[a:b][::-1].copy()
+        mat.has_sorted_indices = False
+    return mat
+
+
+@pytest.mark.parametrize("compressed", [True, False], ids=["deflate", "stored"])
+@pytest.mark.parametrize("index_dtype", [np.int32, np.int64], ids=["i4", "i8"])
+def test_inspect_matches_scipy(tmp_path, compressed, index_dtype):
+    rng = np.random.default_rng(5)
+    mat = _random_csr(rng, 300, 1500, 0.03, index_dtype=index_dtype)
+    path = str(tmp_path / "shard.npz")
+    sp.save_npz(path, mat, compressed=compressed)
+    for shift in (0, 1, 999):
+        cut = mat[:, shift:]
+        lens = np.diff(cut.indptr)
+        assert npz_inspect(path, shift) == (300, 1500 - shift, int(cut.nnz), int(((lens + 7) // 8).sum()))
+
+
+def test_inspect_rejects_other_files(tmp_path):
+    rng = np.random.default_rng(6)
+    mat = _random_csr(rng, 50, 80, 0.1)
+    p_coo = str(tmp_path / "coo.npz")
+    sp.save_npz(p_coo, mat.tocoo())
+    with pytest.raises(NotImplementedError):
+        npz_inspect(p_coo, 0)
+    p_bad = str(tmp_path / "bad.npz")
+    with open(p_bad, "wb") as f:
+        f.write(b"this is not a zip archive at all" * 8)
+    with pytest.raises(ValueError):
+        npz_inspect(p_bad, 0)
+    p_csr = str(tmp_path / "ok.npz")
+    sp.save_npz(p_csr, mat)
+    raw = open(p_csr, "rb").read()
+    p_cut = str(tmp_path / "cut.npz")
+    with open(p_cut, "wb") as f:
+        f.write(raw[: len(raw) // 2])
+    with pytest.raises(ValueError):
+        npz_inspect(p_cut, 0)
+    with pytest.raises(ValueError):
+        npz_inspect(p_csr, 81)                                         # shift beyond the columns
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("store", [nat.VS_F32, nat.VS_F16, nat.VS_NONE], ids=["fp32", "fp16", "binary"])
+def test_append_npz_equals_scipy_slice(tmp_path, store):
+    rng = np.random.default_rng(7)
+    shift = 37
+    shards = [_random_csr(rng, 700, 4000, 0.02, dtype=np.float64, index_dtype=np.int64, sort=False),
+              _random_csr(rng, 450, 4000, 0.05, dtype=np.float32)]
+    if store == nat.VS_NONE:
+        for m in shards:
+            m.data[:] = 1
+    paths = []
+    for i, m in enumerate(shards):
+        paths.append(str(tmp_path / f"s{i}.npz"))
+        sp.save_npz(paths[-1], m, compressed=bool(i))
+    sizes = [npz_inspect(p, shift) for p in paths]
+    idx = DeviceIndex.reserved(sum(s[0] for s in sizes), sum(s[3] for s in sizes), 4000 - shift, store)
+    for p in paths:
+        idx.append_npz(p, shift)
+    ip, ix, d = idx.export_csr(np.float32)
+    ref = sp.vstack([m.tocsr()[:, shift:] for m in shards]).tocsr()
+    ref.sort_indices()
+    assert (ip == ref.indptr).all() and (ix == ref.indices).all()
+    want = ref.data.astype(np.float32)
+    if store == nat.VS_F16:
+        want = want.astype(np.float16).astype(np.float32)
+    assert (d == want).all()
+    if store == nat.VS_NONE:
+        shards[0].data[3] = 2.0
+        sp.save_npz(paths[0], shards[0])
+        idx2 = DeviceIndex.reserved(sizes[0][0], sizes[0][3] + 8, 4000 - shift, store)
+        with pytest.raises(ValueError):
+            idx2.append_npz(paths[0], shift)

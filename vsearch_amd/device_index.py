@@ -58,6 +58,13 @@ def current_stream(device: int):
     return None
 
 
+def npz_inspect(path: str, shift: int = 0):
+    """(n_rows, n_cols after the shift, nnz after the shift, 8-nnz packets) of a scipy.sparse.save_npz CSR shard; no GPU needed."""
+    n_rows, n_cols, nnz, packets = C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_int64(0)
+    nat.check(nat.lib().vs_npz_inspect(str(path).encode(), int(shift), C.byref(n_rows), C.byref(n_cols), C.byref(nnz), C.byref(packets)))
+    return n_rows.value, n_cols.value, nnz.value, packets.value
+
+
 class DeviceIndex:
     """Owner of one device-resident index shard (CSR packets or dense)."""
 
@@ -104,6 +111,11 @@ class DeviceIndex:
         p_v, dt_v, k3 = as_arg(data, (nat.VS_F32, nat.VS_F16))
         nat.check(nat.lib().vs_index_append_csr(self._h, p_rp, dt_rp, p_ci, dt_ci, p_v, dt_v if data is not None else nat.VS_F32,
                                                 int(indptr.shape[0]) - 1))
+
+    def append_npz(self, path: str, shift: int = 0):
+        """Append a scipy.sparse.save_npz CSR shard read natively (zip + npy parsed in the library): columns below `shift` dropped,
+        ids moved down by `shift`, sorted within a row.  NotImplementedError for non-CSR files."""
+        nat.check(nat.lib().vs_index_append_npz(self._h, str(path).encode(), int(shift)))
 
     def save_native(self, path: str):
         """Write the device format verbatim (.vsx shard file)."""

@@ -309,18 +309,21 @@ class SparseIndex(Index):
             self._dtype = torch.float32 if info.store_dtype == nat.VS_F32 else torch.float16
             self._shape = (info.n_rows, info.n_cols)
             return
-        # pass 1: sizes only (row pointers are read lazily from the .npz; the column shift can only shorten rows,
-        # so the packet count before the shift is an upper bound for the reservation)
+        # pass 1: sizes only.  CSR shards are inspected by the library (zip + npy parsed natively, the column shift applied);
+        # other scipy formats go through scipy (bound by nnz).
+        from vsearch_amd.device_index import npz_inspect
         rows_total, packets_cap, n_cols = 0, 0, None
+        native = {}
         for f in files:
-            with np.load(f) as z:
-                fmt = z["format"].item() if "format" in z.files else b"csr"
-                fmt = fmt.decode() if isinstance(fmt, bytes) else str(fmt)
-                shape = tuple(int(x) for x in z["shape"])
-                if fmt == "csr":
-                    lens = np.diff(z["indptr"])
-                    packets_cap += int(((lens + 7) // 8).sum())
-                else:                                           # other scipy formats: bound by nnz
+            try:
+                n_r, n_c, _, pk = npz_inspect(f, self.shift)
+                native[f] = True
+                shape = (n_r, n_c + self.shift)
+                packets_cap += pk
+            except NotImplementedError:                             # not a CSR file
+                native[f] = False
+                with np.load(f) as z:
+                    shape = tuple(int(x) for x in z["shape"])
                     packets_cap += int(z["data"].shape[0]) if "data" in z.files else shape[0] * shape[1]
             rows_total += shape[0]
             if n_cols is None:
@@ -336,6 +339,9 @@ class SparseIndex(Index):
         # pass 2: one shard at a time -- the reference's vstack(shards) (index.py:175) never exists on the host
         dev = DeviceIndex.reserved(rows_total, packets_cap, n_cols - self.shift, store, device=_gpu_ordinal(self.device))
         for f in files:
+            if native[f]:
+                dev.append_npz(f, self.shift)                       # file -> rows, no scipy object in between
+                continue
             mat = load_npz(f).tocsr()[:, self.shift:]
             mat.sort_indices()
             data = mat.data.astype(np.float32, copy=False)
