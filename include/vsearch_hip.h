@@ -131,6 +131,10 @@ VS_API int vs_index_append_csr(vs_index* index, const void* rowptr, int rowptr_d
  *     index -- store VS_NONE -- requires every stored value == 1).                                                            */
 VS_API int vs_npz_inspect(const char* path, int32_t shift, int64_t* n_rows, int64_t* n_cols, int64_t* nnz, int64_t* packets);
 VS_API int vs_index_append_npz(vs_index* index, const char* path, int32_t shift);
+/* SparseIndex.save (index.py:181-202): the index as a scipy.sparse.save_npz file that scipy.sparse.load_npz reads back -- CSR,
+ * int64 indptr / indices (the reference's torch CSR has int64 ids), fp32 data (all 1 for a binary index).  compressed = 0:
+ * stored members; 1: deflate (level 1).  ZIP64 records are written where a member or an offset passes 4 GB.                  */
+VS_API int vs_index_save_npz(const vs_index* index, const char* path, int compressed);
 VS_API int vs_index_save_native(const vs_index* index, const char* path);
 VS_API int vs_index_load_native(const char* path, int device, vs_index** out);
 

@@ -91,3 +91,29 @@ def test_append_npz_equals_scipy_slice(tmp_path, store):
         idx2 = DeviceIndex.reserved(sizes[0][0], sizes[0][3] + 8, 4000 - shift, store)
         with pytest.raises(ValueError):
             idx2.append_npz(paths[0], shift)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("compressed", [False, True], ids=["stored", "deflate"])
+@pytest.mark.parametrize("store", [nat.VS_F32, nat.VS_NONE], ids=["fp32", "binary"])
+def test_save_npz_is_read_by_scipy_and_by_the_library(tmp_path, compressed, store):
+    """vs_index_save_npz writes what scipy.sparse.load_npz reads (SparseIndex.save, reference index.py:181-202) and what the
+    library's own reader reads back."""
+    rng = np.random.default_rng(11)
+    mat = _random_csr(rng, 900, 3000, 0.03, dtype=np.float32, index_dtype=np.int64)
+    if store == nat.VS_NONE:
+        mat.data[:] = 1
+    idx = DeviceIndex.from_csr(mat.indptr, mat.indices, None if store == nat.VS_NONE else mat.data, 3000, store_dtype=store)
+    path = str(tmp_path / "out.npz")
+    idx.save_npz(path, compressed=compressed)
+    back = sp.load_npz(path)
+    assert back.format == "csr" and back.shape == (900, 3000)
+    assert back.indices.dtype == np.int64 and back.indptr.dtype == np.int64 and back.data.dtype == np.float32
+    assert (back.indptr == mat.indptr).all() and (back.indices == mat.indices).all() and (back.data == mat.data).all()
+    with np.load(path) as z:
+        assert sorted(z.files) == ["_is_array", "data", "format", "indices", "indptr", "shape"] and z["format"].item() == b"csr"
+    n_r, n_c, nnz, pk = npz_inspect(path, 0)
+    again = DeviceIndex.reserved(n_r, pk, n_c, store)
+    again.append_npz(path, 0)
+    ip, ix, d = again.export_csr(np.float32)
+    assert (ip == mat.indptr).all() and (ix == mat.indices).all() and (d == mat.data).all()

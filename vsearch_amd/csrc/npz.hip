@@ -358,3 +358,158 @@ extern "C" int vs_index_append_npz(vs_index* idx, const char* path, int32_t shif
     }
     return vs_index_append_csr(idx, rp.data(), VS_I64, cols.data(), VS_I32, binary ? nullptr : vals.data(), VS_F32, c.n_rows);
 }
+
+// ---- writer: SparseIndex.save (index.py:181-202: CSR -> scipy save_npz) without scipy --------------------------------------------
+namespace vs {
+namespace {
+
+struct ZipWriter {
+    FILE* f = nullptr;
+    struct Entry { std::string name; uint32_t crc; uint64_t comp, size, off; uint16_t method; };
+    std::vector<Entry> entries;
+    uint64_t pos = 0;
+    ~ZipWriter() { if (f) fclose(f); }
+    int put(const void* p, size_t n) {
+        if (n && fwrite(p, 1, n, f) != n) return fail(VS_EINVAL, "zip: write failed (disk full?)");
+        pos += n;
+        return VS_OK;
+    }
+    static void w16(std::vector<unsigned char>& b, uint16_t v) { b.push_back((unsigned char)v); b.push_back((unsigned char)(v >> 8)); }
+    static void w32(std::vector<unsigned char>& b, uint32_t v) { for (int i = 0; i < 4; ++i) b.push_back((unsigned char)(v >> (8 * i))); }
+    static void w64(std::vector<unsigned char>& b, uint64_t v) { for (int i = 0; i < 8; ++i) b.push_back((unsigned char)(v >> (8 * i))); }
+
+    // one member = .npy header + payload; sizes are known up front (stored) or patched through a zip64 data descriptor-free layout:
+    // deflated members are compressed into memory chunk by chunk, so the local header can carry the final sizes
+    int add(const std::string& name, const std::vector<char>& head, const void* payload, uint64_t payload_bytes, bool deflate_it) {
+        const uint64_t size = head.size() + payload_bytes;
+        uint32_t crc = (uint32_t)crc32(0L, Z_NULL, 0);
+        auto crc_feed = [&](const void* p, uint64_t n) {
+            const unsigned char* q = reinterpret_cast<const unsigned char*>(p);
+            while (n) { const uInt c = (uInt)std::min<uint64_t>(n, (uint64_t)1 << 30); crc = (uint32_t)crc32(crc, q, c); q += c; n -= c; }
+        };
+        crc_feed(head.data(), head.size());
+        crc_feed(payload, payload_bytes);
+        std::vector<unsigned char> comp;
+        if (deflate_it) {
+            z_stream zs;
+            memset(&zs, 0, sizeof(zs));
+            if (deflateInit2(&zs, 1, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return fail(VS_EINVAL, "zlib: deflateInit2 failed");
+            comp.resize((size_t)(size + size / 1000 + 1024));
+            uint64_t produced = 0;
+            auto feed = [&](const void* p, uint64_t n, int last) -> int {
+                const unsigned char* q = reinterpret_cast<const unsigned char*>(p);
+                do {
+                    const uInt c = (uInt)std::min<uint64_t>(n, (uint64_t)1 << 30);
+                    zs.next_in = const_cast<unsigned char*>(q);
+                    zs.avail_in = c;
+                    q += c; n -= c;
+                    const int flush = (last && n == 0) ? Z_FINISH : Z_NO_FLUSH;
+                    for (;;) {
+                        if (produced == comp.size()) comp.resize(comp.size() + comp.size() / 4 + 65536);
+                        const uInt room = (uInt)std::min<uint64_t>(comp.size() - produced, (uint64_t)1 << 30);
+                        zs.next_out = comp.data() + produced;
+                        zs.avail_out = room;
+                        const int zr = deflate(&zs, flush);
+                        produced += room - zs.avail_out;
+                        if (zr == Z_STREAM_END) break;
+                        if (zr != Z_OK && zr != Z_BUF_ERROR) return fail(VS_EINVAL, "zlib: deflate failed (%d)", zr);
+                        if (zs.avail_in == 0 && zs.avail_out != 0 && flush != Z_FINISH) break;
+                    }
+                } while (n);
+                return VS_OK;
+            };
+            int rc = feed(head.data(), head.size(), payload_bytes == 0);
+            if (rc == VS_OK && payload_bytes) rc = feed(payload, payload_bytes, 1);
+            deflateEnd(&zs);
+            if (rc != VS_OK) return rc;
+            comp.resize((size_t)produced);
+        }
+        Entry e{name, crc, deflate_it ? (uint64_t)comp.size() : size, size, pos, (uint16_t)(deflate_it ? 8 : 0)};
+        const bool z64 = e.size >= 0xFFFFFFFFull || e.comp >= 0xFFFFFFFFull;
+        std::vector<unsigned char> lh;
+        w32(lh, 0x04034b50u); w16(lh, z64 ? 45 : 20); w16(lh, 0); w16(lh, e.method); w16(lh, 0); w16(lh, 0x21);   // (fixed DOS date 1980-01-01)
+        w32(lh, e.crc); w32(lh, z64 ? 0xFFFFFFFFu : (uint32_t)e.comp); w32(lh, z64 ? 0xFFFFFFFFu : (uint32_t)e.size);
+        w16(lh, (uint16_t)name.size()); w16(lh, z64 ? 20 : 0);
+        lh.insert(lh.end(), name.begin(), name.end());
+        if (z64) { w16(lh, 0x0001); w16(lh, 16); w64(lh, e.size); w64(lh, e.comp); }
+        VS_TRY(put(lh.data(), lh.size()));
+        if (deflate_it) VS_TRY(put(comp.data(), comp.size()));
+        else { VS_TRY(put(head.data(), head.size())); VS_TRY(put(payload, (size_t)payload_bytes)); }
+        entries.push_back(e);
+        return VS_OK;
+    }
+    int finish() {
+        const uint64_t cd_off = pos;
+        std::vector<unsigned char> cd;
+        for (const Entry& e : entries) {
+            const bool z64 = e.size >= 0xFFFFFFFFull || e.comp >= 0xFFFFFFFFull || e.off >= 0xFFFFFFFFull;
+            w32(cd, 0x02014b50u); w16(cd, 45); w16(cd, z64 ? 45 : 20); w16(cd, 0); w16(cd, e.method); w16(cd, 0); w16(cd, 0x21);
+            w32(cd, e.crc); w32(cd, z64 ? 0xFFFFFFFFu : (uint32_t)e.comp); w32(cd, z64 ? 0xFFFFFFFFu : (uint32_t)e.size);
+            w16(cd, (uint16_t)e.name.size()); w16(cd, z64 ? 28 : 0); w16(cd, 0); w16(cd, 0); w16(cd, 0); w32(cd, 0);
+            w32(cd, z64 ? 0xFFFFFFFFu : (uint32_t)e.off);
+            cd.insert(cd.end(), e.name.begin(), e.name.end());
+            if (z64) { w16(cd, 0x0001); w16(cd, 24); w64(cd, e.size); w64(cd, e.comp); w64(cd, e.off); }
+        }
+        VS_TRY(put(cd.data(), cd.size()));
+        const uint64_t cd_size = cd.size();
+        std::vector<unsigned char> tail;
+        if (cd_off >= 0xFFFFFFFFull || cd_size >= 0xFFFFFFFFull) {
+            const uint64_t e64 = pos;
+            w32(tail, 0x06064b50u); w64(tail, 44); w16(tail, 45); w16(tail, 45); w32(tail, 0); w32(tail, 0);
+            w64(tail, entries.size()); w64(tail, entries.size()); w64(tail, cd_size); w64(tail, cd_off);
+            w32(tail, 0x07064b50u); w32(tail, 0); w64(tail, e64); w32(tail, 1);
+        }
+        w32(tail, 0x06054b50u); w16(tail, 0); w16(tail, 0); w16(tail, (uint16_t)entries.size()); w16(tail, (uint16_t)entries.size());
+        w32(tail, cd_size >= 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cd_size); w32(tail, cd_off >= 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cd_off);
+        w16(tail, 0);
+        VS_TRY(put(tail.data(), tail.size()));
+        if (fflush(f) != 0) return fail(VS_EINVAL, "zip: flush failed");
+        return VS_OK;
+    }
+};
+
+std::vector<char> npy_header(const char* descr, const std::vector<int64_t>& shape) {
+    std::string d = std::string("{'descr': '") + descr + "', 'fortran_order': False, 'shape': (";
+    for (size_t i = 0; i < shape.size(); ++i) d += std::to_string(shape[i]) + (shape.size() == 1 ? "," : (i + 1 < shape.size() ? ", " : ""));
+    d += "), }";
+    size_t total = 10 + d.size() + 1;
+    const size_t pad = (64 - total % 64) % 64;
+    d.append(pad, ' ');
+    d.push_back('\n');
+    std::vector<char> h;
+    const char magic[8] = {'\x93', 'N', 'U', 'M', 'P', 'Y', 1, 0};
+    h.insert(h.end(), magic, magic + 8);
+    h.push_back((char)(d.size() & 0xFF));
+    h.push_back((char)(d.size() >> 8));
+    h.insert(h.end(), d.begin(), d.end());
+    return h;
+}
+
+}  // namespace
+}  // namespace vs
+
+// the index as a scipy.sparse.save_npz file (CSR; int64 indptr / indices like the reference's torch CSR, fp32 data; a binary
+// index writes data == 1): scipy.sparse.load_npz reads it back.  compressed = 0: stored members (fast), 1: deflate level 1.
+extern "C" int vs_index_save_npz(const vs_index* idx, const char* path, int compressed) {
+    if (!idx || !path) return fail(VS_EINVAL, "NULL argument");
+    if (idx->kind != VS_KIND_CSR) return fail(VS_EINVAL, "not a CSR index");
+    std::vector<int64_t> rp((size_t)idx->n_rows + 1);
+    VS_TRY(vs_index_export_csr(idx, rp.data(), nullptr, nullptr, VS_F32));
+    const int64_t nnz = rp[(size_t)idx->n_rows];
+    std::vector<int64_t> ci((size_t)std::max<int64_t>(nnz, 1));
+    std::vector<float> va((size_t)std::max<int64_t>(nnz, 1), 1.f);
+    VS_TRY(vs_index_export_csr(idx, rp.data(), ci.data(), idx->store_dtype == VS_NONE ? nullptr : (void*)va.data(), VS_F32));
+    ZipWriter zw;
+    zw.f = fopen(path, "wb");
+    if (!zw.f) return fail(VS_EINVAL, "cannot create %s", path);
+    const bool z = compressed != 0;
+    const int64_t shape[2] = {idx->n_rows, idx->n_cols};
+    VS_TRY(zw.add("indices.npy", npy_header("<i8", {nnz}), ci.data(), (uint64_t)nnz * 8, z));
+    VS_TRY(zw.add("indptr.npy", npy_header("<i8", {idx->n_rows + 1}), rp.data(), (uint64_t)(idx->n_rows + 1) * 8, z));
+    VS_TRY(zw.add("format.npy", npy_header("|S3", {}), "csr", 3, z));
+    VS_TRY(zw.add("shape.npy", npy_header("<i8", {2}), shape, 16, z));
+    VS_TRY(zw.add("data.npy", npy_header("<f4", {nnz}), va.data(), (uint64_t)nnz * 4, z));
+    const unsigned char yes = 1;                                  // scipy >= 1.11 marks sparse ARRAYS (the facade holds a csr_array, like the
+    VS_TRY(zw.add("_is_array.npy", npy_header("|b1", {}), &yes, 1, z));      // reference's save path under the pinned scipy: tests/golden/save_load.npz)
+    return zw.finish();
+}

@@ -117,6 +117,10 @@ class DeviceIndex:
         ids moved down by `shift`, sorted within a row.  NotImplementedError for non-CSR files."""
         nat.check(nat.lib().vs_index_append_npz(self._h, str(path).encode(), int(shift)))
 
+    def save_npz(self, path: str, compressed: bool = False):
+        """Write the index as a scipy.sparse.save_npz file (CSR, int64 ids, fp32 data) without scipy."""
+        nat.check(nat.lib().vs_index_save_npz(self._h, str(path).encode(), 1 if compressed else 0))
+
     def save_native(self, path: str):
         """Write the device format verbatim (.vsx shard file)."""
         nat.check(nat.lib().vs_index_save_native(self._h, str(path).encode()))

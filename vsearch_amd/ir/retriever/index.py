@@ -363,9 +363,12 @@ class SparseIndex(Index):
         try:
             # values go to disk as float32: scipy.sparse has no float16, and the loader re-applies fp16 (fp16=True)
             if self._dev is not None:
-                indptr, indices, data = self._dev.export_csr(np.float32)
-                info = self._dev.info()
-                shape = (info.n_rows, info.n_cols)
+                # written by the library (csrc/npz.hip): the same keys / dtypes scipy.sparse.save_npz writes for the reference's
+                # int64 torch CSR, stored (uncompressed) members; numpy's savez appends ".npz" to a bare name, so does this
+                target = str(path) if str(path).endswith(".npz") else str(path) + ".npz"
+                self._dev.save_npz(target, compressed=False)
+                logger.info("Index successfully saved to %s", target)
+                return
             else:
                 ip, ix, d, shape = self._csr_parts(self._vector)
                 indptr, indices, data = ip.cpu().numpy(), ix.cpu().numpy(), d.float().cpu().numpy()
