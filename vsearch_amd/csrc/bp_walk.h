@@ -26,7 +26,17 @@
 //           less than one unit, so  |S * exact - A| < n  (n = matched terms) bounds the exact fp64 sum by the approximate one.
 //           The walk then FILTERS: it returns the K' > k best documents by approximate score; refine_topk_kernel (bp_refine.h)
 //           re-scores exactly those with the exact numerics and proves, per query, that no other document can reach the top k;
-//           queries it cannot prove are re-run on the AM_F64 walk.
+//           queries it cannot prove take the exact one-query CSR scan (exact_scan_topk_kernel).
+//
+// How a block is walked (bp_walk_topk): the tile's (column, slot, weight) entries, sorted by column, are cut into CHUNKS of one
+// wave-slot each (8 lane groups x NB lists); a wave takes its first chunk by number and the following ones from a counter in LDS.
+// A lane group loads one record per lane for each of its NB lists back to back (asm: global_load + per-list s_waitcnt), plus
+// the second record a lane owes to the first of its lists that is longer than one round, then multiplies (v_fma_mix_f32: fp16
+// value x fp32 weight), truncates and adds (ds_add_u32).  Directory words are fetched one chunk ahead.  With head columns
+// (dense fp16 strips in MFMA operand order, bp_strip_index) the same queue also deals DENSE chunks: 64 documents x all head
+// columns on v_mfma_f32_16x16x32_f16 against the tile's weights split in two fp16 numbers.  After the block's barrier a thread
+// turns its two documents' sums into order keys and candidates; thresholds are shared between all work items of a query (gtau).
+// What binds and what was tried: DESIGN.md 4 / 8.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
