@@ -545,8 +545,11 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
         // (short binary lists: one or two slots per block, the directory latency would be exposed once per block; with the long
         //  lists of a valued index the pairs are fetched at block start -- holding them across the epilogue costs more than it hides)
         constexpr bool kPairsAhead = LG == 1;
-        lap(0);
-        if (kPairsAhead && b0 < b1) first_pairs(b0, wv_id);          // (binary index: no dense chunks, chunk = list chunk)
+        // ... and for the headless valued kernels too since the waves take chunks dynamically (B = 16 at 21 M docs: -4 %, B = 1024:
+        // -0.3 %; before, with static dealing, holding the words across the epilogue cost more than it hid).  Not with dense chunks:
+        // there the kind of a wave's first chunk depends on the block.
+        const bool pairs_ahead = kPairsAhead || HD == 0;
+        if (pairs_ahead && b0 < b1) first_pairs(b0, wv_id);          // (no dense chunks: chunk = list chunk)
         for (int64_t b = b0; b < b1 || b == b0; ++b) {
             const bool have = b < b1;
             const int rows_b = have ? (int)min((int64_t)a.rows, a.n_rows - b * a.rows) : 0;
@@ -630,7 +633,7 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
                 };
                 const int par = (int)(b & 1);
                 int cur = wv_id, nxt = grab(par);
-                if (!kPairsAhead) first_pairs(b, list_index(cur));
+                if (!pairs_ahead) first_pairs(b, list_index(cur));
                 while (cur < n_ch) {
                     const int li = list_index(cur), li_n = list_index(nxt);
                     uint32_t cd[OWN];
@@ -765,7 +768,7 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
                         }
                     }
                 }
-                if (kPairsAhead && b + 1 < b1) first_pairs(b + 1, wv_id);
+                if (pairs_ahead && b + 1 < b1) first_pairs(b + 1, wv_id);
             }
             // thresholds other items of the same queries have published meanwhile (read before the barrier: the latency hides in it)
             if (a.gtau && tid < nq) { const unsigned long long g = a.gtau[q0 + tid]; if (g > tau[tid]) tau[tid] = g; }
