@@ -309,6 +309,7 @@ struct BpArgs {
     uint64_t* cand;           // [B, nchunk, k] output keys, sorted descending
     uint64_t* gcand;          // [grid, QT, kBpCap] scratch
     const uint64_t* upper;    // optional [B] exclusive upper bounds ("search after")
+    const unsigned long long* df;   // optional [n_cols]: non-zeros of every column over the whole index (list-length classes of the entry sort)
     unsigned long long* gtau; // optional [B], zeroed per search: the best K-th key any (tile, chunk) item has established for the query --
                               // a lower bound of the K-th best over all chunks, shared so that no item starts (or stays) cold
     const float* qscale;      // AM_FIX: [B] per-query power-of-two scale of the fixed-point sums
@@ -492,7 +493,19 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
                         hw[qs * ldb + hx] = hi;
                         hw[(8 + qs) * ldb + hx] = (_Float16)(ws - (float)hi);
                     }
-                    else key = ((uint64_t)col << 40) | ((uint64_t)qs << 32) | (uint64_t)__float_as_uint(w);
+                    else {
+                        // Lists of similar length are dealt together: the sort key leads with a length class (rounds of the group's
+                        // LG x 8 postings an average block's list of this column takes: 1, 2, 3-4, 5-8, more), so a chunk's lists
+                        // finish their rounds together instead of one long list keeping a lane group's slot alone (skewed
+                        // vocabularies; a uniform corpus has one class).  Within a class the entries stay sorted by column.
+                        uint32_t cls = 0;
+                        if (a.df) {
+                            const float per_block = (float)a.df[col] * (float)a.rows / (float)max(a.n_rows, (int64_t)1);
+                            const float rounds = per_block * (1.f / (8.f * LG));
+                            cls = rounds <= 1.f ? 0u : rounds <= 2.f ? 1u : rounds <= 4.f ? 2u : rounds <= 8.f ? 3u : 4u;
+                        }
+                        key = ((uint64_t)cls << 56) | ((uint64_t)col << 40) | ((uint64_t)qs << 32) | (uint64_t)__float_as_uint(w);
+                    }
                 }
                 skey[i] = key;
             }
@@ -508,7 +521,7 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
             }
             for (int i = tid; i < n_ent; i += kScanThreads) {
                 const uint64_t key = skey[i];
-                ent[i] = make_uint2((uint32_t)(key >> 40) | ((uint32_t)((key >> 32) & 0xFFu) * (uint32_t)sizeof(acc_t) << 16), (uint32_t)key);
+                ent[i] = make_uint2(((uint32_t)(key >> 40) & 0xFFFFu) | ((uint32_t)((key >> 32) & 0xFFu) * (uint32_t)sizeof(acc_t) << 16), (uint32_t)key);
             }
             __syncthreads();
         }

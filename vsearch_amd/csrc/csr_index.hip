@@ -1040,6 +1040,7 @@ int bp_filter_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64
     a.gcand = idx->ws_mq_cand.as<uint64_t>();
     a.qscale = qscale;
     a.gtau = gtau;
+    a.df = idx->bp_df.p ? idx->bp_df.as<unsigned long long>() + V : nullptr;          // (second half of bp_df: non-zeros per column)
     a.hmap = idx->bp_n_head > 0 ? idx->bp_hmap.as<uint16_t>() : nullptr;
     a.strip = idx->bp_strip.as<__half>();
     a.n_head = idx->bp_n_head;
