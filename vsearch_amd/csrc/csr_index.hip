@@ -933,15 +933,18 @@ int32_t bp_head_slack(const vs_index* idx) {
 // chunks of the postings walk for `n_tiles` query tiles (see bp_filter_search)
 int bp_choose_chunks(const vs_index* idx, int n_tiles, int64_t n_blocks, int plan_nchunk) {
     int nchunk = (int)std::min<int64_t>(choose_chunks(idx, n_tiles, plan_nchunk), n_blocks);
-    // Big index, enough tiles: as FEW chunks as give every CU two work items.  Every tile sweeps its chunk's blocks in the same
+    // Big index, enough tiles: as FEW chunks as give every CU ONE work item.  Every tile sweeps its chunk's blocks in the same
     // order at the same pace, so with few chunks all tiles are within a few blocks of each other and each block is fetched from
-    // HBM once for all of them (Infinity Cache): 21 M docs, 1024 queries, walk time: 2 chunks 203 .. 233 ms (one item per CU,
-    // no second round to even out), 4: 207, 8: 227.  The binary index (short lists, request-bound) is steady at one item per
-    // CU: 2 chunks 63.5 ms, 4: 64.9, 8: 68.1.
+    // HBM once for all of them (Infinity Cache); and every item pays its start-up (entry sort, the candidate flood until its
+    // threshold rises) once.  21 M docs, 1024 queries, walk time: 2 chunks 159.0 ms (5 of 6 fresh processes; 167.3 in the sixth),
+    // 4 chunks 169.4, 3 chunks (384 items on 256 CUs) 328.  (Before the waves took their chunks of a block dynamically, one item
+    // per CU was unstable: 203 .. 233 ms against 207 at two per CU.)  Binary index: 2 chunks 63.5 ms, 4: 64.9, 8: 68.1.
     if (idx->n_rows >= (2 << 20) && (int64_t)n_tiles * 4 >= idx->cu_count) {
         int best = 1;
         double best_eff = 0.0;
-        const int per_cu = idx->store_dtype == VS_NONE ? 1 : 2;
+        // (a skewed corpus -- one with head columns -- keeps two items per CU: its tiles differ in weight, and with one item
+        //  each the heaviest tile's CU finishes alone: zipf 21 M docs 441 ms against 289)
+        const int per_cu = idx->bp_n_head > 0 ? 2 : 1;
         const int c0 = (int)std::max<int64_t>(1, ceil_div64(per_cu * (int64_t)idx->cu_count, n_tiles));
         for (int c = c0; c <= c0 + 3; ++c) {
             const int64_t it = (int64_t)n_tiles * c;
