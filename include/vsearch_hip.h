@@ -182,7 +182,7 @@ VS_API int  vs_index_set_queries_per_pass(vs_index* index, int qt);
  *   "blocked_postings"  -1 = auto (long-row valued indexes, when HBM has room for the second copy), 0 = off, 1 = on:
  *                       sparse queries are scored from a row-blocked, column-grouped copy of the index that is built on
  *                       first use -- a query tile reads only the posting lists of its own columns
- *   "postings_rows"     0 = auto (a column's list in a block averages ~20 postings), else documents per block of the copy
+  *   "postings_rows"     0 = auto (a column's list in a block averages ~50 postings, at most 2048 documents), else documents per block of the copy
  *   "postings_chunks"   0 = auto, else the number of block runs the postings scan cuts the index into (work items = tiles x runs)
  *   "postings_filter"   1 (default) = the postings walk accumulates int32 fixed-point sums (3.4x the LDS atomic rate of fp64 on
  *                       MI355X) and returns k + max(28, k/4) candidates per query, which are re-scored with the exact numerics

@@ -217,6 +217,7 @@ struct vs_index {
     vs::DevBuf bp_vmax;  // [2] uint32: float bits of max |value| (bounds the fixed-point walk's products), any-value-negative flag
     int bp_lanes = 0;    // option "postings_lanes": lanes per posting list of a valued index (4 | 8, auto = 8); binary index: records in flight per lane (auto = 8)
     bool bp_force_fb = false;   // option "postings_force_fallback" (tests)
+    int bp_rows_forced = 0;  // bp_build restarting itself with this block size (skewed corpus found): consumed by the next bp_build
     int bp_al_shift = 0;     // lists of the copy start on a multiple of 2^bp_al_shift records (bp_walk.h)
     int bp_align_pref = -1;  // option "postings_align": -1 auto (= 0), 0 = packed lists, 1 = lists start on whole 128-byte lines
     bool bp_quant = false;   // the records of this fp32 index hold fp16-rounded values (lossy filter copy, bp_refine.h)

@@ -780,10 +780,19 @@ int launch_bp_walk(const vs_index* idx, const BpArgs& a, int grid, int ent_cap, 
 int bp_build(vs_index* idx, hipStream_t s) {
     idx->bp_tried = true;
     bp_release(idx);
-    // documents per block: as many as the filter walk's accumulators hold -- the longer a column's list in a block, the more of
-    // every 128-byte line the walk fetches is used (768-nnz documents, V = 29 523: 53 postings = 6.7 records per list)
-    idx->bp_rows = idx->store_dtype == VS_NONE ? (idx->bp_rows_pref > 0 ? idx->bp_rows_pref : kBpRowsMaxBin)
-                                               : (idx->bp_rows_pref > 0 ? std::min(idx->bp_rows_pref, kBpRowsMax) : kBpRowsMax);
+    // Documents per block.  Valued index: as many as give an average list ~50 postings (768-nnz documents, V = 29 523: 1920) --
+    // a list is read by 8 lanes x 8 postings per round, and at 53 postings a list (2048 documents) 1 list in 15 needs a second
+    // record per lane, at 50 (1920) 1 in 40: 152.2 vs 158.7 ms at 21 M docs (1792: 156.1) -- capped by what the accumulators
+    // hold (2048) and kept a multiple of 128 (dense strips).  Binary index: 2048.
+    auto auto_rows = [&]() -> int {
+        if (idx->store_dtype == VS_NONE) return kBpRowsMaxBin;
+        const double avg = idx->n_rows > 0 ? (double)idx->nnz / (double)idx->n_rows : 1.0;
+        const int r = (int)(50.0 * (double)idx->n_cols / std::max(avg, 1.0)) / 128 * 128;
+        return std::max(256, std::min(r, kBpRowsMax));
+    };
+    idx->bp_rows = idx->bp_rows_pref > 0 ? std::min(idx->bp_rows_pref, idx->store_dtype == VS_NONE ? kBpRowsMaxBin : kBpRowsMax)
+                   : idx->bp_rows_forced > 0 ? idx->bp_rows_forced : auto_rows();
+    idx->bp_rows_forced = 0;
     const int64_t n_blocks = ceil_div64(idx->n_rows, idx->bp_rows);
     const int V = idx->n_cols;
     const int RS0 = bp_rec_bytes(idx->store_dtype == VS_F32 ? VM_F16 : idx->store_dtype == VS_F16 ? VM_F16 : VM_BIN);   // smallest record this index can get
@@ -853,6 +862,12 @@ int bp_build(vs_index* idx, hipStream_t s) {
         VS_HIP(hipMemcpyAsync(&h_n, nh.p, 4, hipMemcpyDeviceToHost, s));
         VS_HIP(hipStreamSynchronize(s));
         idx->bp_n_head = h_n;
+        if (h_n > 0 && idx->bp_rows_pref <= 0 && idx->bp_rows < kBpRowsMax) {
+            // a skewed corpus: its lists are long whatever the block size, and the dense strips and the per-block costs want the
+            // largest blocks (zipf 21 M docs: 289 ms at 2048 documents per block, 301 at 1920) -- start over with those
+            idx->bp_rows_forced = kBpRowsMax;
+            return bp_build(idx, s);
+        }
         if (h_n > 0) {
             // the directory again, without the head columns' lists
             VS_HIP(hipMemsetAsync(idx->bp_df.p, 0, (size_t)V * 16, s));
