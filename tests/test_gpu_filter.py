@@ -25,7 +25,8 @@ def _search(idx, q, k, **opts):
 
 
 def _modes(idx, q, k, want_quant, tied_queries=0):
-    """-> results of {csr scan, filter, filter on exact records, forced fallback x 2, fp64 walk}; checks paths and bit-equality."""
+    """-> results of {csr scan, filter, filter on exact records, forced fallback x 2, filter on the flat walk (bp_flat.h) x 2,
+    fp64 walk}; checks paths and bit-equality."""
     ref_ids, ref_sc, info = _search(idx, q, k, blocked_postings=0)
     assert info.last_path == 1
     out = {}
@@ -33,7 +34,9 @@ def _modes(idx, q, k, want_quant, tied_queries=0):
                        ("filter-exact-records", dict(postings_filter=1, postings_quant=0, postings_force_fallback=0)),
                        ("fallback", dict(postings_filter=1, postings_quant=-1, postings_force_fallback=1)),
                        ("fallback-exact-records", dict(postings_filter=1, postings_quant=0, postings_force_fallback=1)),
-                       ("fp64-walk", dict(postings_filter=0, postings_force_fallback=0))]:
+                       ("filter-flat-walk", dict(postings_filter=1, postings_quant=-1, postings_force_fallback=0, postings_walk=1)),
+                       ("filter-flat-walk-exact-records", dict(postings_filter=1, postings_quant=0, postings_force_fallback=0, postings_walk=1)),
+                       ("fp64-walk", dict(postings_filter=0, postings_force_fallback=0, postings_walk=-1))]:
         ids, sc, info = _search(idx, q, k, blocked_postings=1, **opts)
         if name == "fp64-walk":
             assert info.last_path == 2
@@ -45,6 +48,7 @@ def _modes(idx, q, k, want_quant, tied_queries=0):
     idx.set_option("postings_force_fallback", 0)
     idx.set_option("postings_quant", -1)
     idx.set_option("postings_filter", 1)
+    idx.set_option("postings_walk", -1)
     return ref_ids, ref_sc
 
 

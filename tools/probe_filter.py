@@ -20,6 +20,7 @@ q = torch.from_numpy(oracle.synth_queries(1, B)).cuda()
 res = {}
 idx.set_option("postings_lanes", lanes)
 idx.set_option("postings_align", align)
+idx.set_option("postings_walk", int(os.environ.get("VS_PROBE_WALK", "-1")))
 for mode, chunks in [(m, c) for m in modes for c in (chunk_list if m != "csr" else [0])]:
     idx.set_option("postings_chunks", chunks)
     idx.set_option("blocked_postings", 0 if mode == "csr" else 1)

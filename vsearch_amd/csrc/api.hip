@@ -127,6 +127,11 @@ extern "C" int vs_index_set_option(vs_index* idx, const char* name, int value) {
         idx->bp_lanes = value;
         return VS_OK;
     }
+    if (n == "postings_walk") {
+        if (value < -1 || value > 1) return fail(VS_EINVAL, "postings_walk: -1 = auto, 0 = a list per lane group, 1 = flat worklists");
+        idx->bp_walk_pref = value;
+        return VS_OK;
+    }
     if (n == "mq_variant") {
         if (value < -1 || value > 1) return fail(VS_EINVAL, "mq_variant: -1 = auto, 0 = plain, 1 = shared columns");
         idx->mq_variant = value;

@@ -265,6 +265,17 @@ __global__ __launch_bounds__(kScanThreads) void bp_fill_kernel(const uint32_t* p
                 const uint32_t lim = (((d[i] >> 12) << al_shift) + (d[i] & kBpDirRecMask)) * 8u;
                 for (uint32_t pos = cur[i]; pos < lim; ++pos) reinterpret_cast<uint16_t*>(brec + (size_t)(pos >> 3) * RS)[pos & 7u] = (uint16_t)kBpRowsMaxBin;
             }
+        } else {
+            // pad postings of a valued list carry value 0 (the array was zero-filled): they add nothing WHEREVER they point, so
+            // they point at scattered documents of the block -- all on document 0, the pads of a wave's ds_add pile up on one
+            // LDS bank (slot-major accumulators, bp_flat.h: every slot's document 0 is bank 0)
+            __syncthreads();
+            const uint32_t nb = (uint32_t)(r1 - r0);
+            for (int i = tid; i < n_cols; i += kScanThreads) {
+                const uint32_t lim = (((d[i] >> 12) << al_shift) + (d[i] & kBpDirRecMask)) * 8u;
+                for (uint32_t pos = cur[i]; pos < lim; ++pos)
+                    reinterpret_cast<uint16_t*>(brec + (size_t)(pos >> 3) * RS)[pos & 7u] = (uint16_t)(((uint32_t)i * 2654435761u + pos * 40503u) % nb);
+            }
         }
     }
 }

@@ -236,6 +236,8 @@ struct vs_index {
     int bp_pref = -1;    // option "blocked_postings": -1 auto, 0 never, 1 always
     int bp_rows_pref = 0;// option "postings_rows": 0 = auto, else documents per block (multiple of 64, 256..2048); applies at the next build
     int bp_chunks = 0;   // option "postings_chunks": 0 = auto, else block runs per tile on the postings path
+    int bp_walk_pref = -1;   // option "postings_walk": -1 auto (= 0 until the flat walk wins), 0 = one list per lane group (bp_walk.h), 1 = flat worklists (bp_flat.h)
+    int64_t bp_max_block_recs = 0;   // records of the fullest block (the flat walk's items address 2^19)
     int mq_variant = -1; // option "mq_variant": -1 auto (from the batch's query overlap), 0 plain, 1 shared columns
     // dense
     vs::DevBuf mat;      // [n_rows, n_cols] store_dtype

@@ -5,6 +5,7 @@
 #include "csr_scan_mq.h"
 #include "bp_walk.h"
 #include "bp_refine.h"
+#include "bp_flat.h"
 #include "synth_device.h"
 
 #include <algorithm>
@@ -749,12 +750,22 @@ void bp_release(vs_index* idx) {
 
 // valued index: QT queries per tile, blocks of <= 2048 documents (exact fp64 walk: QT = 4, filter walk: QT = 8);
 // binary index: filter walk only, one lane per (short) list
+constexpr int kFlRoundsF16 = 8, kFlRoundsF32 = 5;     // record loads in flight per lane (registers: 8 / 12 per record)
+template <int AM>
+bool bp_flat_ok(const vs_index* idx, const BpArgs& a) {
+    return AM == AM_FIX && idx->store_dtype != VS_NONE && a.n_head == 0 && idx->bp_walk_pref == 1 && !a.upper &&
+           idx->bp_max_block_recs < ((int64_t)1 << kFlRecBits) - 4096;
+}
 template <int QT, int AM>
 int launch_bp_walk(const vs_index* idx, const BpArgs& a, int grid, int ent_cap, hipStream_t s) {
     const int vm = bp_record_vm(idx);
     size_t lds = bp_lds_bytes<QT, AM, kBpRowsMax>(ent_cap, AM == AM_FIX ? a.n_head : 0);
     void (*kern)(BpArgs) = nullptr;
-    if (vm == VM_BIN) {
+    if (bp_flat_ok<AM>(idx, a)) {
+        // valued records, no dense strips, fixed-point filter: the flat walk (bp_flat.h)
+        if (vm == VM_F32) { kern = bp_flat_topk<VM_F32, kFlRoundsF32, kBpRowsMax>; lds = bp_flat_lds_bytes<kFlRoundsF32, kBpRowsMax>(ent_cap); }
+        else { kern = bp_flat_topk<VM_F16, kFlRoundsF16, kBpRowsMax>; lds = bp_flat_lds_bytes<kFlRoundsF16, kBpRowsMax>(ent_cap); }
+    } else if (vm == VM_BIN) {
         if (AM != AM_FIX) return fail(VS_EUNSUPPORTED, "binary postings serve the filter walk only");
         // one lane per list; the option picks the records in flight per lane = the size of the chunks dealt to the waves (8: 512
         // entries, 13 chunks a block on the Wiki21M shape, 16.4 k q/s; 4: 25 chunks for 16 waves, 13.0 k)
@@ -890,7 +901,11 @@ int bp_build(vs_index* idx, hipStream_t s) {
     int32_t h_ovf = 0;
     VS_HIP(hipMemcpyAsync(&n_rec, idx->bp_base.as<unsigned long long>() + n_blocks, 8, hipMemcpyDeviceToHost, s));
     VS_HIP(hipMemcpyAsync(&h_ovf, ovf.p, 4, hipMemcpyDeviceToHost, s));
+    std::vector<uint32_t> h_brecs((size_t)n_blocks);
+    VS_HIP(hipMemcpyAsync(h_brecs.data(), block_recs.p, (size_t)n_blocks * 4, hipMemcpyDeviceToHost, s));
     VS_HIP(hipStreamSynchronize(s));
+    idx->bp_max_block_recs = 0;
+    for (uint32_t r : h_brecs) idx->bp_max_block_recs = std::max<int64_t>(idx->bp_max_block_recs, (int64_t)r);
     if (h_ovf) {                                                        // (2048 documents x 29 523 columns, all present, would do it)
         fprintf(stderr, "[vsearch_hip] blocked-postings copy not built: a block holds more records than a directory word addresses -- sparse queries use the CSR scan\n");
         bp_release(idx);
@@ -1034,7 +1049,7 @@ int bp_filter_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64
     const int nchunk = bp_choose_chunks(idx, n_tiles_est, n_blocks, plan.nchunk);
     const int nchunk_fb = (int)std::min<int64_t>(n_blocks, 64);
     const int grid = (int)std::min<int64_t>((int64_t)B * nchunk, idx->cu_count);
-    VS_TRY(idx->ws_mq_cand.reserve((size_t)idx->cu_count * kQT * kBpCap * 8));
+    VS_TRY(idx->ws_mq_cand.reserve((size_t)idx->cu_count * kQT * std::max(kBpCap, kFlCap) * 8));
     VS_TRY(idx->ws_cand.reserve(std::max((size_t)B * nchunk * kp, (size_t)B * nchunk_fb * k) * 8));
     BpArgs a{};
     a.rows = idx->bp_rows;
@@ -1087,6 +1102,10 @@ int bp_filter_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64
         unsigned long long h[8] = {0};
         VS_HIP(hipMemcpyAsync(h, timing.p, 64, hipMemcpyDeviceToHost, s));
         VS_HIP(hipStreamSynchronize(s));
+        if (bp_flat_ok<AM_FIX>(idx, a)) {        // the flat walk has no dense part: slot 3 carries 100 MHz ticks
+            fprintf(stderr, "[vsearch_hip] flat walk: shader clock %.0f MHz\n", 100.0 * (double)(h[0] + h[1] + h[2] + h[4]) / (double)std::max<unsigned long long>(1, h[3]));
+            h[3] = 0;
+        }
         const double tot = (double)(h[0] + h[1] + h[2] + h[3] + h[4]);
         fprintf(stderr, "[vsearch_hip] walk wave-cycles: prologue %.1f %%, list walk %.1f %%, barrier wait %.1f %%, dense %.1f %%, epilogue %.1f %%; per block and wave: "
                         "walk %.0f wait %.0f dense %.0f epilogue %.0f cycles\n", 100.0 * h[0] / tot, 100.0 * h[1] / tot, 100.0 * h[2] / tot, 100.0 * h[3] / tot, 100.0 * h[4] / tot,
