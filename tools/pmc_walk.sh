@@ -9,7 +9,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 run() {
   name=$1; shift
-  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$name -- python3 $ROOT/tools/probe_filter.py $DOCS 1024 100 fp32 filter > $OUT/$name.log 2>&1
+  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$name -- python3 $ROOT/tools/probe_filter.py $DOCS ${VS_PMC_B:-1024} 100 fp32 filter > $OUT/$name.log 2>&1
 }
 ONLY=${3:-all}
 want() { [ "$ONLY" = all ] || echo ",$ONLY," | grep -q ",$1,"; }

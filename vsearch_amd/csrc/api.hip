@@ -128,8 +128,13 @@ extern "C" int vs_index_set_option(vs_index* idx, const char* name, int value) {
         return VS_OK;
     }
     if (n == "postings_walk") {
-        if (value < -1 || value > 1) return fail(VS_EINVAL, "postings_walk: -1 = auto, 0 = a list per lane group, 1 = flat worklists");
+        if (value < -1 || value > 2) return fail(VS_EINVAL, "postings_walk: -1 = auto, 0 = a list per lane group, 1 = flat worklists, 2 = pipelined flat walk");
         idx->bp_walk_pref = value;
+        return VS_OK;
+    }
+    if (n == "postings_pace") {
+        if (value < -1 || value > 4096) return fail(VS_EINVAL, "postings_pace: -1 = auto, 0 = free running, N = lock-step window in blocks");
+        idx->bp_pace = value;
         return VS_OK;
     }
     if (n == "mq_variant") {

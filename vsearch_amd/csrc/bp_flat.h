@@ -80,6 +80,8 @@ __global__ __launch_bounds__(kScanThreads) void bp_flat_topk(BpArgs a) {
     const int64_t items = (int64_t)(a.n_tiles_dev ? a.n_tiles_dev[0] : a.n_tiles) * a.nchunk;
     const size_t dir_ld = (size_t)a.n_cols + 1;
     constexpr int NW = kScanThreads / 64;
+    const unsigned long long k_rt0 = a.timing ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    const long long k_c0 = a.timing ? (long long)__builtin_readcyclecounter() : 0;
 
     for (int64_t item = blockIdx.x; item < items; item += gridDim.x) {
         const int tile = (int)(item / a.nchunk), c = (int)(item % a.nchunk);
@@ -263,6 +265,18 @@ __global__ __launch_bounds__(kScanThreads) void bp_flat_topk(BpArgs a) {
             // thresholds other items of the same queries have published meanwhile (read before the barrier: the latency hides in it)
             if (a.gtau && tid < nq) { const unsigned long long g = a.gtau[q0 + tid]; if (g > tau[tid]) tau[tid] = g; }
             lap(1);
+            // Lock step: every tile of this chunk sweeps the same blocks; held within `pace_window` blocks of the slowest, a block's
+            // records are fetched from HBM once for all of them (L2 / Infinity Cache).  Only when all items are resident (one per
+            // workgroup): a waiting item would otherwise wait for one that has not started.
+            if (a.pace && items <= (int64_t)gridDim.x && tid == 0 && have_b) {
+                uint32_t* pc = a.pace + (size_t)c * a.blocks_per_chunk;
+                const int64_t rel = b - b0;
+                __hip_atomic_fetch_add(pc + rel, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (rel >= a.pace_window) {
+                    const uint32_t need = (uint32_t)(items / a.nchunk);
+                    while (__hip_atomic_load(pc + rel - a.pace_window, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(8);
+                }
+            }
             __syncthreads();
             if (tid == 0) scratch[40 + (int)((b + 1) & 1)] = 0;     // the next block's chunk counter (its last user was block b - 1)
             lap(2);
@@ -336,6 +350,12 @@ __global__ __launch_bounds__(kScanThreads) void bp_flat_topk(BpArgs a) {
 #pragma unroll
             for (int i = 0; i < 6; ++i) atomicAdd(a.timing + i, (unsigned long long)tacc[i]);
         }
+    }
+    if (a.timing && tid == 0) {        // per workgroup: 100 MHz ticks, shader cycles, where it ran (XCC_ID, HW_ID)
+        a.timing[16 + 4 * blockIdx.x] = __builtin_amdgcn_s_memrealtime() - k_rt0;
+        a.timing[17 + 4 * blockIdx.x] = (unsigned long long)((long long)__builtin_readcyclecounter() - k_c0);
+        a.timing[18 + 4 * blockIdx.x] = (unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20);
+        a.timing[19 + 4 * blockIdx.x] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);
     }
 }
 

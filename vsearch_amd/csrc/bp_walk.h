@@ -328,6 +328,8 @@ struct BpArgs {
     const __half* strip;      // fp16 values of the head columns, MFMA operand order (bp_strip_index)
     int32_t n_head;
     float head_pre, head_mul; // powers of two: weights enter the fp16 operand as w * scale * head_pre (< 2^15), the sums leave as C * head_mul
+    uint32_t* pace;           // optional [nchunk][blocks_per_chunk], zeroed per search: work items that have finished a block (flat walk: lock-step window)
+    int32_t pace_window;      // blocks an item may run ahead of the slowest item of its chunk
     unsigned long long* timing;   // optional (VS_BP_TIMING=1): [8] wave-cycles per phase, summed over waves: 0 item prologue, 1 list walk,
                                   // 2 wait at the barrier after the walk, 3 dense part, 4 epilogue; [5] = blocks x waves
 };

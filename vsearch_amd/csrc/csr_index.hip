@@ -6,6 +6,7 @@
 #include "bp_walk.h"
 #include "bp_refine.h"
 #include "bp_flat.h"
+#include "bp_pipe.h"
 #include "synth_device.h"
 
 #include <algorithm>
@@ -751,17 +752,26 @@ void bp_release(vs_index* idx) {
 // valued index: QT queries per tile, blocks of <= 2048 documents (exact fp64 walk: QT = 4, filter walk: QT = 8);
 // binary index: filter walk only, one lane per (short) list
 constexpr int kFlRoundsF16 = 8, kFlRoundsF32 = 5;     // record loads in flight per lane (registers: 8 / 12 per record)
-template <int AM>
-bool bp_flat_ok(const vs_index* idx, const BpArgs& a) {
-    return AM == AM_FIX && idx->store_dtype != VS_NONE && a.n_head == 0 && idx->bp_walk_pref == 1 && !a.upper &&
-           idx->bp_max_block_recs < ((int64_t)1 << kFlRecBits) - 4096;
+// which walk serves the fixed-point filter of this index: 0 = a list per lane group (bp_walk.h), 1 = flat worklists (bp_flat.h),
+// 2 = flat worklists on two accumulator sets, no block barrier (bp_pipe.h)
+int bp_walk_kind(const vs_index* idx) {
+    const bool can = idx->store_dtype != VS_NONE && idx->bp_n_head == 0 && idx->bp_max_block_recs < ((int64_t)1 << kFlRecBits) - 4096;
+    if (!can) return 0;
+    return idx->bp_walk_pref < 0 ? 0 : idx->bp_walk_pref;
 }
+template <int AM>
+bool bp_flat_ok(const vs_index* idx, const BpArgs& a) { return AM == AM_FIX && !a.upper && bp_walk_kind(idx) >= 1; }
 template <int QT, int AM>
 int launch_bp_walk(const vs_index* idx, const BpArgs& a, int grid, int ent_cap, hipStream_t s) {
     const int vm = bp_record_vm(idx);
     size_t lds = bp_lds_bytes<QT, AM, kBpRowsMax>(ent_cap, AM == AM_FIX ? a.n_head : 0);
     void (*kern)(BpArgs) = nullptr;
-    if (bp_flat_ok<AM>(idx, a)) {
+    if (bp_flat_ok<AM>(idx, a) && bp_walk_kind(idx) == 2) {
+        if (ent_cap > kPipeEntCap) return fail(VS_EINVAL, "pipelined walk: %d entries per tile, %d fit", ent_cap, kPipeEntCap);
+        if (vm == VM_F32) kern = bp_pipe_topk<VM_F32, 5, kBpRowsMax>;
+        else kern = bp_pipe_topk<VM_F16, 7, kBpRowsMax>;
+        lds = bp_pipe_lds_bytes<kBpRowsMax>(ent_cap);
+    } else if (bp_flat_ok<AM>(idx, a)) {
         // valued records, no dense strips, fixed-point filter: the flat walk (bp_flat.h)
         if (vm == VM_F32) { kern = bp_flat_topk<VM_F32, kFlRoundsF32, kBpRowsMax>; lds = bp_flat_lds_bytes<kFlRoundsF32, kBpRowsMax>(ent_cap); }
         else { kern = bp_flat_topk<VM_F16, kFlRoundsF16, kBpRowsMax>; lds = bp_flat_lds_bytes<kFlRoundsF16, kBpRowsMax>(ent_cap); }
@@ -1002,9 +1012,9 @@ int bp_filter_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64
                      hipStream_t s, bool* done, int32_t out_ld) {
     const int V = idx->n_cols;
     const int kp = k + std::max(28, k / 4);
-    const int qt = idx->store_dtype == VS_NONE ? kBpBinQT : kQT;
+    const int qt = idx->store_dtype == VS_NONE ? kBpBinQT : (bp_walk_kind(idx) == 2 ? kPipeQT : kQT);
     // (dense strips: their weight matrix takes 16 KB of the LDS the entries would use)
-    const int vals_cap = std::min(mq_vals_cap(idx), idx->bp_n_head > 0 ? kBpEntCap - 512 : kBpEntCap);
+    const int vals_cap = std::min(mq_vals_cap(idx), bp_walk_kind(idx) == 2 ? kPipeEntCap : (idx->bp_n_head > 0 ? kBpEntCap - 512 : kBpEntCap));
     const int64_t qcap = (int64_t)B * vals_cap;                               // bound of the batch's (query, column) entries that enter a tile
     const int64_t n_blocks = ceil_div64(idx->n_rows, idx->bp_rows);
     if (idx->bp_rows > (idx->store_dtype == VS_NONE ? kBpRowsMaxBin : kBpRowsMax)) return fail(VS_EINVAL, "postings_rows beyond the walk's block capacity");
@@ -1087,11 +1097,19 @@ int bp_filter_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64
     idx->last_plan_dev = dplan;
     idx->last_plan_rs = bp_rec_bytes(bp_record_vm(idx));
     idx->last_plan_blocks = n_blocks;
+    static const int pace_env = getenv("VS_BP_PACE") ? atoi(getenv("VS_BP_PACE")) : -1;
+    const int pace_w = pace_env >= 0 ? pace_env : (idx->bp_pace >= 0 ? idx->bp_pace : (bp_walk_kind(idx) == 2 ? 8 : 0));
+    if (pace_w > 0 && bp_flat_ok<AM_FIX>(idx, a)) {
+        VS_TRY(idx->ws_pace.reserve((size_t)nchunk * a.blocks_per_chunk * 4));
+        VS_HIP(hipMemsetAsync(idx->ws_pace.p, 0, (size_t)nchunk * a.blocks_per_chunk * 4, s));
+        a.pace = idx->ws_pace.as<uint32_t>();
+        a.pace_window = pace_w;
+    }
     static const bool timing_on = getenv("VS_BP_TIMING") != nullptr;            // developer aid: where the walk's wave-cycles go
     DevBuf timing;
     if (timing_on) {
-        VS_TRY(timing.alloc(64));
-        VS_HIP(hipMemsetAsync(timing.p, 0, 64, s));
+        VS_TRY(timing.alloc(128 + (size_t)grid * 32));
+        VS_HIP(hipMemsetAsync(timing.p, 0, 128 + (size_t)grid * 32, s));
         a.timing = timing.as<unsigned long long>();
     }
     {
@@ -1099,9 +1117,40 @@ int bp_filter_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64
         VS_TRY((launch_bp_walk<kQT, AM_FIX>(idx, a, grid, vals_cap, s)));
     }
     if (timing_on) {
-        unsigned long long h[8] = {0};
-        VS_HIP(hipMemcpyAsync(h, timing.p, 64, hipMemcpyDeviceToHost, s));
+        unsigned long long h[16] = {0};
+        VS_HIP(hipMemcpyAsync(h, timing.p, 128, hipMemcpyDeviceToHost, s));
         VS_HIP(hipStreamSynchronize(s));
+        if (bp_flat_ok<AM_FIX>(idx, a)) {
+            std::vector<unsigned long long> wg((size_t)grid * 4);
+            VS_HIP(hipMemcpy(wg.data(), timing.as<unsigned long long>() + 16, wg.size() * 8, hipMemcpyDeviceToHost));
+            double tmin = 1e30, tmax = 0, tsum = 0;
+            double xs[8] = {0}, xc[8] = {0}, xn[8] = {0};
+            for (int i = 0; i < grid; ++i) {
+                const double t = (double)wg[4 * i] * 1e-5, cyc = (double)wg[4 * i + 1];       // ms
+                tmin = std::min(tmin, t); tmax = std::max(tmax, t); tsum += t;
+                const int x = (int)(wg[4 * i + 2] & 7);
+                xs[x] += t; xc[x] += cyc; xn[x] += 1;
+            }
+            fprintf(stderr, "[vsearch_hip] flat walk: workgroup time min %.2f mean %.2f max %.2f ms;", tmin, tsum / grid, tmax);
+            for (int x = 0; x < 8; ++x) if (xn[x] > 0) fprintf(stderr, " xcc%d: %d wgs %.2f ms %.0f MHz;", x, (int)xn[x], xs[x] / xn[x], xc[x] / xs[x] * 1e-3);
+            fprintf(stderr, "\n");
+            if (getenv("VS_BP_TIMING_WG")) {
+                std::vector<int> ord(grid);
+                for (int i = 0; i < grid; ++i) ord[i] = i;
+                std::sort(ord.begin(), ord.end(), [&](int x, int y) { return wg[4 * x] > wg[4 * y]; });
+                for (int j = 0; j < std::min(grid, 12); ++j) {
+                    const int i = ord[j];
+                    const unsigned hw = (unsigned)wg[4 * i + 3];
+                    fprintf(stderr, "   wg %3d: %.2f ms, %.1f Mcycles, xcc %d se %d sh %d cu %d simd %d\n", i, (double)wg[4 * i] * 1e-5, (double)wg[4 * i + 1] * 1e-6, (int)(wg[4 * i + 2] & 7),
+                            (hw >> 13) & 7, (hw >> 12) & 1, (hw >> 8) & 15, (hw >> 4) & 3);
+                }
+            }
+        }
+        if (bp_walk_kind(idx) == 2) {
+            const double bw = (double)std::max<unsigned long long>(1, h[5]);
+            fprintf(stderr, "[vsearch_hip] pipe walk chunk anatomy, wave-cycles per block and wave: produce %.0f, item round trip %.0f, first record %.0f, adds %.0f\n",
+                    (double)h[8] / bw, (double)h[9] / bw, (double)h[10] / bw, (double)h[11] / bw);
+        }
         if (bp_flat_ok<AM_FIX>(idx, a)) {        // the flat walk has no dense part: slot 3 carries 100 MHz ticks
             fprintf(stderr, "[vsearch_hip] flat walk: shader clock %.0f MHz\n", 100.0 * (double)(h[0] + h[1] + h[2] + h[4]) / (double)std::max<unsigned long long>(1, h[3]));
             h[3] = 0;
