@@ -38,6 +38,8 @@ def _modes(idx, q, k, want_quant, tied_queries=0):
                        ("filter-flat-walk-exact-records", dict(postings_filter=1, postings_quant=0, postings_force_fallback=0, postings_walk=1)),
                        ("filter-pipe-walk", dict(postings_filter=1, postings_quant=-1, postings_force_fallback=0, postings_walk=2)),
                        ("filter-pipe-walk-exact-records", dict(postings_filter=1, postings_quant=0, postings_force_fallback=0, postings_walk=2)),
+                       ("filter-stream-walk", dict(postings_filter=1, postings_quant=-1, postings_force_fallback=0, postings_walk=3)),
+                       ("filter-stream-walk-exact-records", dict(postings_filter=1, postings_quant=0, postings_force_fallback=0, postings_walk=3)),
                        ("fp64-walk", dict(postings_filter=0, postings_force_fallback=0, postings_walk=-1))]:
         ids, sc, info = _search(idx, q, k, blocked_postings=1, **opts)
         if name == "fp64-walk":

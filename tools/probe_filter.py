@@ -21,6 +21,7 @@ res = {}
 idx.set_option("postings_lanes", lanes)
 idx.set_option("postings_align", align)
 idx.set_option("postings_walk", int(os.environ.get("VS_PROBE_WALK", "-1")))
+idx.set_option("postings_arrange", int(os.environ.get("VS_PROBE_ARRANGE", "-1")))
 for mode, chunks in [(m, c) for m in modes for c in (chunk_list if m != "csr" else [0])]:
     idx.set_option("postings_chunks", chunks)
     idx.set_option("blocked_postings", 0 if mode == "csr" else 1)

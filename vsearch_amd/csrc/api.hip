@@ -128,8 +128,14 @@ extern "C" int vs_index_set_option(vs_index* idx, const char* name, int value) {
         return VS_OK;
     }
     if (n == "postings_walk") {
-        if (value < -1 || value > 2) return fail(VS_EINVAL, "postings_walk: -1 = auto, 0 = a list per lane group, 1 = flat worklists, 2 = pipelined flat walk");
+        if (value < -1 || value > 3) return fail(VS_EINVAL, "postings_walk: -1 = auto, 0 = a list per lane group, 1 = flat worklists, 2 = two accumulator sets, 3 = streamed flat walk");
         idx->bp_walk_pref = value;
+        return VS_OK;
+    }
+    if (n == "postings_arrange") {
+        if (value < -1 || value > 1) return fail(VS_EINVAL, "postings_arrange: -1 = auto (off), 0 = off, 1 = on");
+        if (value != idx->bp_arrange_pref) { idx->bp_dir.release(); idx->bp_base.release(); idx->bp_rec.release(); idx->bp_ready = false; idx->bp_tried = false; }
+        idx->bp_arrange_pref = value;
         return VS_OK;
     }
     if (n == "postings_pace") {

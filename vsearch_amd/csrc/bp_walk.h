@@ -280,6 +280,99 @@ __global__ __launch_bounds__(kScanThreads) void bp_fill_kernel(const uint32_t* p
     }
 }
 
+// pass 4 (valued records): bank-aware order INSIDE each list.  The walks give consecutive records of a list to consecutive lanes and
+// add posting t of every record in one ds_add_u32; a document's LDS bank is its id mod 32 (slot-major sums; 9 * id + slot mod 32 in
+// the padded layout of bp_walk_topk: the same classes).  Within a round of 8 records the 8 postings of position t are re-dealt so
+// that their documents fall into DIFFERENT banks (greedy: a posting goes to the first position whose column has a free record
+// and not yet its bank; 8 of 32 banks per column: it practically always finds one); pad postings (value 0) get documents of
+// unused banks.  The lanes of one list then never collide -- 23 % of the lane pairs of a 32-lane group: Monte Carlo of the
+// group's worst bank 3.27 -> 2.81 cycles.  Sums do not depend on the order of a list's postings.  One thread per list.
+template <int VM>
+__global__ __launch_bounds__(256) void bp_arrange_kernel(const uint32_t* dir, const unsigned long long* base, char* rec, int64_t n_blocks, int32_t n_cols,
+                                                         int32_t al_shift) {
+    static_assert(VM == VM_F16 || VM == VM_F32, "valued records");
+    constexpr int RS = bp_rec_bytes(VM);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint16_t* oid = reinterpret_cast<uint16_t*>(smem) + (size_t)threadIdx.x * 64;                               // [256][64] the re-dealt round
+    uint32_t* oval = reinterpret_cast<uint32_t*>(smem + 256 * 64 * 2) + (size_t)threadIdx.x * 64;               // [256][64] (fp16 bits or fp32 bits)
+    for (int64_t b = blockIdx.x; b < n_blocks; b += gridDim.x) {
+        const uint32_t* d = dir + (size_t)b * ((size_t)n_cols + 1);
+        char* brec = rec + (size_t)base[b] * RS;
+        for (int c = threadIdx.x; c < n_cols; c += 256) {
+            const uint32_t w = d[c];
+            const uint32_t first = (w >> 12) << al_shift, nrec = w & kBpDirRecMask;
+            for (uint32_t r0 = 0; r0 < nrec; r0 += 8) {
+                const int R = (int)min(8u, nrec - r0);
+                char* rp = brec + (size_t)(first + r0) * RS;
+                // greedy deal: column t = position in the record; its cells fill from record 0 up
+                uint32_t mask[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};      // banks taken in column t
+                uint32_t fill[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};      // cells taken in column t
+                int start = 0;
+                for (int j = 0; j < R; ++j) {
+                    const uint4 iw = *reinterpret_cast<const uint4*>(rp + (size_t)j * RS);
+                    const uint32_t iv[4] = {iw.x, iw.y, iw.z, iw.w};
+                    uint32_t vv[8];
+                    if constexpr (VM == VM_F16) {
+                        const uint4 vw = *reinterpret_cast<const uint4*>(rp + (size_t)j * RS + 16);
+                        const uint32_t v4[4] = {vw.x, vw.y, vw.z, vw.w};
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) vv[t] = (t & 1) ? (v4[t >> 1] >> 16) : (v4[t >> 1] & 0xFFFFu);
+                    } else {
+                        const uint4 v0 = *reinterpret_cast<const uint4*>(rp + (size_t)j * RS + 16), v1 = *reinterpret_cast<const uint4*>(rp + (size_t)j * RS + 32);
+                        vv[0] = v0.x; vv[1] = v0.y; vv[2] = v0.z; vv[3] = v0.w; vv[4] = v1.x; vv[5] = v1.y; vv[6] = v1.z; vv[7] = v1.w;
+                    }
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        const uint32_t v = vv[t];
+                        if ((v & (VM == VM_F16 ? 0x7FFFu : 0x7FFFFFFFu)) == 0u) continue;      // a pad (or an explicit zero: adds nothing either)
+                        const uint32_t id = (t & 1) ? (iv[t >> 1] >> 16) : (iv[t >> 1] & 0xFFFFu), bit = 1u << (id & 31u);
+                        int pick = -1, any = -1;
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            const int tt = (start + k) & 7;
+                            const bool room = fill[tt] < (uint32_t)R;
+                            if (room && any < 0) any = tt;
+                            if (room && pick < 0 && !(mask[tt] & bit)) pick = tt;
+                        }
+                        if (pick < 0) pick = any;                                              // (every free column holds the bank already: a conflict stays)
+                        oid[fill[pick] * 8 + pick] = (uint16_t)id;
+                        oval[fill[pick] * 8 + pick] = v;
+                        mask[pick] |= bit;
+                        ++fill[pick];
+                        start = (pick + 1) & 7;
+                    }
+                }
+                // pads: value 0, a document of a bank the column does not hold yet (documents 0 .. 31 exist in every block)
+                for (int t = 0; t < 8; ++t) {
+                    while (fill[t] < (uint32_t)R) {
+                        const uint32_t freeb = ~mask[t];
+                        const uint32_t bk = freeb ? (uint32_t)(__ffs((int)freeb) - 1) : 0u;
+                        oid[fill[t] * 8 + t] = (uint16_t)bk;
+                        oval[fill[t] * 8 + t] = 0u;
+                        mask[t] |= 1u << bk;
+                        ++fill[t];
+                    }
+                }
+                for (int j = 0; j < R; ++j) {
+                    uint4 iw;
+                    iw.x = oid[j * 8 + 0] | ((uint32_t)oid[j * 8 + 1] << 16); iw.y = oid[j * 8 + 2] | ((uint32_t)oid[j * 8 + 3] << 16);
+                    iw.z = oid[j * 8 + 4] | ((uint32_t)oid[j * 8 + 5] << 16); iw.w = oid[j * 8 + 6] | ((uint32_t)oid[j * 8 + 7] << 16);
+                    *reinterpret_cast<uint4*>(rp + (size_t)j * RS) = iw;
+                    if constexpr (VM == VM_F16) {
+                        uint4 vw;
+                        vw.x = oval[j * 8 + 0] | (oval[j * 8 + 1] << 16); vw.y = oval[j * 8 + 2] | (oval[j * 8 + 3] << 16);
+                        vw.z = oval[j * 8 + 4] | (oval[j * 8 + 5] << 16); vw.w = oval[j * 8 + 6] | (oval[j * 8 + 7] << 16);
+                        *reinterpret_cast<uint4*>(rp + (size_t)j * RS + 16) = vw;
+                    } else {
+                        *reinterpret_cast<uint4*>(rp + (size_t)j * RS + 16) = make_uint4(oval[j * 8 + 0], oval[j * 8 + 1], oval[j * 8 + 2], oval[j * 8 + 3]);
+                        *reinterpret_cast<uint4*>(rp + (size_t)j * RS + 32) = make_uint4(oval[j * 8 + 4], oval[j * 8 + 5], oval[j * 8 + 6], oval[j * 8 + 7]);
+                    }
+                }
+            }
+        }
+    }
+}
+
 // out[0] = records, out[1] = non-zeros this batch's walk visits: sum over columns of (queries of the batch using the column) x df
 template <int UNUSED>
 __global__ __launch_bounds__(kScanThreads) void bp_walk_kernel(const uint32_t* colfreq, const unsigned long long* df_rec, const unsigned long long* df_nnz,
@@ -330,6 +423,8 @@ struct BpArgs {
     float head_pre, head_mul; // powers of two: weights enter the fp16 operand as w * scale * head_pre (< 2^15), the sums leave as C * head_mul
     uint32_t* pace;           // optional [nchunk][blocks_per_chunk], zeroed per search: work items that have finished a block (flat walk: lock-step window)
     int32_t pace_window;      // blocks an item may run ahead of the slowest item of its chunk
+    int32_t knob;             // developer switches (VS_BP_KNOB)
+    unsigned long long* debug;    // optional (VS_BP_DEBUG=1): [8] consistency counters of the streamed walk
     unsigned long long* timing;   // optional (VS_BP_TIMING=1): [8] wave-cycles per phase, summed over waves: 0 item prologue, 1 list walk,
                                   // 2 wait at the barrier after the walk, 3 dense part, 4 epilogue; [5] = blocks x waves
 };
@@ -799,6 +894,19 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
             // thresholds other items of the same queries have published meanwhile (read before the barrier: the latency hides in it)
             if (a.gtau && tid < nq) { const unsigned long long g = a.gtau[q0 + tid]; if (g > tau[tid]) tau[tid] = g; }
             lap(1);
+            // Lock step (BpArgs::pace): the tiles of a chunk of blocks sweep the same blocks; one that falls behind loses the L2 /
+            // Infinity-Cache copies the pack left behind and falls further behind (per-workgroup clocks of a 4 M-doc run: 250 of 256
+            // at 31 ms, a handful at 41 ms -- and the launch ends with the last).  An item counts its arrival at the end of block j
+            // and waits while the slowest item of its chunk has not reached block j - window.  Only when every item is resident.
+            if (a.pace && items <= (int64_t)gridDim.x && tid == 0 && have) {
+                uint32_t* pc = a.pace + (size_t)c * a.blocks_per_chunk;
+                const int64_t rel = b - b0;
+                __hip_atomic_fetch_add(pc + rel, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (rel >= a.pace_window) {
+                    const uint32_t need = (uint32_t)(items / a.nchunk);
+                    while (__hip_atomic_load(pc + rel - a.pace_window, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(8);
+                }
+            }
             __syncthreads();
             if (tid == 0) scratch[40 + (int)((b + 1) & 1)] = 0;     // the next block's chunk counter (its last user was block b - 1)
             lap(2);

@@ -7,6 +7,7 @@
 #include "bp_refine.h"
 #include "bp_flat.h"
 #include "bp_pipe.h"
+#include "bp_stream.h"
 #include "synth_device.h"
 
 #include <algorithm>
@@ -753,7 +754,7 @@ void bp_release(vs_index* idx) {
 // binary index: filter walk only, one lane per (short) list
 constexpr int kFlRoundsF16 = 8, kFlRoundsF32 = 5;     // record loads in flight per lane (registers: 8 / 12 per record)
 // which walk serves the fixed-point filter of this index: 0 = a list per lane group (bp_walk.h), 1 = flat worklists (bp_flat.h),
-// 2 = flat worklists on two accumulator sets, no block barrier (bp_pipe.h)
+// 2 = flat worklists on two accumulator sets, no block barrier (bp_pipe.h), 3 = flat worklists, record loads software-pipelined (bp_stream.h)
 int bp_walk_kind(const vs_index* idx) {
     const bool can = idx->store_dtype != VS_NONE && idx->bp_n_head == 0 && idx->bp_max_block_recs < ((int64_t)1 << kFlRecBits) - 4096;
     if (!can) return 0;
@@ -766,7 +767,11 @@ int launch_bp_walk(const vs_index* idx, const BpArgs& a, int grid, int ent_cap, 
     const int vm = bp_record_vm(idx);
     size_t lds = bp_lds_bytes<QT, AM, kBpRowsMax>(ent_cap, AM == AM_FIX ? a.n_head : 0);
     void (*kern)(BpArgs) = nullptr;
-    if (bp_flat_ok<AM>(idx, a) && bp_walk_kind(idx) == 2) {
+    if (bp_flat_ok<AM>(idx, a) && bp_walk_kind(idx) == 3) {
+        if (vm == VM_F32) kern = bp_stream_topk<VM_F32, 3, kBpRowsMax>;
+        else kern = bp_stream_topk<VM_F16, 4, kBpRowsMax>;
+        lds = bp_stream_lds_bytes<kBpRowsMax>(ent_cap);
+    } else if (bp_flat_ok<AM>(idx, a) && bp_walk_kind(idx) == 2) {
         if (ent_cap > kPipeEntCap) return fail(VS_EINVAL, "pipelined walk: %d entries per tile, %d fit", ent_cap, kPipeEntCap);
         if (vm == VM_F32) kern = bp_pipe_topk<VM_F32, 5, kBpRowsMax>;
         else kern = bp_pipe_topk<VM_F16, 7, kBpRowsMax>;
@@ -940,6 +945,18 @@ int bp_build(vs_index* idx, hipStream_t s) {
     }
     VS_HIP(hipGetLastError());
     VS_STAGE("bp_fill", s);
+    // bank-aware order inside the lists (option "postings_arrange" = 1; off by default: 4 M docs, list walk 29.83 -> 29.58 ms for 55 ms more
+    // build time -- the scatter-add's bank conflicts are not what the walk waits for)
+    if (idx->store_dtype != VS_NONE && idx->bp_arrange_pref == 1) {
+        void (*arr)(const uint32_t*, const unsigned long long*, char*, int64_t, int32_t, int32_t) =
+            bp_record_vm(idx) == VM_F32 ? bp_arrange_kernel<VM_F32> : bp_arrange_kernel<VM_F16>;
+        const size_t alds = (size_t)256 * 64 * (2 + 4);
+        VS_HIP(hipFuncSetAttribute((const void*)arr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)alds));
+        hipLaunchKernelGGL(arr, dim3((unsigned)std::min<int64_t>(n_blocks, (int64_t)idx->cu_count * 8)), dim3(256), alds, s, idx->bp_dir.as<uint32_t>(),
+                           idx->bp_base.as<unsigned long long>(), idx->bp_rec.as<char>(), n_blocks, V, idx->bp_al_shift);
+        VS_HIP(hipGetLastError());
+        VS_STAGE("bp_arrange", s);
+    }
     VS_HIP(hipStreamSynchronize(s));                                     // `block_recs` is freed on return
     if (debug_sync_on()) {
         std::vector<unsigned long long> hb((size_t)n_blocks + 1);
@@ -1097,13 +1114,23 @@ int bp_filter_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64
     idx->last_plan_dev = dplan;
     idx->last_plan_rs = bp_rec_bytes(bp_record_vm(idx));
     idx->last_plan_blocks = n_blocks;
+    // lock-step window of the walk's work items (all walks; kernels ignore it when not every item is resident)
     static const int pace_env = getenv("VS_BP_PACE") ? atoi(getenv("VS_BP_PACE")) : -1;
-    const int pace_w = pace_env >= 0 ? pace_env : (idx->bp_pace >= 0 ? idx->bp_pace : (bp_walk_kind(idx) == 2 ? 8 : 0));
-    if (pace_w > 0 && bp_flat_ok<AM_FIX>(idx, a)) {
+    const int pace_w = pace_env >= 0 ? pace_env : (idx->bp_pace >= 0 ? idx->bp_pace : 0);      // (off by default: it costs the list walk 10 %)
+    if (pace_w > 0) {
         VS_TRY(idx->ws_pace.reserve((size_t)nchunk * a.blocks_per_chunk * 4));
         VS_HIP(hipMemsetAsync(idx->ws_pace.p, 0, (size_t)nchunk * a.blocks_per_chunk * 4, s));
         a.pace = idx->ws_pace.as<uint32_t>();
         a.pace_window = pace_w;
+    }
+    static const int knob_env = getenv("VS_BP_KNOB") ? atoi(getenv("VS_BP_KNOB")) : 0;
+    a.knob = knob_env;
+    static const bool debug_on = getenv("VS_BP_DEBUG") != nullptr;
+    DevBuf dbg;
+    if (debug_on) {
+        VS_TRY(dbg.alloc(64));
+        VS_HIP(hipMemsetAsync(dbg.p, 0, 64, s));
+        a.debug = dbg.as<unsigned long long>();
     }
     static const bool timing_on = getenv("VS_BP_TIMING") != nullptr;            // developer aid: where the walk's wave-cycles go
     DevBuf timing;
@@ -1115,6 +1142,13 @@ int bp_filter_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64
     {
         ProfScope prof("csr_scan_topk", s);
         VS_TRY((launch_bp_walk<kQT, AM_FIX>(idx, a, grid, vals_cap, s)));
+    }
+    if (debug_on) {
+        unsigned long long d[8] = {0};
+        VS_HIP(hipMemcpyAsync(d, dbg.p, 64, hipMemcpyDeviceToHost, s));
+        VS_HIP(hipStreamSynchronize(s));
+        fprintf(stderr, "[vsearch_hip] stream walk debug: %llu bad items (e.g. item %08llx, block of %llu records, block %llu, batch of %llu)\n", d[0], d[1] >> 32, d[1] & 0xFFFFFFFFull,
+                d[2] >> 32, d[2] & 0xFFFFFFFFull);
     }
     if (timing_on) {
         unsigned long long h[16] = {0};
