@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--k", type=int, default=K)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dump-ids", default=None, help="rank 0 writes the last step's (ids, scores) to this .npz (tests)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary configurations (C3, C5, Zipf 21 M, small-batch latency, facade leg) "
+                                                                "that follow the headline measurement on one GPU")
     ap.add_argument("--scan", choices=["auto", "csr", "postings"], default="auto",
                     help="auto: blocked postings when HBM has room for the second copy (default); csr: the 8-query CSR scan only")
     ap.add_argument("--cpu-sample-docs", type=int, default=100_000)
@@ -59,6 +62,16 @@ def parse():
 
 
 KIND = {"uniform": 0, "zipf": 2}
+
+
+def kernel_source_hash():
+    """sha256 over the sources of the scan kernels: a PMC profile under profiles/ is only quoted for the build it was taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("bp_walk.h", "bp_refine.h", "csr_scan.h", "csr_scan_mq.h", "csr_index.hip", "common.h"):
+        with open(os.path.join(REPO, "vsearch_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def make_query_batches(n_batches, batch, device, kind=0):
@@ -77,21 +90,28 @@ def make_query_batches(n_batches, batch, device, kind=0):
     return out
 
 
-def parity_check(device, kind=0):
+def parity_check(device, kind=0, nnz_doc=NNZ_DOC, store=0, val_law=0, expect_path=None, n=20_000, exact=False):
     """Small prefix of the same synthetic index (rows are a pure function of (seed, row id)) searched
-    by the HIP path and by the CPU oracle: recall@100 and max relative score error."""
+    by the HIP path and by the CPU oracle: recall@100 and max relative score error.  `expect_path`: the scan path the full-size
+    run took -- the prefix must take the same one (3 = postings filter + refine), or the flag says nothing about it."""
     import oracle
     from oracle import compare
+    from vsearch_amd import _native as nat
     from vsearch_amd.device_index import DeviceIndex
-    n = 20_000
-    idx = DeviceIndex.synthetic(INDEX_SEED, 0, n, V, NNZ_DOC, kind, 0, 0, device)
-    q = oracle.synth_queries(QUERY_SEED, 8, V, NNZ_Q, kind=kind)
+    idx = DeviceIndex.synthetic(INDEX_SEED, 0, n, V, nnz_doc, kind, 0, store, device)
+    q = oracle.synth_queries(QUERY_SEED, 8, V, NNZ_Q, val_law, kind=0 if kind == 1 else kind)
     ids, sc = idx.search(q, K)
+    path = idx.info().last_path
+    if expect_path is not None and path != expect_path:
+        raise AssertionError(f"parity prefix took scan path {path}, the measured run took {expect_path}")
     ip, ix, d = idx.export_csr()
-    o_ids, o_sc, allsc = oracle.csr_search(ip, ix.astype(np.int32), d, V, q, K, acc64=True, return_all=True)
-    compare.check_topk_valid(allsc, ids, sc, rtol=1e-4)
+    binary = store == nat.VS_NONE
+    o_ids, o_sc, allsc = oracle.csr_search(ip, ix.astype(np.int32), None if binary else d, V, q, K, acc64=True, return_all=True)
+    compare.check_topk_valid(allsc, ids, sc, rtol=1e-4, exact=exact, canonical=exact)
     rel = float(np.max(np.abs(sc.astype(np.float64) - o_sc) / np.abs(o_sc)))
-    return {"docs": n, "queries": 8, "recall_at_100_vs_oracle": compare.recall_at_k(o_ids, ids), "max_rel_score_err": rel}
+    idx.close()
+    return {"docs": n, "queries": 8, "scan_path": path, "recall_at_100_vs_oracle": compare.recall_at_k(o_ids, ids), "max_rel_score_err": rel,
+            "ids_bit_exact": bool((np.asarray(ids) == o_ids).all()) if exact else None}
 
 
 def cpu_baseline(sample_docs, device, kind=0):
@@ -119,6 +139,114 @@ def cpu_baseline(sample_docs, device, kind=0):
                       f"{n} of the same synthetic docs x 768 nnz, {bq}-query batches, {reps} timed calls, "
                       f"{qps_sample:.1f} q/s on the sample, scaled linearly in nnz to {N_DOCS} docs",
             "sample_qps": qps_sample, "host_cpus": os.cpu_count()}
+
+
+def _timed(fn, steps, warmup=1):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def secondary(index, batches, args, local_rank, device, headline_s):
+    """The other configurations of BASELINE.json and the drop-in API, AFTER the headline's timed region (never inside it), each
+    with its own oracle-prefix parity flag: so that they stand under the driver's clock too.
+      facade      -- the same 21 M-doc index searched through the reference's API (SparseIndex.search: cast, device move, SearchResults)
+      latency     -- B = 1 and B = 32 on the same index
+      C3          -- 1 M docs x 768 nnz, B = 1024
+      C5          -- SVDR bag-of-token index, 21 M docs x ~86 binary nnz, dyadic query weights (bit-exact ids)
+      zipf_21m    -- the 21 M-doc index with Zipf column popularity (dense head strips on the matrix cores)"""
+    from vsearch_amd import _native as nat
+    from vsearch_amd import synth
+    from vsearch_amd.device_index import DeviceIndex, Profile
+    from vsearch_amd.ir.retriever.index import SparseIndex
+    out = {}
+    B = args.batch
+    # facade leg: Index.search of the reference's API (index.py:88-94) on the SAME device index
+    fac = SparseIndex()
+    fac.adopt_device_index(index, dtype=torch.float32)
+    t_direct = _timed(lambda: index.search(batches[0], args.k), 3)
+    t_facade = _timed(lambda: fac.search(batches[0], args.k), 3)
+    fac._dev = None                                               # (the bench owns the index)
+    out["facade"] = {"api": "vsearch_amd.ir.retriever.index.SparseIndex.search (reference: src/ir/retriever/index.py:88-94)", "ms_per_step": t_facade * 1e3,
+                     "device_index_ms_per_step": t_direct * 1e3, "overhead_frac": t_facade / t_direct - 1.0, "queries_per_sec": B / t_facade}
+    lat = {}
+    for b in (1, 32):
+        lat[f"B={b}_ms"] = _timed(lambda: index.search(batches[0][:b], args.k), 20, 3) * 1e3
+    out["latency_21m"] = lat
+    index.close()
+
+    def run(name, docs, nnz, kind, store, val_law, steps, exact=False, columns="uniform"):
+        t0 = time.perf_counter()
+        idx = DeviceIndex.synthetic(INDEX_SEED, 0, docs, V, nnz, kind, 0, store, local_rank)
+        qkind = 0 if kind == synth.KIND_BOT else kind
+        qs = []
+        for i in range(2):
+            gen = DeviceIndex.synthetic(QUERY_SEED, i * B, B, V, NNZ_Q, qkind, val_law, 0, local_rank)
+            ip, ix, d = gen.export_csr()
+            gen.close()
+            q = torch.zeros((B, V), dtype=torch.float32, device=device)
+            q[torch.from_numpy(np.repeat(np.arange(B), np.diff(ip))).to(device), torch.from_numpy(ix).to(device)] = torch.from_numpy(d).to(device)
+            qs.append(q)
+        idx.search(qs[0][:8], args.k)
+        torch.cuda.synchronize()
+        build_s = time.perf_counter() - t0
+        it = [0]
+
+        def step():
+            idx.search(qs[it[0] % 2], args.k)
+            it[0] += 1
+        Profile.enable(True)
+        Profile.reset()
+        dt = _timed(step, steps)
+        Profile.enable(False)
+        scan_ms, launches = Profile.read("csr_scan_topk")
+        info = idx.info()
+        rec = {"docs": docs, "nnz_per_doc": nnz, "columns": columns, "batch": B, "k": args.k, "steps": steps, "ms_per_step": dt * 1e3, "queries_per_sec": B / dt,
+               "scan_path": info.last_path, "scan_kernel_ms": scan_ms / max(1, launches), "fallback_queries": info.last_fallbacks, "head_columns": info.head_columns,
+               "walk_adds_per_s": (info.last_walk_postings * launches / (steps + 1) / (scan_ms / 1e3)) if scan_ms > 0 and info.last_path >= 2 else None,
+               "bound": "on-chip (LDS scatter-adds / matrix cores for head strips), not HBM", "index_build_s": round(build_s, 2)}
+        idx.close()
+        rec["parity"] = parity_check(local_rank, kind, nnz, store, val_law, expect_path=info.last_path, n=80_000 if kind == synth.KIND_BOT else 20_000, exact=exact)
+        out[name] = rec
+
+    # one process, 8 row shards of the same index on this one device (vs_shard_group_*: per-shard searches on their own streams, the
+    # B * k pairs gathered and merged on the first shard's device): what the in-process sharding adds to 8 x the single-shard step
+    try:
+        from vsearch_amd.device_index import ShardGroup
+        from vsearch_amd.distributed import shard_rows
+        t0 = time.perf_counter()
+        shards = []
+        for r in range(8):
+            row0, n_loc = shard_rows(N_DOCS, 8, r)
+            shards.append(DeviceIndex.synthetic(INDEX_SEED, row0, n_loc, V, NNZ_DOC, 0, 0, nat.VS_F32, local_rank))
+        grp = ShardGroup(shards)
+        grp.search(batches[0][:8], args.k)
+        torch.cuda.synchronize()
+        build_s = time.perf_counter() - t0
+        t_one = _timed(lambda: shards[3].search(batches[0], args.k), 3)
+        t_grp = _timed(lambda: grp.search(batches[0], args.k), 2)
+        out["shard_group_8_on_one_gpu"] = {"shards": 8, "docs_per_shard": shard_rows(N_DOCS, 8, 0)[1], "ms_per_step": t_grp * 1e3, "single_shard_ms_per_step": t_one * 1e3,
+                                           "overhead_ms_per_step": (t_grp - 8 * t_one) * 1e3, "queries_per_sec": B / t_grp, "index_build_s": round(build_s, 2),
+                                           "note": "all 8 shards share ONE GPU here: the searches serialise; on 8 GPUs a step is the slowest shard's step + the exchange"}
+        grp.close()
+        for sh in shards:
+            sh.close()
+    except Exception as e:                                       # (never lose the headline line to a secondary leg)
+        out["shard_group_8_on_one_gpu"] = {"error": str(e)[:200]}
+    run("C3_1m_sparse", 1_000_000, NNZ_DOC, 0, nat.VS_F32, 0, 10)
+    for leg in (lambda: run("C5_bot_21m", N_DOCS, 86, synth.KIND_BOT, nat.VS_NONE, synth.VAL_DYADIC, 5, exact=True),
+                lambda: run("zipf_21m", N_DOCS, NNZ_DOC, synth.KIND_SKEW, nat.VS_F32, 0, 3, columns="zipf")):
+        try:
+            leg()
+        except Exception as e:
+            out.setdefault("errors", []).append(str(e)[:300])
+    out["headline_ms_per_step"] = headline_s * 1e3
+    return out
 
 
 def main():
@@ -176,6 +304,7 @@ def main():
         step(i)
     Profile.enable(True)
     Profile.reset()
+    searcher.enable_timing(True)
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -183,14 +312,29 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     Profile.enable(False)
+    phases = searcher.read_timing()
+    searcher.enable_timing(False)
     scan_ms, scan_launches = Profile.read("csr_scan_topk")
     merge_ms, _ = Profile.read("merge_topk")
     refine_ms, _ = Profile.read("refine_topk")
     fb_ms, _ = Profile.read("exact_fallback")
+    per_rank = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # per-rank breakdown (ms per step): the walk and refine kernels (hipEvents inside the library), the whole local search, the
+        # exchange (one all-gather) and the final merge (CUDA events around the phases of ShardedSearcher.search)
+        mine = torch.tensor([scan_ms, refine_ms, phases["local_ms"], phases["exchange_ms"], phases["merge_ms"]], dtype=torch.float64) / max(1, args.steps)
+        mine = mine.to("cpu" if share_gpu else device)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        m = torch.stack(allr).cpu().numpy()
+        names = ["walk_ms", "refine_ms", "local_search_ms", "exchange_ms", "merge_ms"]
+        per_rank = {n: {"max": float(m[:, i].max()), "min": float(m[:, i].min())} for i, n in enumerate(names)}
+        per_rank["by_rank"] = [{n: float(m[r, i]) for i, n in enumerate(names)} for r in range(world)]
+    if rank == 0 and args.dump_ids:
+        np.savez(args.dump_ids, ids=ids.cpu().numpy(), scores=scores.cpu().numpy())
 
     if rank == 0:
         qps = args.steps * args.batch / elapsed
@@ -217,7 +361,8 @@ def main():
                 rec = json.load(open(pmc)).get(kernel, {})
                 # only when the profile was taken on this kernel build and this configuration (it goes stale otherwise)
                 if rec.get("hbm_bytes_per_launch") and rec.get("queries_per_launch") == args.batch and rec.get("docs") == n_local \
-                        and rec.get("store", "fp32") == args.store and rec.get("scan", "auto") == args.scan and rec.get("columns", "uniform") == args.columns:
+                        and rec.get("store", "fp32") == args.store and rec.get("scan", "auto") == args.scan and rec.get("columns", "uniform") == args.columns \
+                        and rec.get("source_hash") == kernel_source_hash():
                     traffic = rec["hbm_bytes_per_launch"]
                     traffic_src = f"profiles/pmc_summary.json ({rec.get('tag', '?')}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command)"
             except Exception:
@@ -265,12 +410,17 @@ def main():
                        "lanes_per_row": info.lanes_per_row, "index_bytes_per_gpu": info.device_bytes,
                        "postings_copy_bytes_per_gpu": info.aux_bytes, "scan_path": path, "dominant_kernel": kernel, "index_build_s": round(build_s, 2)},
             "exchange": {"backend": ("rccl (torch.distributed nccl)" if backend == "nccl" else backend) if world > 1 else None,
-                         "world_size": dist.get_world_size() if world > 1 else 1,
+                         "process_group_backend": dist.get_backend() if world > 1 else None,
+                         "nccl_version": ".".join(str(x) for x in torch.cuda.nccl.version()) if world > 1 and backend == "nccl" else None,
+                         "world_size": dist.get_world_size() if world > 1 else 1, "per_rank_ms_per_step": per_rank,
                          "collective": "one all_gather_into_tensor of B*k packed (score, global id) int64 per rank + vs_merge_topk" if world > 1 else None},
             "roofline": roofline,
         }
+        line["roofline"]["kernel_source_hash"] = kernel_source_hash()
         if world == 1:
-            line["parity"] = parity_check(local_rank, kind)
+            line["parity"] = parity_check(local_rank, kind, expect_path=info.last_path if n_local >= 20_000 and args.scan == "auto" else None)
+            if not args.no_secondary and args.docs == N_DOCS and args.columns == "uniform" and args.scan == "auto":
+                line["secondary"] = secondary(index, batches, args, local_rank, device, elapsed / args.steps)
             if not args.no_cpu_baseline:
                 line["cpu_baseline"] = cpu_baseline(args.cpu_sample_docs, local_rank, kind)
         print(json.dumps(line), flush=True)

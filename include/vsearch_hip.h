@@ -186,10 +186,16 @@ VS_API int  vs_index_set_queries_per_pass(vs_index* index, int qt);
  *   "postings_chunks"   0 = auto, else the number of block runs the postings scan cuts the index into (work items = tiles x runs)
  *   "postings_filter"   1 (default) = the postings walk accumulates int32 fixed-point sums (3.4x the LDS atomic rate of fp64 on
  *                       MI355X) and returns k + max(28, k/4) candidates per query, which are re-scored with the exact numerics
- *                       and PROVEN to contain the top k; unproven queries re-run on the fp64 walk.  Results are identical to
- *                       0 = fp64 walk only
+ *                       and PROVEN to contain the top k; unproven queries re-run on the exact one-query scan of the CSR packets
+ *                       (exact_scan_topk_kernel).  Results are identical to 0 = fp64 walk only
  *   "postings_quant"    1 (default) = an fp32 index keeps fp16-rounded values in the postings copy (the filter only ranks
  *                       candidates; the refine step re-scores them from the fp32 CSR), 0 = fp32 values there too
+ *   "postings_walk"     which kernel walks the postings for the filter: -1 / 0 = a list per 8-lane group (bp_walk.h, the default: the fastest
+ *                       measured), 1 = flat per-wave worklists (bp_flat.h), 2 = flat worklists on two accumulator sets without block
+ *                       barrier (bp_pipe.h), 3 = flat worklists with software-pipelined record loads (bp_stream.h).  All four return
+ *                       identical results; 1 - 3 are kept as measured experiments.  Valued indexes without head strips only.
+ *   "postings_pace"     lock-step window of the walk's work items in blocks (-1 / 0 = free running, the default)
+ *   "postings_arrange"  1 = bank-aware order inside each posting list at build time (off by default: no measured gain)
  *   "postings_lanes"    0 = auto; valued index: lanes per posting list (4 | 8, auto 8); binary index: records in flight per lane (4 | 8, auto 8)
  *   "postings_align"    1 = posting lists start on whole 128-byte lines (16 % more bytes, ~2 % less walk time); 0 / -1 = packed
  *   "postings_head"     -1 = auto (4), 0 = off, N in 2..64: columns present in >= 1/N of the documents (at most 512, the most
@@ -205,7 +211,10 @@ VS_API int  vs_index_set_option(vs_index* index, const char* name, int value);
  * its own device; the group does not own them.  vs_shard_group_search scores the batch on every GPU concurrently, moves the
  * B * k (id, score) pairs of each shard to the first shard's device with peer copies (xGMI), and merges there: the result is
  * identical to searching the unsharded index (global ids, canonical order).  q: host pointer or device pointer on any GPU;
- * outputs: host pointers or device pointers on the first shard's device.  Blocking.  Fewer than 2^32 - 1 documents in total.
+ * outputs: host pointers or device pointers on the first shard's device.  Blocking.  The shards run on streams of the group: with a
+ * device-resident q (or device outputs) the call first synchronises that device, so that work the caller has queued on ANY of its
+ * streams (the encoder writing q, a kernel still reading a recycled output buffer) is done before the shards touch the buffers.
+ * Fewer than 2^32 - 1 documents in total.
  * (One process per GPU with torch.distributed / RCCL uses vs_index_search's id_offset + vs_merge_topk instead:
  * vsearch_amd/distributed.py.)                                                                                                */
 typedef struct vs_shard_group vs_shard_group;

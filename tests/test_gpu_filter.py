@@ -24,6 +24,36 @@ def _search(idx, q, k, **opts):
     return np.asarray(ids), np.asarray(sc), idx.info()
 
 
+
+def _oracle_pin(seed, n, q, ids, sc, k, kind=0, val_law=0, nnz=768, windows=48, window_rows=8192, binary=False, exact=False):
+    """Pin a result on an index too large for the oracle to the CPU oracle: the synthetic rows are a pure function of (seed, row), so
+    the oracle (a) regenerates every RETURNED row and re-scores it (fp64 sums): the returned scores must be the oracle's, and (b)
+    regenerates `windows` runs of `window_rows` consecutive rows spread over the whole index and scores them all: no sampled row
+    may beat a query's k-th returned score unless it was returned."""
+    ids = np.asarray(ids); sc = np.asarray(sc)
+    B = q.shape[0]
+    for b in range(B):
+        rows = ids[b]
+        parts = [oracle.synth_csr(seed, int(r), 1, V, nnz, kind, val_law) for r in rows]
+        ip = np.concatenate([[0], np.cumsum([len(p[1]) for p in parts])]).astype(np.int64)
+        ix = np.concatenate([p[1] for p in parts]); d = None if binary else np.concatenate([p[2] for p in parts])
+        _, _, allsc = oracle.csr_search(ip, ix, d, V, q[b:b + 1], 1, acc64=True, return_all=True)
+        want = allsc[0].astype(np.float32)
+        if exact:
+            assert (want == sc[b]).all(), f"query {b}: returned scores differ from the oracle's"
+        else:
+            assert np.allclose(want, sc[b], rtol=RTOL, atol=0), f"query {b}: returned scores differ from the oracle's by {np.abs(want - sc[b]).max()}"
+    starts = np.linspace(0, n - window_rows, windows).astype(np.int64)
+    for r0 in starts:
+        ip, ix, d = oracle.synth_csr(seed, int(r0), window_rows, V, nnz, kind, val_law)
+        _, _, allsc = oracle.csr_search(ip, ix, None if binary else d, V, q, 1, acc64=True, return_all=True)
+        for b in range(B):
+            kth = sc[b, k - 1]
+            better = np.nonzero(allsc[b] > kth * (1 + RTOL if kth > 0 else 1 - RTOL))[0] + r0
+            missing = np.setdiff1d(better, ids[b])
+            assert missing.size == 0, f"query {b}: rows {missing[:5]} beat the k-th score {kth} and were not returned"
+
+
 def _modes(idx, q, k, want_quant, tied_queries=0):
     """-> results of {csr scan, filter, filter on exact records, forced fallback x 2, filter on the flat walk (bp_flat.h) x 2,
     fp64 walk}; checks paths and bit-equality."""
@@ -113,6 +143,50 @@ def test_ties_beyond_the_candidate_margin_take_the_exact_pass():
     assert info.last_fallbacks >= 1 and (ids == ref_ids).all() and (sc == ref_sc).all()
 
 
+@pytest.mark.parametrize("quant", [-1, 0], ids=["lossy-records", "exact-records"])
+def test_short_and_dominant_weight_queries(quant):
+    """Queries of 1, 2, 8 and 31 non-zeros and queries with one dominant weight: the per-query scale then puts single products
+    above 2^25 fixed-point units, where the fp32 rounding of a product exceeds the one unit of truncation -- the proof's slack has to
+    cover it (bp_refine.h).  Index values sit at fp16 / fp32 rounding midpoints, and blocks of duplicated rows make near-ties at the
+    k-th rank.  Results: the CSR scan's, bit for bit, and a valid top-k of the oracle's fp64 scores."""
+    rng = np.random.default_rng(11)
+    n = 20000
+    ip, ix, d = oracle.synth_csr(5, 0, n)
+    d = d.copy()
+    # values at rounding midpoints: halfway between two fp16 numbers (exactly representable in fp32), and fp32 numbers with a long tail
+    h = d[::3].astype(np.float16).astype(np.float32)
+    d[::3] = h * (1 + 2.0 ** -11)
+    d[1::3] = np.nextafter(d[1::3].astype(np.float16).astype(np.float32), np.float32(4))
+    # near-ties: 300 rows equal row 7 except for one value nudged by an ulp
+    for j, r in enumerate(range(1000, 1300)):
+        ix[ip[r]:ip[r + 1]] = ix[ip[7]:ip[8]]
+        d[ip[r]:ip[r + 1]] = d[ip[7]:ip[8]]
+        d[ip[r] + (j % 768)] = np.nextafter(d[ip[r] + (j % 768)], np.float32(4))
+    cols7 = ix[ip[7]:ip[8]]
+    qs = []
+    for nnz_q in (1, 2, 8, 31):
+        for rep in range(2):
+            v = np.zeros(V, np.float32)
+            c = rng.choice(cols7, size=nnz_q, replace=False) if rep == 0 else rng.choice(V, size=nnz_q, replace=False)
+            v[c] = (0.01 + 3 * rng.random(nnz_q)).astype(np.float32)
+            qs.append(v)
+    for dom in (1e3, 1e6):                                          # 776 non-zeros, one of them dominant
+        v = oracle.synth_queries(9, 1)[0].copy()
+        v[cols7[5]] = np.float32(dom)
+        qs.append(v)
+    q = np.stack(qs)
+    idx = DeviceIndex.from_csr(ip, ix, d, V)
+    ref_ids, ref_sc, info = _search(idx, q, 100, blocked_postings=0)
+    assert info.last_path == 1
+    for walk in (0, 1, 3):
+        ids, sc, info = _search(idx, q, 100, blocked_postings=1, postings_quant=quant, postings_walk=walk)
+        assert info.last_path == 3
+        assert (ids == ref_ids).all() and (sc == ref_sc).all(), f"walk {walk}: differs from the CSR scan"
+    idx.set_option("postings_walk", -1)
+    _, _, allsc = oracle.csr_search(ip, ix, d, V, q, 100, acc64=True, return_all=True)
+    compare.check_topk_valid(allsc, ref_ids, ref_sc, rtol=RTOL)
+
+
 def test_signed_values_and_weights():
     """Negative index values keep fp32 records (the lossy copy needs non-negative data); a negative query weight on a lossy
     copy sends that query to the exact pass.  Results stay those of the CSR scan."""
@@ -192,6 +266,10 @@ def test_baseline_sized_index_on_one_gpu():
     assert info.last_path == 3 and info.last_fallbacks == 0
     ref_ids, ref_sc, _ = _search(idx, qb[500:516], 100, blocked_postings=0)
     assert (np.asarray(ids_b)[500:516] == ref_ids).all() and (np.asarray(sc_b)[500:516] == ref_sc).all()
+    # ... and against the CPU oracle at full size (every 21 M-doc check compared HIP with HIP): the returned rows
+    # re-scored, 48 x 8192 sampled rows scored -- for the 4-query search and for 8 queries of the 1024-query batch
+    _oracle_pin(0, n, q, ids, sc, 100)
+    _oracle_pin(0, n, qb[500:508], np.asarray(ids_b)[500:508], np.asarray(sc_b)[500:508], 100, windows=16)
 
 
 def test_skewed_columns_device_generator_and_search():
@@ -312,6 +390,9 @@ def test_baseline_sized_bag_of_token_index():
     assert (ids == ref_ids).all() and (sc == ref_sc).all()
     allsc = idx.scores(q[:4])
     compare.check_topk_valid(allsc, ids[:4], sc[:4], rtol=RTOL, exact=True, canonical=True)
+    del allsc
+    # the CPU oracle at full size: returned rows re-scored (bit-exact: integer-scaled sums), sampled rows scored
+    _oracle_pin(0, n, q[:4], ids[:4], sc[:4], 100, kind=synth.KIND_BOT, nnz=86, windows=32, window_rows=65536, binary=True, exact=True)
 
 
 def test_baseline_sized_skewed_index_with_head_strips():
@@ -325,6 +406,7 @@ def test_baseline_sized_skewed_index_with_head_strips():
     ref_ids, ref_sc, info = _search(idx, q[20:28], 100, blocked_postings=0)
     assert info.last_path == 1
     assert (ids[20:28] == ref_ids).all() and (sc[20:28] == ref_sc).all()
+    _oracle_pin(0, n, q[20:24], ids[20:24], sc[20:24], 100, kind=synth.KIND_SKEW, windows=24)
 
 
 def test_head_strips_edge_cases_empty_queries_and_append():

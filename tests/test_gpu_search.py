@@ -300,6 +300,38 @@ def test_nccl_single_rank_exchange_path():
         dist.destroy_process_group()
 
 
+def test_two_rank_bench_launch_on_one_gpu_equals_the_unsharded_search(tmp_path):
+    """the multi-rank path end to end on the hardware at hand -- `bench.py --gpus 2` through launch.spawn_ranks
+    (two fresh rank processes, env:// rendezvous on 127.0.0.1; both share cuda:0 and exchange over gloo because RCCL refuses two
+    ranks on one device), row shards of 200 000 docs each, one all-gather, merge.  Rank 0's ids and scores must be the unsharded
+    index's, bit for bit; the JSON line carries the per-rank phase breakdown."""
+    import json, os, subprocess, sys
+    from vsearch_amd import launch
+    import bench
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dump = str(tmp_path / "ids.npz")
+    out = str(tmp_path / "line.json")
+    docs, batch, k = 400_000, 64, 100
+    cmd = [sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--docs", str(docs), "--batch", str(batch), "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--dump-ids", dump]
+    env = dict(os.environ, VS_BENCH_SHARE_GPU="1")
+    # the parent of the ranks must not have touched the GPU: run the launcher in a fresh interpreter (this pytest process has)
+    code = ("import sys, json; sys.path.insert(0, %r); from vsearch_amd import launch; "
+            "raise SystemExit(launch.spawn_ranks(%r, 2, timeout_s=600, extra_env={'VS_BENCH_SHARE_GPU': '1'}))" % (repo, cmd))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["exchange"]["world_size"] == 2 and line["exchange"]["process_group_backend"] == "gloo"
+    pr = line["exchange"]["per_rank_ms_per_step"]
+    assert len(pr["by_rank"]) == 2 and pr["walk_ms"]["max"] > 0 and pr["exchange_ms"]["max"] > 0 and pr["merge_ms"]["max"] > 0
+    got = np.load(dump)
+    idx = DeviceIndex.synthetic(bench.INDEX_SEED, 0, docs, V, bench.NNZ_DOC, 0, 0, nat.VS_F32)
+    import torch
+    qb = bench.make_query_batches(3, batch, torch.device("cuda", 0))
+    ids, sc = idx.search(qb[2], k)                                   # steps 2 + warmup 1: the last step searched batch 2
+    assert (ids.cpu().numpy() == got["ids"]).all() and (sc.cpu().numpy() == got["scores"]).all()
+
+
 def test_reserve_and_append_equals_single_shot():
     """Shard-by-shard construction (vs_index_create_reserved + vs_index_append_csr) == one-shot creation."""
     n = 1500

@@ -59,6 +59,77 @@ def test_inspect_rejects_other_files(tmp_path):
         npz_inspect(p_csr, 81)                                         # shift beyond the columns
 
 
+def _write_npz(path, **arrays):
+    """An .npz with arbitrary (possibly inconsistent) members, written member by member so that headers can be doctored."""
+    import io, zipfile
+    with zipfile.ZipFile(path, "w", zipfile.ZIP_STORED) as z:
+        for name, a in arrays.items():
+            if isinstance(a, bytes):
+                z.writestr(name + ".npy", a)
+            else:
+                buf = io.BytesIO()
+                np.save(buf, a)
+                z.writestr(name + ".npy", buf.getvalue())
+
+
+def test_inspect_survives_hostile_files(tmp_path):
+    """the reader must treat the file as untrusted -- a row pointer far beyond the indices, an item size it cannot read,
+    2-d members, size fields that would allocate the world: every one an error code (ValueError / NotImplementedError), no read past
+    a buffer, no C++ exception through the C ABI (which would kill the process)."""
+    import io
+    fmt = np.array("csr")
+    shape = np.array([2, 10], dtype=np.int64)
+    good_idx = np.array([1, 2, 3, 4, 5], dtype=np.int32)
+    good_dat = np.ones(5, dtype=np.float32)
+    # (1) indptr = [0, 1e9, 5]: consistent at both ends, wild in the middle (reproduced by the advisor as a heap read)
+    p = str(tmp_path / "spike.npz")
+    _write_npz(p, indices=good_idx, indptr=np.array([0, 10**9, 5], dtype=np.int64), format=fmt, shape=shape, data=good_dat)
+    with pytest.raises(ValueError):
+        npz_inspect(p, 0)
+    # (2) a negative row pointer
+    p = str(tmp_path / "neg.npz")
+    _write_npz(p, indices=good_idx, indptr=np.array([0, -3, 5], dtype=np.int64), format=fmt, shape=shape, data=good_dat)
+    with pytest.raises(ValueError):
+        npz_inspect(p, 0)
+    # (3) item sizes the integer reader does not know: '<i3', '<i0' (header doctored by hand)
+    buf = io.BytesIO()
+    np.save(buf, np.array([0, 2, 5], dtype=np.int32))
+    raw = buf.getvalue()
+    for bad in (b"<i3", b"<i0", b"<i9"):
+        p = str(tmp_path / ("descr_" + bad.decode()[1:] + ".npz"))
+        _write_npz(p, indices=good_idx, indptr=raw.replace(b"<i4", bad), format=fmt, shape=shape, data=good_dat)
+        with pytest.raises((ValueError, NotImplementedError)):
+            npz_inspect(p, 0)
+    # (4) 2-d indptr / indices
+    p = str(tmp_path / "twod.npz")
+    _write_npz(p, indices=good_idx.reshape(5, 1), indptr=np.array([[0, 2, 5]], dtype=np.int64).reshape(3, 1), format=fmt, shape=shape, data=good_dat)
+    with pytest.raises(ValueError):
+        npz_inspect(p, 0)
+    # (5) a shape whose element count overflows int64
+    buf = io.BytesIO()
+    np.save(buf, np.zeros(3, dtype=np.int64))
+    raw = buf.getvalue().replace(b"(3,)", b"(4611686018427387904, 4611686018427387904)"[:0] + b"(3,)")   # (keep the header length: patch below)
+    hdr_pad = raw.index(b"(3,)")
+    big = b"(9223372036854775807,9)"
+    doctored = raw[:hdr_pad] + big + raw[hdr_pad + 4 + (len(big) - 4):]                                    # overwrite padding spaces
+    p = str(tmp_path / "overflow.npz")
+    _write_npz(p, indices=good_idx, indptr=doctored, format=fmt, shape=shape, data=good_dat)
+    with pytest.raises((ValueError, NotImplementedError)):
+        npz_inspect(p, 0)
+    # (6) a central directory that claims to be larger than the file
+    ok = str(tmp_path / "ok.npz")
+    sp.save_npz(ok, sp.csr_matrix((good_dat, good_idx, np.array([0, 2, 5])), shape=(2, 10)), compressed=False)
+    raw = bytearray(open(ok, "rb").read())
+    eocd = raw.rfind(b"PK\x05\x06")
+    raw[eocd + 12:eocd + 16] = (0x7FFFFFF0).to_bytes(4, "little")
+    p = str(tmp_path / "cdsize.npz")
+    open(p, "wb").write(bytes(raw))
+    with pytest.raises(ValueError):
+        npz_inspect(p, 0)
+    # the untouched file still reads
+    assert npz_inspect(ok, 0) == (2, 10, 5, 2)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("store", [nat.VS_F32, nat.VS_F16, nat.VS_NONE], ids=["fp32", "fp16", "binary"])
 def test_append_npz_equals_scipy_slice(tmp_path, store):

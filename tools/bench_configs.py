@@ -60,7 +60,13 @@ def sparse_like(name, n, nnz, kind, store, batch, q_law):
     compare.check_topk_valid(allsc, ids[:4].cpu().numpy(), sc[:4].cpu().numpy(), rtol=1e-4, exact=(kind == 1), canonical=(kind == 1))
     return {"config": name, "metric": "queries/sec", "value": batch / dt, "ms_per_batch": dt * 1e3, "docs": n, "batch": batch, "k": K,
             "queries_per_pass": qt, "lanes_per_row": info.lanes_per_row, "index_bytes": info.device_bytes,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK, "unit": "GB/s", "frac": achieved / HBM_PEAK,
+            # (postings paths: the walk's bytes come from L2 / Infinity Cache and what binds is the LDS scatter-add rate -- an "hbm" fraction
+            #  of algorithmic bytes would exceed 1 and mean nothing; HBM traffic needs a PMC pass: tools/pmc_walk.sh)
+            "roofline": {"bound": "hbm" if info.last_path < 2 else "on-chip: LDS scatter-adds (ds_add_u32, bank conflicts) + L2->L1 record loads",
+                         "achieved": achieved if info.last_path < 2 else (info.last_walk_postings / (scan_ms / 1e3 / launches) / 1e9),
+                         "peak": HBM_PEAK if info.last_path < 2 else 5000.0, "unit": "GB/s" if info.last_path < 2 else "Gadd/s (ds_add_u32 at random addresses, tools/microbench/lds_scatter.hip)",
+                         "frac": (achieved / HBM_PEAK) if info.last_path < 2 else (info.last_walk_postings / (scan_ms / 1e3 / launches) / 5.0e12),
+                         "algorithmic_GBps": achieved,
                          "kernel": "bp_walk_topk" if info.last_path >= 2 else "csr_scan_topk_mq", "avg_launch_ms": scan_ms / launches,
                          "scan_path": info.last_path, "fallback_queries": info.last_fallbacks, "postings_copy_bytes": info.aux_bytes,
                          "walk_adds_per_s": (info.last_walk_postings / (scan_ms / 1e3 / launches)) if info.last_path >= 2 else None,

@@ -16,6 +16,15 @@ import os
 import sqlite3
 
 
+def source_hash():
+    """bench.py's kernel_source_hash(): the profile is quoted only for the kernel sources it was taken on."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m.kernel_source_hash()
+
+
 def top_kernels(db):
     con = sqlite3.connect(db)
     rows = con.execute("select name, total_calls, total_duration, average, percentage from top_kernels").fetchall()
@@ -86,6 +95,7 @@ def main():
                 continue
             pmc[key] = {"hbm_bytes_per_launch": (2 * fetch + write) * 1024, "fetch_KiB": fetch, "write_KiB": write,
                         "queries_per_launch": a.queries, "docs": a.docs, "store": a.store, "scan": a.scan, "columns": a.columns, "tag": a.tag,
+                        "source_hash": source_hash(),
                         "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024  (gfx950: FETCH_SIZE counts 1/2 of a 16 B/lane coalesced stream)",
                         "source": f"profiles/{a.tag}_fetch_size.txt, profiles/{a.tag}_write_size.txt (rocprofv3 --pmc, separate passes, {a.note})"}
         with open(pmc_path, "w") as f:

@@ -225,6 +225,12 @@ extern "C" int vs_shard_group_search(vs_shard_group* g, const void* q, int q_dty
         VS_HIP(hipPointerGetAttributes(&attr, q));
         q_device = attr.device;
     }
+    // Device-resident queries or outputs: the shards run on the group's OWN non-blocking streams, which nothing orders after the
+    // stream that produced `q` (an encoder still writing it) or that last used the output buffers (an allocator that recycles them).
+    // The caller's stream is not known here, so the devices concerned are synchronised first (documented in the header).
+    const bool out_dev_early = is_device_ptr(out_ids);
+    if (q_dev) { VS_HIP(hipSetDevice(q_device)); VS_HIP(hipDeviceSynchronize()); }
+    if (out_dev_early && (!q_dev || q_device != g->shards[0]->device)) { VS_HIP(hipSetDevice(g->shards[0]->device)); VS_HIP(hipDeviceSynchronize()); }
     // 1. every shard scores the whole batch on its own GPU and stream (asynchronous on the postings filter path)
     std::vector<int> ki((size_t)n);
     int64_t k_tot = 0;

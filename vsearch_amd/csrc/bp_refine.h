@@ -3,9 +3,14 @@
 // The fixed-point walk returns, per query, the K' > k documents with the largest APPROXIMATE scores.  Here those K'
 // documents are re-scored from their CSR rows with the library's exact numerics (fp32 product, fp64 sum -- what the CSR
 // pass and the fp64 walk compute), the exact top k is written out, and the kernel PROVES per query that no document
-// outside the K' can belong to it:  a document the walk did not return has an approximate sum A <= A_cut (the K'-th best),
-// hence an exact sum below (A_cut + n) / S, n = the query's non-zeros (one unit of truncation per matched term).  If the
-// exact k-th score is above that bound the query is done; otherwise its flag is set and an exact pass re-runs it.
+// outside the K' can belong to it:  a document the walk did not return has an approximate sum A <= A_cut (the K'-th best).
+// The walk adds trunc(fl32(w S v)) per matched term: the truncation loses less than one unit per term (n = the query's non-zeros
+// bounds the terms), the fp32 rounding of a product x at most 2^-24 |x| -- more than a unit once x >= 2^25, which a query of few or
+// one dominant non-zero reaches -- but sum |x| <= sum |w| vmax S < 2^30 (the choice of S), so all roundings of a document together
+// stay below 2^6 units.  The library's own score sums fl32(w v) in fp64: above the real sum by at most another 2^-24 sum |w v|,
+// again < 2^6 units of 1 / S.  Hence a document outside the K' has a library score below (A_cut + n + 1 + 128) / S -- the slack
+// bp_qscale_kernel stores; round-2 builds left the 128 out (a hole no test could reach, closed here).  If the exact
+// k-th score is above that bound the query is done; otherwise its flag is set and an exact pass re-runs it.
 //
 // Lossy records: for an fp32 index the filter's copy stores the values ROUNDED TO fp16 (4 instead of 6 bytes per posting -- the
 // walk is bound by the bytes a CU can pull through its L1, rocprofv3: ~23 B/clk/CU).  The rounding error is relative
@@ -38,7 +43,7 @@ __global__ __launch_bounds__(256) void bp_vmax_kernel(const void* vals, int64_t 
     if (__builtin_amdgcn_ballot_w64(neg) && (threadIdx.x & 63) == 0) atomicOr(out_bits + 1, 1u);
 }
 
-// Per query: S = 2^e with (sum |w|) * vmax * S < 2^30 (no int32 sum can wrap), the slack n = non-zeros + 1 in fixed-point
+// Per query: S = 2^e with (sum |w|) * vmax * S < 2^30 (no int32 sum can wrap), the slack n = non-zeros + 1 + 128 (truncations + the fp32 rounding of the products, see the header) in fixed-point
 // units and sum |w|.  n = 0 marks a query whose walk is EXACT (binary index and every w * S an integer): its approximate order
 // is the exact order, nothing to prove.  n = -1 marks a query the quantised records cannot bound (a negative weight): it
 // goes straight to the exact pass.  One wave per query, fixed reduction order.
@@ -82,7 +87,8 @@ __global__ __launch_bounds__(256) void bp_qscale_kernel(const int64_t* qptr, con
         qwsum[q] = sum * 1.0001f;
         // the dense part of a score (matrix cores, bp_walk.h): bp_head_slack
         const int64_t dense_slack = heads > 0 ? (int64_t)head_slack : 0;
-        qslack[q] = (exact || e1 == e0) ? 0 : (((quant || heads > 0) && neg) ? -1 : (int32_t)min((int64_t)1 << 24, e1 - e0 + 1 + dense_slack));
+        // one unit of truncation per term, + 2 x 2^6 for the fp32 rounding of the products (the walk's and the library's: header)
+        qslack[q] = (exact || e1 == e0) ? 0 : (((quant || heads > 0) && neg) ? -1 : (int32_t)min((int64_t)1 << 24, e1 - e0 + 1 + 128 + dense_slack));
     }
 }
 

@@ -27,9 +27,12 @@ struct Npy {
     std::string descr;              // e.g. "<i4"
     std::vector<int64_t> shape;
     const char* data() const { return raw.data() + data_off; }
-    int64_t count() const {
+    int64_t count() const {                 // -1: a negative dimension or a product beyond int64 (parse_npy refuses such arrays)
         int64_t n = 1;
-        for (int64_t s : shape) n *= s;
+        for (int64_t s : shape) {
+            if (s < 0 || (s != 0 && n > INT64_MAX / s)) return -1;
+            n *= s;
+        }
         return n;
     }
     size_t item() const { return descr.size() >= 3 ? (size_t)atoi(descr.c_str() + 2) : 0; }
@@ -77,6 +80,7 @@ int list_members(File& zf, std::vector<Member>& out) {
         cd_size = rd64(r + 40);
         cd_off = rd64(r + 48);
     }
+    if (cd_size > zf.size || cd_off > zf.size - cd_size || n_entries > cd_size / 46 + 1) return fail(VS_EINVAL, "zip: central directory beyond the end of the file");
     std::vector<unsigned char> cd(cd_size);
     VS_TRY(zf.read(cd_off, cd.data(), cd_size));
     size_t p = 0;
@@ -113,6 +117,9 @@ int read_member(File& zf, const Member& m, std::vector<char>& out) {
     VS_TRY(zf.read(m.local_off, lh, 30));
     if (rd32(lh) != 0x04034b50u) return fail(VS_EINVAL, "zip: bad local header of %s", m.name.c_str());
     const uint64_t data_off = m.local_off + 30 + rd16(lh + 26) + rd16(lh + 28);
+    // untrusted sizes: the compressed bytes must lie inside the file, and deflate expands at most ~1032 x
+    if (data_off > zf.size || m.comp_size > zf.size - data_off) return fail(VS_EINVAL, "zip: member %s lies beyond the end of the file", m.name.c_str());
+    if (m.size > (uint64_t)1 << 46 || (m.method == 8 && m.size / 1040 > m.comp_size + 1)) return fail(VS_EINVAL, "zip: member %s claims an impossible size", m.name.c_str());
     out.resize(m.size);
     if (m.method == 0) {
         if (m.comp_size != m.size) return fail(VS_EINVAL, "zip: stored member %s with differing sizes", m.name.c_str());
@@ -169,7 +176,8 @@ int parse_npy(Npy& a, const char* what) {
     auto find_val = [&](const char* key) -> size_t {
         const size_t k = h.find(key);
         if (k == std::string::npos) return k;
-        return h.find(':', k) + 1;
+        const size_t c = h.find(':', k);
+        return c == std::string::npos ? c : c + 1;
     };
     size_t p = find_val("'descr'");
     if (p == std::string::npos) return fail(VS_EINVAL, "%s: .npy header without descr", what);
@@ -177,7 +185,10 @@ int parse_npy(Npy& a, const char* what) {
     if (q0 == std::string::npos || q1 == std::string::npos) return fail(VS_EUNSUPPORTED, "%s: structured .npy dtypes are not supported", what);
     a.descr = h.substr(q0 + 1, q1 - q0 - 1);
     p = find_val("'fortran_order'");
-    if (p != std::string::npos && h.compare(h.find_first_not_of(' ', p), 4, "True") == 0) return fail(VS_EUNSUPPORTED, "%s: Fortran-ordered .npy", what);
+    if (p != std::string::npos) {
+        const size_t v = h.find_first_not_of(' ', p);
+        if (v != std::string::npos && h.compare(v, 4, "True") == 0) return fail(VS_EUNSUPPORTED, "%s: Fortran-ordered .npy", what);
+    }
     p = find_val("'shape'");
     if (p == std::string::npos) return fail(VS_EINVAL, "%s: .npy header without shape", what);
     const size_t s0 = h.find('(', p), s1 = h.find(')', s0);
@@ -193,7 +204,16 @@ int parse_npy(Npy& a, const char* what) {
     }
     a.data_off = hoff + hlen;
     if (a.descr.size() < 3 || (a.descr[0] != '<' && a.descr[0] != '|' && a.descr[0] != '=')) return fail(VS_EUNSUPPORTED, "%s: dtype %s (big-endian?)", what, a.descr.c_str());
-    if ((uint64_t)a.count() * a.item() > r.size() - a.data_off) return fail(VS_EINVAL, "%s: .npy payload shorter than its shape", what);
+    // untrusted file: the item size must be one the readers below handle, the shape must not overflow, the payload must be there
+    const size_t isz = a.item();
+    const char kind = a.descr[1];
+    const bool known = ((kind == 'i' || kind == 'u') && (isz == 1 || isz == 2 || isz == 4 || isz == 8)) || (kind == 'b' && isz == 1) ||
+                       (kind == 'f' && (isz == 2 || isz == 4 || isz == 8)) || ((kind == 'U' || kind == 'S') && isz >= 1 && isz <= 64);
+    if (!known) return fail(VS_EUNSUPPORTED, "%s: dtype %s is not supported", what, a.descr.c_str());
+    if (a.shape.size() > 2) return fail(VS_EINVAL, "%s: %zu-dimensional array", what, a.shape.size());
+    const int64_t cnt = a.count();
+    const size_t esz = (kind == 'U') ? isz * 4 : isz;              // ('<U3' = 3 UCS-4 characters)
+    if (cnt < 0 || a.data_off > r.size() || (uint64_t)cnt > (r.size() - a.data_off) / esz) return fail(VS_EINVAL, "%s: .npy payload shorter than its shape", what);
     return VS_OK;
 }
 
@@ -253,7 +273,8 @@ int load_csr_members(const char* path, bool want_payload, CsrFile& c) {
         Npy f;
         VS_TRY(read_member(zf, *m_fmt, f.raw));
         VS_TRY(parse_npy(f, "format"));
-        const std::string v(f.data(), std::min<size_t>(f.item() * (size_t)std::max<int64_t>(1, f.count()), 8));
+        const size_t fesz = f.descr[1] == 'U' ? f.item() * 4 : f.item();
+        const std::string v(f.data(), std::min<size_t>(fesz * (size_t)std::max<int64_t>(1, f.count()), 16));
         // '|S3' b"csr" or '<U3' "csr" (4 bytes per character)
         std::string flat;
         for (char ch : v) if (ch) flat.push_back(ch);
@@ -267,7 +288,7 @@ int load_csr_members(const char* path, bool want_payload, CsrFile& c) {
     Npy sh;
     VS_TRY(read_member(zf, *m_shape, sh.raw));
     VS_TRY(parse_npy(sh, "shape"));
-    if (sh.count() != 2) return fail(VS_EINVAL, "%s: shape is not 2-d", path);
+    if (sh.count() != 2 || (sh.descr[1] != 'i' && sh.descr[1] != 'u')) return fail(VS_EINVAL, "%s: shape is not a pair of integers", path);
     c.n_rows = int_at(sh, 0);
     c.n_cols = int_at(sh, 1);
     VS_TRY(read_member(zf, *m_ptr, c.indptr.raw));
@@ -277,11 +298,18 @@ int load_csr_members(const char* path, bool want_payload, CsrFile& c) {
     VS_TRY(read_member(zf, *m_idx, c.indices.raw));
     VS_TRY(parse_npy(c.indices, "indices"));
     if (c.indices.descr[1] != 'i' && c.indices.descr[1] != 'u') return fail(VS_EINVAL, "%s: indices is not an integer array", path);
+    if (c.n_rows < 0 || c.n_cols < 0 || c.indptr.shape.size() != 1 || c.indices.shape.size() != 1) return fail(VS_EINVAL, "%s: indptr / indices must be 1-d", path);
     const int64_t nnz = int_at(c.indptr, c.n_rows);
     if (int_at(c.indptr, 0) != 0 || nnz != c.indices.count()) return fail(VS_EINVAL, "%s: indptr does not match indices (%lld vs %lld)", path, (long long)nnz, (long long)c.indices.count());
+    // the WHOLE row-pointer array before anybody indexes `indices` with it: monotone, inside [0, nnz]
+    for (int64_t r = 0; r < c.n_rows; ++r) {
+        const int64_t a = int_at(c.indptr, r), b = int_at(c.indptr, r + 1);
+        if (a < 0 || b < a || b > nnz) return fail(VS_EINVAL, "%s: indptr is not a row-pointer array at row %lld (%lld, %lld; %lld non-zeros)", path, (long long)r, (long long)a, (long long)b, (long long)nnz);
+    }
     if (m_dat && want_payload) {
         VS_TRY(read_member(zf, *m_dat, c.data.raw));
         VS_TRY(parse_npy(c.data, "data"));
+        if (c.data.shape.size() != 1 || c.data.descr[1] == 'U' || c.data.descr[1] == 'S') return fail(VS_EINVAL, "%s: data must be a 1-d numeric array", path);
         if (c.data.count() != nnz) return fail(VS_EINVAL, "%s: data has %lld entries for %lld non-zeros", path, (long long)c.data.count(), (long long)nnz);
         c.has_data = true;
     }
@@ -294,7 +322,7 @@ int load_csr_members(const char* path, bool want_payload, CsrFile& c) {
 using namespace vs;
 
 // scipy.sparse.save_npz file (CSR): shape, non-zeros and 8-nnz packets that remain after `[:, shift:]` (index.py:172)
-extern "C" int vs_npz_inspect(const char* path, int32_t shift, int64_t* n_rows, int64_t* n_cols, int64_t* nnz, int64_t* packets) {
+static int npz_inspect_impl(const char* path, int32_t shift, int64_t* n_rows, int64_t* n_cols, int64_t* nnz, int64_t* packets) {
     if (!path || shift < 0) return fail(VS_EINVAL, "bad argument");
     CsrFile c;
     VS_TRY(load_csr_members(path, false, c));
@@ -321,7 +349,7 @@ extern "C" int vs_npz_inspect(const char* path, int32_t shift, int64_t* n_rows, 
 
 // appends the rows of a scipy .npz CSR shard to a reserved index: columns below `shift` dropped, ids moved down by `shift`,
 // columns sorted within a row (what `load_npz(f)[:, shift:]` + sort_indices() gives the reference's vstack, index.py:172-175)
-extern "C" int vs_index_append_npz(vs_index* idx, const char* path, int32_t shift) {
+static int index_append_npz_impl(vs_index* idx, const char* path, int32_t shift) {
     if (!idx || !path || shift < 0) return fail(VS_EINVAL, "bad argument");
     if (idx->kind != VS_KIND_CSR) return fail(VS_EINVAL, "not a CSR index");
     CsrFile c;
@@ -490,7 +518,7 @@ std::vector<char> npy_header(const char* descr, const std::vector<int64_t>& shap
 
 // the index as a scipy.sparse.save_npz file (CSR; int64 indptr / indices like the reference's torch CSR, fp32 data; a binary
 // index writes data == 1): scipy.sparse.load_npz reads it back.  compressed = 0: stored members (fast), 1: deflate level 1.
-extern "C" int vs_index_save_npz(const vs_index* idx, const char* path, int compressed) {
+static int index_save_npz_impl(const vs_index* idx, const char* path, int compressed) {
     if (!idx || !path) return fail(VS_EINVAL, "NULL argument");
     if (idx->kind != VS_KIND_CSR) return fail(VS_EINVAL, "not a CSR index");
     std::vector<int64_t> rp((size_t)idx->n_rows + 1);
@@ -512,4 +540,28 @@ extern "C" int vs_index_save_npz(const vs_index* idx, const char* path, int comp
     const unsigned char yes = 1;                                  // scipy >= 1.11 marks sparse ARRAYS (the facade holds a csr_array, like the
     VS_TRY(zw.add("_is_array.npy", npy_header("|b1", {}), &yes, 1, z));      // reference's save path under the pinned scipy: tests/golden/save_load.npz)
     return zw.finish();
+}
+
+// The C entry points: a corrupt or hostile file must come back as an error code, never as a C++ exception through the C ABI
+// (std::bad_alloc / length_error from a size field, out_of_range from a header parser) -- that would terminate the caller's process.
+template <class F>
+static int npz_guard(F&& f) {
+    try {
+        return f();
+    } catch (const std::bad_alloc&) {
+        return fail(VS_ENOMEM, "npz: out of host memory (a size field of the file?)");
+    } catch (const std::exception& e) {
+        return fail(VS_EINVAL, "npz: malformed file (%s)", e.what());
+    } catch (...) {
+        return fail(VS_EINVAL, "npz: malformed file");
+    }
+}
+extern "C" int vs_npz_inspect(const char* path, int32_t shift, int64_t* n_rows, int64_t* n_cols, int64_t* nnz, int64_t* packets) {
+    return npz_guard([&] { return npz_inspect_impl(path, shift, n_rows, n_cols, nnz, packets); });
+}
+extern "C" int vs_index_append_npz(vs_index* idx, const char* path, int32_t shift) {
+    return npz_guard([&] { return index_append_npz_impl(idx, path, shift); });
+}
+extern "C" int vs_index_save_npz(const vs_index* idx, const char* path, int compressed) {
+    return npz_guard([&] { return index_save_npz_impl(idx, path, compressed); });
 }

@@ -56,6 +56,32 @@ class ShardedSearcher:
             # candidates travel as (score bits << 32 | global id): ids are 32-bit on the wire and 2^32 - 1 is the pad sentinel
             raise ValueError(f"row-sharded search addresses at most {_PAD_ID - 1} documents (n_total = {self.n_total})")
         self.force_exchange = False     # tests: run the all-gather + merge even in a 1-rank group
+        self._events = None             # enable_timing(): per search (start, after local search, after exchange, after merge) CUDA events
+
+    def enable_timing(self, on: bool = True):
+        """Record CUDA events around the three phases of every search (no synchronisation inside the search): read_timing()
+        sums them afterwards -- the per-rank breakdown bench.py prints for N > 1."""
+        self._events = [] if on else None
+
+    def read_timing(self):
+        """-> {"local_ms", "exchange_ms", "merge_ms", "searches"} summed over the searches since enable_timing(); synchronises."""
+        out = {"local_ms": 0.0, "exchange_ms": 0.0, "merge_ms": 0.0, "searches": 0}
+        if not self._events:
+            return out
+        torch.cuda.synchronize()
+        for e0, e1, e2, e3 in self._events:
+            out["local_ms"] += e0.elapsed_time(e1)
+            out["exchange_ms"] += e1.elapsed_time(e2)
+            out["merge_ms"] += e2.elapsed_time(e3)
+            out["searches"] += 1
+        return out
+
+    def _mark(self, q):
+        if self._events is None or q.device.type != "cuda":
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
 
     @classmethod
     def from_device_index(cls, index, row0: int, n_total: int, group=None):
@@ -71,12 +97,16 @@ class ShardedSearcher:
         world = dist.get_world_size(self.group) if dist.is_initialized() else 1
         k_local = min(k, self.n_local)
         B = q.shape[0]
+        e0 = self._mark(q)
         if k_local > 0:
             ids, scores = self.local_search(q, k_local, self.row0)
         else:
             ids = torch.empty((B, 0), dtype=torch.int64, device=q.device)
             scores = torch.empty((B, 0), dtype=torch.float32, device=q.device)
+        e1 = self._mark(q)
         if world == 1 and not self.force_exchange:
+            if e0 is not None:
+                self._events.append((e0, e1, e1, e1))
             return ids, scores
         if k_local < k:                      # pad so that every rank contributes exactly k slots
             pad = k - k_local
@@ -89,5 +119,9 @@ class ShardedSearcher:
         gathered = torch.empty((world * B, k), dtype=torch.int64, device=packed.device)   # rank-major concatenation
         dist.all_gather_into_tensor(gathered, packed, group=self.group)        # the one exchange step
         gathered = gathered.to(dev)
+        e2 = self._mark(q)
         cand_ids, cand_scores = unpack_candidates(gathered.view(world, B, k).permute(1, 0, 2).reshape(B, world * k).contiguous())
-        return self.merge(cand_ids.contiguous(), cand_scores.contiguous(), k)
+        out = self.merge(cand_ids.contiguous(), cand_scores.contiguous(), k)
+        if e0 is not None:
+            self._events.append((e0, e1, e2, self._mark(q)))
+        return out

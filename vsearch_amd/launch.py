@@ -32,8 +32,10 @@ def rank_env(rank: int, world: int, port: int, base: Optional[Dict[str, str]] = 
     env.update({
         "RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_WORLD_SIZE": str(world),
         "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
-        "HSA_ENABLE_IPC_MODE_LEGACY": "0",            # dmabuf IPC: RCCL needs it on this host driver
     })
+    # dmabuf IPC between the ranks' GPUs (RCCL's peer buffers): the build / GPU images of this project export it because their host
+    # driver has no legacy IPC (`hipIpcGetMemHandle: invalid argument` otherwise).  A DEFAULT only: a value the user has set stands.
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return env
 
 
@@ -44,34 +46,60 @@ def spawn_ranks(argv: Sequence[str], world: int, timeout_s: Optional[float] = No
     that a failed rank does not leave its peers waiting in a collective)."""
     if world < 1:
         raise ValueError("world must be >= 1")
+    import signal
     port = free_port()
     procs: List[subprocess.Popen] = []
-    for r in range(world):
-        env = rank_env(r, world, port)
-        if extra_env:
-            env.update(extra_env)
-        procs.append(subprocess.Popen(list(argv), env=env))
-    deadline = None if timeout_s is None else time.monotonic() + timeout_s
     rc = 0
-    live = set(range(world))
-    while live:
-        for r in sorted(live):
-            code = procs[r].poll()
-            if code is None:
-                continue
-            live.discard(r)
-            if code != 0 and rc == 0:
-                rc = code
-                for o in live:                          # exact PIDs we started, nothing else
-                    procs[o].terminate()
-        if deadline is not None and time.monotonic() > deadline and live:
-            for o in live:
-                procs[o].kill()
-            rc = rc or 124
-            deadline = None
-        if live:
-            time.sleep(0.05)
-    return rc
+    # SIGTERM / SIGINT to the parent reach the ranks (exact PIDs we started): a rank left behind holds its GPU and may sit in a collective
+    def forward(signum, _frame):
+        for p in procs:
+            if p.poll() is None:
+                p.send_signal(signum)
+    old = {}
+    try:
+        for sig in (signal.SIGTERM, signal.SIGINT):
+            try:
+                old[sig] = signal.signal(sig, forward)
+            except ValueError:                          # not the main thread: no handlers, the finally below still cleans up
+                pass
+        for r in range(world):
+            env = rank_env(r, world, port)
+            if extra_env:
+                env.update(extra_env)
+            procs.append(subprocess.Popen(list(argv), env=env))
+        deadline = None if timeout_s is None else time.monotonic() + timeout_s
+        live = set(range(world))
+        while live:
+            for r in sorted(live):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                live.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for o in live:                      # exact PIDs we started, nothing else
+                        procs[o].terminate()
+            if deadline is not None and time.monotonic() > deadline and live:
+                for o in live:
+                    procs[o].kill()
+                rc = rc or 124
+                deadline = None
+            if live:
+                time.sleep(0.05)
+        return rc
+    finally:
+        # an exception or KeyboardInterrupt in the loop above: terminate, then kill, what is still running
+        alive = [p for p in procs if p.poll() is None]
+        for p in alive:
+            p.terminate()
+        t_end = time.monotonic() + 5.0
+        for p in alive:
+            try:
+                p.wait(timeout=max(0.0, t_end - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+        for sig, h in old.items():
+            signal.signal(sig, h)
 
 
 def relaunch_as_ranks(world: int, script: str, args: Sequence[str]) -> None:
