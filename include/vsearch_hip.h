@@ -89,7 +89,9 @@ typedef struct vs_index_info_t {
     int64_t last_walk_postings; /* score terms (query weight x document value) the most recent walk accumulated: scatter-adds
                               * of posting lists + multiply-adds on the dense head strips                                 */
     int32_t head_columns;    /* columns of the blocked-postings copy kept as dense strips (option "postings_head")         */
-    int32_t reserved0;
+    int32_t postings_state;  /* the blocked-postings copy: 0 = not attempted yet, 1 = built, 2 = NOT built: no room in HBM (sparse
+                              * queries take the ~10x slower CSR scan), 3 = NOT built: a block holds more records than a directory
+                              * word addresses, 4 = not wanted (small / short-row index, or option "blocked_postings" = 0)          */
 } vs_index_info_t;
 
 /* ---- library ------------------------------------------------------------------------------- */
@@ -176,6 +178,12 @@ VS_API int  vs_index_info(const vs_index* index, vs_index_info_t* out);
  * pass; larger k takes several passes), else one query per pass with a dense fp32 query image;
  * 1 = always the latter.                                                                          */
 VS_API int  vs_index_set_queries_per_pass(vs_index* index, int qt);
+
+/* Builds NOW what the first sparse search would otherwise build inside the call (the blocked-postings copy: 0.5 s at 21 M docs):
+ * Index.move_to_device / load_index / build_index of the Python facade call it, so a user's first retrieve() pays nothing extra.
+ * Idempotent; indexes that get no copy return at once.  vs_index_info_t.postings_state tells what happened.  stream as in
+ * vs_index_search (NULL = blocking).                                                                                           */
+VS_API int  vs_index_prepare(vs_index* index, void* stream);
 
 /* Tuning / test options by name (no reference counterpart):
  *   "queries_per_pass"  as above

@@ -232,6 +232,25 @@ def test_binary_index_on_the_postings_walk(law):
         compare.compare_topk(o_ids, o_sc, got[0], got[1], rtol=RTOL)
 
 
+def test_prepare_builds_the_postings_copy_ahead_of_the_first_search():
+    """vs_index_prepare (the facade calls it from move_to_device / load_index): the copy exists before any search, and
+    vs_index_info_t.postings_state says why an index has none."""
+    idx = DeviceIndex.synthetic(0, 0, 20000, V, 768, 0, 0, nat.VS_F32)
+    assert idx.info().postings_state == 0 and idx.info().aux_bytes == 0
+    idx.prepare()
+    info = idx.info()
+    assert info.postings_state == 1 and info.aux_bytes > 0
+    ids, sc, info = _search(idx, oracle.synth_queries(1, 3), 10)
+    assert info.last_path == 3
+    small = DeviceIndex.synthetic(0, 0, 1000, V, 768, 0, 0, nat.VS_F32)
+    small.prepare()
+    assert small.info().postings_state == 4 and small.info().aux_bytes == 0
+    off = DeviceIndex.synthetic(0, 0, 20000, V, 768, 0, 0, nat.VS_F32)
+    off.set_option("blocked_postings", 0)
+    off.prepare()
+    assert off.info().postings_state == 4
+
+
 def test_large_k_leaves_the_filter():
     """k + margin beyond the candidate buffers: 'search after' passes of the CSR scan (lossy records) or the fp64 walk."""
     ip, ix, d = oracle.synth_csr(0, 0, 4000)

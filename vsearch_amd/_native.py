@@ -28,7 +28,7 @@ class IndexInfo(C.Structure):
                 ("device", C.c_int32), ("nnz", C.c_int64), ("n_packets", C.c_int64), ("device_bytes", C.c_int64),
                 ("bytes_per_pass", C.c_int64), ("lanes_per_row", C.c_int32), ("queries_per_pass", C.c_int32),
                 ("last_scan_bytes", C.c_int64), ("aux_bytes", C.c_int64), ("last_path", C.c_int32), ("last_fallbacks", C.c_int32),
-                ("last_walk_postings", C.c_int64), ("head_columns", C.c_int32), ("reserved0", C.c_int32)]
+                ("last_walk_postings", C.c_int64), ("head_columns", C.c_int32), ("postings_state", C.c_int32)]
 
 
 _vp, _i32, _i64, _int = C.c_void_p, C.c_int32, C.c_int64, C.c_int
@@ -49,6 +49,7 @@ _SIGNATURES = {
     "vs_index_create_synthetic": ([C.c_uint64, _i64, _i64, _i32, _i32, _int, _int, _int, _int, C.POINTER(_vp)], _int),
     "vs_index_search": ([_vp, _vp, _int, _i64, _i32, _i32, _i64, _vp, _vp, _vp], _int),
     "vs_index_scores": ([_vp, _vp, _int, _i64, _i32, _vp, _vp], _int),
+    "vs_index_prepare": ([_vp, _vp], _int),
     "vs_index_info": ([_vp, C.POINTER(IndexInfo)], _int),
     "vs_index_set_option": ([_vp, C.c_char_p, _int], _int),
     "vs_index_set_queries_per_pass": ([_vp, _int], _int),

@@ -6,6 +6,7 @@
 using namespace vs;
 
 int vs_csr_search(vs_index*, const void*, int, int64_t, int32_t, int32_t, int64_t, int64_t*, float*, hipStream_t);
+int vs_csr_prepare(vs_index*, hipStream_t);
 int vs_csr_scores(vs_index*, const void*, int, int64_t, int32_t, float*, hipStream_t);
 int vs_dense_search(vs_index*, const void*, int, int64_t, int32_t, int32_t, int64_t, int64_t*, float*, hipStream_t);
 int vs_dense_scores(vs_index*, const void*, int, int64_t, int32_t, float*, hipStream_t);
@@ -45,6 +46,14 @@ extern "C" int vs_index_search(vs_index* idx, const void* q, int q_dtype, int64_
     if (rc != VS_OK) return rc;
     if (!stream) VS_HIP(hipStreamSynchronize(s));
     if (Profiler::get().on) Profiler::get().drain();
+    return VS_OK;
+}
+
+extern "C" int vs_index_prepare(vs_index* idx, void* stream) {
+    if (!idx) return fail(VS_EINVAL, "NULL index");
+    VS_HIP(hipSetDevice(idx->device));
+    if (idx->kind == VS_KIND_CSR) VS_TRY(vs_csr_prepare(idx, (hipStream_t)stream));
+    if (!stream) VS_HIP(hipStreamSynchronize((hipStream_t)stream));
     return VS_OK;
 }
 

@@ -231,6 +231,7 @@ struct vs_index {
     int64_t last_plan_blocks = 0;
     int bp_rows = 2048;  // documents per block of the copy (picked at build time)
     bool bp_ready = false, bp_tried = false;
+    int bp_state = 0;    // vs_index_info_t.postings_state: 0 not attempted, 1 ready, 2 no HBM room, 3 directory overflow, 4 not wanted (small index / option)
     int64_t last_scan_bytes = 0;   // bytes the scan kernels of the most recent search had to read (algorithmic, per path)
     int last_path = 0;             // 0 = one query per pass, 1 = 8-query CSR scan, 2 = blocked postings
     int bp_pref = -1;    // option "blocked_postings": -1 auto, 0 never, 1 always

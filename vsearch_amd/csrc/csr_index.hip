@@ -470,6 +470,7 @@ extern "C" int vs_index_info(const vs_index* idx, vs_index_info_t* o) {
     o->last_path = idx->last_path;
     o->last_walk_postings = idx->last_walk_postings;
     o->head_columns = idx->bp_ready ? idx->bp_n_head : 0;
+    o->postings_state = idx->bp_ready ? 1 : idx->bp_state;
     if (idx->last_path == 3 && idx->last_plan_dev) {               // the filter search keeps its plan on the device: read it now
         int64_t hp[6] = {0, 0, 0, 0, 0, 0};
         VS_HIP(hipSetDevice(idx->device));
@@ -830,6 +831,7 @@ int bp_build(vs_index* idx, hipStream_t s) {
         fprintf(stderr, "[vsearch_hip] blocked-postings copy not built: needs %.1f GB, %.1f GB of HBM free -- sparse queries use the CSR scan (3x slower)\n",
                 (double)need / 1e9, (double)free_b / 1e9);
         bp_release(idx);
+        idx->bp_state = 2;
         (void)hipGetLastError();
         return VS_OK;
     };
@@ -924,6 +926,7 @@ int bp_build(vs_index* idx, hipStream_t s) {
     if (h_ovf) {                                                        // (2048 documents x 29 523 columns, all present, would do it)
         fprintf(stderr, "[vsearch_hip] blocked-postings copy not built: a block holds more records than a directory word addresses -- sparse queries use the CSR scan\n");
         bp_release(idx);
+        idx->bp_state = 3;
         return VS_OK;
     }
     VS_STAGE("bp_vmax", s);
@@ -971,6 +974,16 @@ int bp_build(vs_index* idx, hipStream_t s) {
                 idx->bp_rows, (long long)n_blocks, n_rec, hb.size() > 1 ? hb[1] : 0ull, hb[n_blocks], (int)mono, (hd[V - 1] >> 12) << idx->bp_al_shift, hb[n_blocks] - hb[n_blocks - 1], (int)dmono);
     }
     idx->bp_ready = true;
+    idx->bp_state = 1;
+    return VS_OK;
+}
+
+// Builds the blocked-postings copy NOW when this index would get one at its first sparse search (vs_index_prepare: the 0.5 s of a
+// 21 M-doc build then belong to load / move_to_device, not to a user's first retrieve).  Idempotent.
+int csr_prepare_impl(vs_index* idx, hipStream_t s) {
+    if (idx->kind != VS_KIND_CSR || idx->qt_pref == 1) return VS_OK;
+    if (!bp_wanted(idx)) { if (!idx->bp_ready) idx->bp_state = 4; return VS_OK; }
+    if (!idx->bp_ready && !idx->bp_tried) VS_TRY(bp_build(idx, s));
     return VS_OK;
 }
 
@@ -1431,6 +1444,8 @@ int mq_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64_t id_o
 
 }  // namespace
 
+int vs_csr_prepare(vs_index* idx, hipStream_t s) { return csr_prepare_impl(idx, s); }
+
 int vs_csr_search(vs_index* idx, const void* q, int q_dtype, int64_t ldq, int32_t B, int32_t k, int64_t id_offset,
                   int64_t* out_ids, float* out_scores, hipStream_t s) {
     const float* dq = nullptr;
@@ -1455,6 +1470,7 @@ int vs_csr_search(vs_index* idx, const void* q, int q_dtype, int64_t ldq, int32_
     idx->last_path = 0;
     if (idx->qt_pref != 1) {
         if (!idx->bp_ready && !idx->bp_tried && bp_wanted(idx)) VS_TRY(bp_build(idx, s));
+        if (!idx->bp_ready && !idx->bp_tried) idx->bp_state = 4;
         bool done = false;
         // k > kMaxKMq: "search after" passes of kMaxKMq ranks each (the k-th key of a pass is the next pass's exclusive
         // upper bound); large batches are cut so that the candidate scratch stays bounded

@@ -154,6 +154,11 @@ class DeviceIndex:
         return cls(h)
 
     # ---- lifetime -------------------------------------------------------------------------------
+    def prepare(self):
+        """Build now what the first sparse search would build inside the call (vs_index_prepare)."""
+        nat.check(nat.lib().vs_index_prepare(self._h, None))
+        return self
+
     def close(self):
         if self._h is not None and self._h.value:
             nat.lib().vs_index_destroy(self._h)

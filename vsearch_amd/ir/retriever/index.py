@@ -94,6 +94,7 @@ class Index:
         self._dtype = dtype
         self._shape = (int(info.n_rows), int(info.n_cols))
         self.device = device or f"cuda:{info.device}"
+        self._prepare()
 
     def _export_vector(self):
         mat = self._dev.export_dense(np.float16 if self._dtype == torch.float16 else np.float32)
@@ -112,9 +113,18 @@ class Index:
         return DeviceIndex.from_dense(v.contiguous(), store_dtype=store, device=_gpu_ordinal(self.device),
                                       max_density=self.DENSE_AS_CSR_DENSITY)
 
+    # The column-grouped copy sparse queries are searched on is built when the index reaches the device (move_to_device, load_index,
+    # build_index) -- 0.5 s at 21 M docs that would otherwise sit inside a user's first retrieve().
+    EAGER_POSTINGS = True
+
+    def _prepare(self):
+        if self._dev is not None and self.EAGER_POSTINGS:
+            self._dev.prepare()
+
     def _device_index(self) -> DeviceIndex:
         if self._dev is None:
             self._dev = self._build_device_index()
+            self._prepare()
         return self._dev
 
     # ---- loading -------------------------------------------------------------------------------
@@ -258,12 +268,10 @@ class SparseIndex(Index):
             data = data.float()
         if isinstance(data, np.ndarray) and data.dtype not in (np.float32, np.float16):
             data = data.astype(np.float32)
-        if self._binary():
-            ok = bool((data == 1).all())
-            if not ok:
-                raise ValueError("BoTIndex expects a binary matrix (every stored value == 1)")
-            store, data = nat.VS_NONE, None
+        if self._binary() and bool((data == 1).all()):
+            store, data = nat.VS_NONE, None                          # ids only: 2 bytes per non-zero, integer-exact scores
         else:
+            # (a BoTIndex over a VALUED matrix: the reference searches it like any sparse index, index.py:205-218 -- so do we)
             store = nat.VS_F16 if self._dtype == torch.float16 else nat.VS_F32
         return DeviceIndex.from_csr(indptr, indices, data, shape[1], store_dtype=store, device=_gpu_ordinal(self.device))
 
@@ -291,12 +299,13 @@ class SparseIndex(Index):
             self._drop_device()
             self._vector = None
             self._dev = DeviceIndex.load_native(files[0], device=_gpu_ordinal(self.device))
+            self._prepare()
             info = self._dev.info()
             # the file holds the device format verbatim: it must be the kind of index this class searches
             if info.kind != nat.VS_KIND_CSR:
                 self._drop_device()
                 raise ValueError(f"{files[0]} holds a dense index (sparsity-aware dense store): load it with Index, not {type(self).__name__}")
-            if self._binary() != (info.store_dtype == nat.VS_NONE):
+            if not self._binary() and info.store_dtype == nat.VS_NONE:   # (a BoTIndex may hold a valued matrix, like the reference's)
                 kind = "binary (bag-of-token)" if info.store_dtype == nat.VS_NONE else "valued"
                 self._drop_device()
                 raise ValueError(f"{files[0]} holds a {kind} index: it cannot be loaded as {type(self).__name__}")
@@ -334,23 +343,40 @@ class SparseIndex(Index):
         self._vector = None
         self._dtype = torch.float16 if fp16 else torch.float32
         self._shape = (rows_total, n_cols - self.shift)
-        store = nat.VS_NONE if self._binary() else (nat.VS_F16 if fp16 else nat.VS_F32)   # fp32 -> fp16 happens on the device
         logger.info("***** Converting Sparse index to the device CSR format *****")
+
         # pass 2: one shard at a time -- the reference's vstack(shards) (index.py:175) never exists on the host
-        dev = DeviceIndex.reserved(rows_total, packets_cap, n_cols - self.shift, store, device=_gpu_ordinal(self.device))
-        for f in files:
-            if native[f]:
-                dev.append_npz(f, self.shift)                       # file -> rows, no scipy object in between
-                continue
-            mat = load_npz(f).tocsr()[:, self.shift:]
-            mat.sort_indices()
-            data = mat.data.astype(np.float32, copy=False)
-            if self._binary():
-                if not bool((data == 1).all()):
-                    raise ValueError("BoTIndex expects a binary matrix (every stored value == 1)")
-                data = None
-            dev.append_csr(mat.indptr, mat.indices, data)
+        def convert(store):
+            dev = DeviceIndex.reserved(rows_total, packets_cap, n_cols - self.shift, store, device=_gpu_ordinal(self.device))
+            for f in files:
+                if native[f]:
+                    dev.append_npz(f, self.shift)                   # file -> rows, no scipy object in between
+                    continue
+                mat = load_npz(f).tocsr()[:, self.shift:]
+                mat.sort_indices()
+                data = mat.data.astype(np.float32, copy=False)
+                if store == nat.VS_NONE:
+                    if not bool((data == 1).all()):
+                        dev.close()
+                        raise ValueError("BoTIndex expects a binary matrix (every stored value == 1)")
+                    data = None
+                dev.append_csr(mat.indptr, mat.indices, data)
+            return dev
+
+        valued = nat.VS_F16 if fp16 else nat.VS_F32                  # fp32 -> fp16 happens on the device
+        if self._binary():
+            try:
+                dev = convert(nat.VS_NONE)
+            except ValueError as e:
+                if "binary matrix" not in str(e):
+                    raise
+                # shards with values other than 1: the reference's BoTIndex searches them like any sparse index (index.py:205-218)
+                logger.info("%s: the shards hold values other than 1 -- stored as a valued sparse index", type(self).__name__)
+                dev = convert(valued)
+        else:
+            dev = convert(valued)
         self._dev = dev
+        self._prepare()
 
     # -- persistence (index.py:181-202) --------------------------------------------------------------
     def save(self, path):

@@ -6,7 +6,8 @@ Deviations (supersets): ``retrieve(index=...)`` really use
 ``load_index`` accepts ``IndexType`` as well as ``str``; ``build_index(SPARSE)`` emits CSR batch by
 batch on the GPU instead of materialising the dense [N, V] matrix; the bag-of-token builder
 implements the intended per-document semantics for any batch size (upstream aliases batches).
-Training-time methods (``forward`` with negatives, ``retireve_negatives``) are out of scope.
+Training-time methods (``forward`` with negatives, ``retireve_negatives``: hard-negative mining for the training loop,
+retriever.py:150-205) are out of scope and absent.
 """
 from __future__ import annotations
 
@@ -70,36 +71,6 @@ class Retriever(BiEncoder):
         if rerank and index.index_type == IndexType.BAG_OF_TOKEN:
             results = self._rerank(index, q_emb, results, k, batch_size)
         return results
-
-    # ---- in-training hard negatives (retriever.py:150-206; the method name keeps the reference's spelling) ----
-    def retireve_negatives(self, q_emb: Union[np.ndarray, T], answers: List[List[str]], ret_neg_num: int = 1, ret_topk: int = 100,
-                           pool_size: int = 20, ret_dropout: float = 0, index: Index = None) -> List[List[str]]:
-        """Per query: search top-`ret_topk`, keep hits whose text contains none of the answers (first `pool_size` of them),
-        pad with random passages when fewer than `ret_neg_num` survive, sample `ret_neg_num` texts."""
-        import random
-
-        from ...inference.score.eval_wiki21m import _normalize, has_answer
-        index = self.index or index
-        assert index, "No index Found"
-        assert answers, "No answer strings Found"
-        ret_indices, _ = self.retrieve(q_emb, a=768, k=ret_topk, dropout=ret_dropout, index=index)
-        ret_indices = ret_indices.cpu().tolist() if isinstance(ret_indices, T) else np.asarray(ret_indices).tolist()
-        batch_neg_texts, pool_sizes = [], []
-        for sample_id, hits in enumerate(ret_indices):
-            pool = []
-            for doc in hits:
-                if not has_answer(answers[sample_id], index.data[doc], "string"):
-                    pool.append(doc)
-                if len(pool) >= pool_size:
-                    break
-            pool_sizes.append(len(pool))
-            if len(pool) < ret_neg_num:
-                pool += random.sample(range(len(index)), ret_neg_num - len(pool))
-            batch_neg_texts.append([_normalize(index.data[i]) for i in random.sample(pool, ret_neg_num)])
-        logger.debug("Retrieved %.1f negatives within batch (%d samples)", float(np.mean(pool_sizes)), len(ret_indices))
-        return batch_neg_texts
-
-    retrieve_negatives = retireve_negatives
 
     def _rerank(self, index: Index, q_emb: T, results: SearchResults, k: int, batch_size: int) -> SearchResults:
         """Re-embed the k hits with encoder_p, score against q, re-sort (retriever.py:137-147) -- on the device:
