@@ -556,6 +556,7 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
     const int64_t items = (int64_t)(a.n_tiles_dev ? a.n_tiles_dev[0] : a.n_tiles) * a.nchunk;
     const size_t dir_ld = (size_t)a.n_cols + 1;
 
+    const unsigned long long k_rt0 = a.timing ? __builtin_amdgcn_s_memrealtime() : 0ull;
     // Work items = (tile, chunk), taken round-robin (the host picks nchunk so that an XCD keeps to few chunks, see the launch)
     for (int64_t item = blockIdx.x; item < items; item += gridDim.x) {
         const int tile = (int)(item / a.nchunk), c = (int)(item % a.nchunk);
@@ -979,6 +980,12 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
 #pragma unroll
             for (int i = 0; i < 6; ++i) atomicAdd(a.timing + i, (unsigned long long)tacc[i]);
         }
+    }
+    if (a.timing && threadIdx.x == 0) {        // per workgroup: 100 MHz ticks, shader cycles, where it ran (XCC_ID, HW_ID)
+        a.timing[16 + 4 * blockIdx.x] = __builtin_amdgcn_s_memrealtime() - k_rt0;
+        a.timing[17 + 4 * blockIdx.x] = k_rt0;                       // (absolute start, 100 MHz ticks)
+        a.timing[18 + 4 * blockIdx.x] = (unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20);
+        a.timing[19 + 4 * blockIdx.x] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);
     }
 }
 

@@ -8,6 +8,7 @@
 #include "bp_flat.h"
 #include "bp_pipe.h"
 #include "bp_stream.h"
+#include "bp_bin.h"
 #include "synth_device.h"
 
 #include <algorithm>
@@ -781,6 +782,10 @@ int launch_bp_walk(const vs_index* idx, const BpArgs& a, int grid, int ent_cap, 
         // valued records, no dense strips, fixed-point filter: the flat walk (bp_flat.h)
         if (vm == VM_F32) { kern = bp_flat_topk<VM_F32, kFlRoundsF32, kBpRowsMax>; lds = bp_flat_lds_bytes<kFlRoundsF32, kBpRowsMax>(ent_cap); }
         else { kern = bp_flat_topk<VM_F16, kFlRoundsF16, kBpRowsMax>; lds = bp_flat_lds_bytes<kFlRoundsF16, kBpRowsMax>(ent_cap); }
+    } else if (vm == VM_BIN && AM == AM_FIX && idx->bp_walk_pref != 0 && !a.upper && ent_cap <= kBpEntCap) {
+        // bag-of-token index: the walk with the next block's records prefetched across the barrier (bp_bin.h); postings_walk = 0: the list walk
+        kern = bp_bin_topk<kBpRowsMaxBin>;
+        lds = bp_bin_lds_bytes<kBpRowsMaxBin>(ent_cap);
     } else if (vm == VM_BIN) {
         if (AM != AM_FIX) return fail(VS_EUNSUPPORTED, "binary postings serve the filter walk only");
         // one lane per list; the option picks the records in flight per lane = the size of the chunks dealt to the waves (8: 512
@@ -931,7 +936,7 @@ int bp_build(vs_index* idx, hipStream_t s) {
     }
     VS_STAGE("bp_vmax", s);
     const int RS = bp_rec_bytes(bp_record_vm(idx));
-    const size_t b_rec = ((size_t)n_rec + 1) * RS;                       // + one record: a lane past the last list's end re-reads "the record at the end"
+    const size_t b_rec = ((size_t)n_rec + 2) * RS;                       // + one record: a lane past the last list's end re-reads "the record at the end"
     VS_HIP(hipMemGetInfo(&free_b, &total_b));
     if (free_b < b_rec + margin || idx->bp_rec.alloc(b_rec) != VS_OK) return no_room(b_rec);
     idx->bp_records = (int64_t)n_rec;
@@ -1129,7 +1134,10 @@ int bp_filter_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64
     idx->last_plan_blocks = n_blocks;
     // lock-step window of the walk's work items (all walks; kernels ignore it when not every item is resident)
     static const int pace_env = getenv("VS_BP_PACE") ? atoi(getenv("VS_BP_PACE")) : -1;
-    const int pace_w = pace_env >= 0 ? pace_env : (idx->bp_pace >= 0 ? idx->bp_pace : 0);      // (off by default: it costs the list walk 10 %)
+    // (off by default for the list walk: it costs it 10 %; the bag-of-token walk of bp_bin.h runs ahead of its memory and
+    //  NEEDS it: free running 81 ms, window 16: 66.7, 32: 56.5, 48: 57.2, 64: 58.7, 128: 73 -- the list walk: 61.3)
+    const bool bin_walk = idx->store_dtype == VS_NONE && idx->bp_walk_pref != 0;
+    const int pace_w = pace_env >= 0 ? pace_env : (idx->bp_pace >= 0 ? idx->bp_pace : (bin_walk ? 32 : 0));
     if (pace_w > 0) {
         VS_TRY(idx->ws_pace.reserve((size_t)nchunk * a.blocks_per_chunk * 4));
         VS_HIP(hipMemsetAsync(idx->ws_pace.p, 0, (size_t)nchunk * a.blocks_per_chunk * 4, s));
@@ -1167,19 +1175,21 @@ int bp_filter_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64
         unsigned long long h[16] = {0};
         VS_HIP(hipMemcpyAsync(h, timing.p, 128, hipMemcpyDeviceToHost, s));
         VS_HIP(hipStreamSynchronize(s));
-        if (bp_flat_ok<AM_FIX>(idx, a)) {
+        {
             std::vector<unsigned long long> wg((size_t)grid * 4);
             VS_HIP(hipMemcpy(wg.data(), timing.as<unsigned long long>() + 16, wg.size() * 8, hipMemcpyDeviceToHost));
             double tmin = 1e30, tmax = 0, tsum = 0;
             double xs[8] = {0}, xc[8] = {0}, xn[8] = {0};
+            unsigned long long s_min = ~0ull, s_max = 0, e_max = 0;
             for (int i = 0; i < grid; ++i) {
                 const double t = (double)wg[4 * i] * 1e-5, cyc = (double)wg[4 * i + 1];       // ms
                 tmin = std::min(tmin, t); tmax = std::max(tmax, t); tsum += t;
                 const int x = (int)(wg[4 * i + 2] & 7);
                 xs[x] += t; xc[x] += cyc; xn[x] += 1;
+                s_min = std::min(s_min, wg[4 * i + 1]); s_max = std::max(s_max, wg[4 * i + 1]); e_max = std::max(e_max, wg[4 * i + 1] + wg[4 * i]);
             }
-            fprintf(stderr, "[vsearch_hip] flat walk: workgroup time min %.2f mean %.2f max %.2f ms;", tmin, tsum / grid, tmax);
-            for (int x = 0; x < 8; ++x) if (xn[x] > 0) fprintf(stderr, " xcc%d: %d wgs %.2f ms %.0f MHz;", x, (int)xn[x], xs[x] / xn[x], xc[x] / xs[x] * 1e-3);
+            fprintf(stderr, "[vsearch_hip] walk: workgroup time min %.2f mean %.2f max %.2f ms; starts spread over %.2f ms, first start -> last end %.2f ms;", tmin, tsum / grid, tmax,
+                    (double)(s_max - s_min) * 1e-5, (double)(e_max - s_min) * 1e-5);
             fprintf(stderr, "\n");
             if (getenv("VS_BP_TIMING_WG")) {
                 std::vector<int> ord(grid);
