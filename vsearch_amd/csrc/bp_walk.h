@@ -768,7 +768,9 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
                         if (li_n >= 0 && lu < NB && e < n_ent) nd[o] = dirb[ent[e].x & 0xFFFFu];
                     }
                     if (li < 0) {                                   // a dense chunk (the words fetched above wait in nd for the next list chunk)
+                        const long long t_d = a.timing ? (long long)__builtin_readcyclecounter() : 0;
                         dense_chunk(dense_before(cur));
+                        if (a.timing) { const uint32_t dt = (uint32_t)((long long)__builtin_readcyclecounter() - t_d); tacc[3] += dt; tacc[1] -= dt; }
                         cur = nxt;
                         nxt = grab(par);
                         continue;

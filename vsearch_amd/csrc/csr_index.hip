@@ -883,6 +883,8 @@ int bp_build(vs_index* idx, hipStream_t s) {
     // Head columns (skewed vocabularies): present in >= 1/4 of the documents -> dense strips instead of posting lists.  Valued
     // indexes with the filter search only (the strips hold fp16 values: the fp64 walk cannot use them).
     idx->bp_vmax_f = vmax_f;
+    static const int head_env = getenv("VS_BP_HEAD") ? atoi(getenv("VS_BP_HEAD")) : -2;           // (developer override of "postings_head")
+    if (head_env > -2) idx->bp_head_pref = head_env;
     if (idx->store_dtype != VS_NONE && idx->bp_filter != 0 && idx->bp_head_pref != 0 && idx->n_rows >= 4096 && lossy_ok && idx->bp_rows % 128 == 0 &&
         vmax_f >= 1.f / 64.f) {
         DevBuf nh;
@@ -1030,6 +1032,8 @@ int bp_choose_chunks(const vs_index* idx, int n_tiles, int64_t n_blocks, int pla
         nchunk = (int)std::min<int64_t>(best, n_blocks);
     }
     if (idx->bp_chunks > 0) nchunk = (int)std::min<int64_t>(idx->bp_chunks, n_blocks);
+    static const int chunks_env = getenv("VS_BP_CHUNKS") ? atoi(getenv("VS_BP_CHUNKS")) : 0;      // (developer override)
+    if (chunks_env > 0) nchunk = (int)std::min<int64_t>(chunks_env, n_blocks);
     return std::max(1, nchunk);
 }
 
