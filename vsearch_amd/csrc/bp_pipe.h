@@ -413,6 +413,9 @@ __global__ __launch_bounds__(kScanThreads) void bp_pipe_topk(BpArgs a) {
             tacc[5] += 1u;
             lap(1);
         }
+        // (the directory load issued for a block past the item's last is still in flight: wait with its register tied, or the register is
+        //  handed to something else and then overwritten by the late load)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(nd));
         // the end of the item: every epilogue but the last block's is done (a wave finishes the block it owes before it gets here);
         // the overflow check of block b1 - 2, then the last block's epilogue by all waves
         __syncthreads();
