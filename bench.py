@@ -166,18 +166,21 @@ def secondary(index, batches, args, local_rank, device, headline_s):
     from vsearch_amd.ir.retriever.index import SparseIndex
     out = {}
     B = args.batch
+    only = [x for x in os.environ.get("VS_BENCH_LEGS", "").split(",") if x]      # developer: run only these legs (facade,shards,C3,C5,zipf)
+    want = lambda name: not only or name in only
     # facade leg: Index.search of the reference's API (index.py:88-94) on the SAME device index
-    fac = SparseIndex()
-    fac.adopt_device_index(index, dtype=torch.float32)
-    t_direct = _timed(lambda: index.search(batches[0], args.k), 3)
-    t_facade = _timed(lambda: fac.search(batches[0], args.k), 3)
-    fac._dev = None                                               # (the bench owns the index)
-    out["facade"] = {"api": "vsearch_amd.ir.retriever.index.SparseIndex.search (reference: src/ir/retriever/index.py:88-94)", "ms_per_step": t_facade * 1e3,
-                     "device_index_ms_per_step": t_direct * 1e3, "overhead_frac": t_facade / t_direct - 1.0, "queries_per_sec": B / t_facade}
-    lat = {}
-    for b in (1, 32):
-        lat[f"B={b}_ms"] = _timed(lambda: index.search(batches[0][:b], args.k), 20, 3) * 1e3
-    out["latency_21m"] = lat
+    if want("facade"):
+        fac = SparseIndex()
+        fac.adopt_device_index(index, dtype=torch.float32)
+        t_direct = _timed(lambda: index.search(batches[0], args.k), 3)
+        t_facade = _timed(lambda: fac.search(batches[0], args.k), 3)
+        fac._dev = None                                               # (the bench owns the index)
+        out["facade"] = {"api": "vsearch_amd.ir.retriever.index.SparseIndex.search (reference: src/ir/retriever/index.py:88-94)", "ms_per_step": t_facade * 1e3,
+                         "device_index_ms_per_step": t_direct * 1e3, "overhead_frac": t_facade / t_direct - 1.0, "queries_per_sec": B / t_facade}
+        lat = {}
+        for b in (1, 32):
+            lat[f"B={b}_ms"] = _timed(lambda: index.search(batches[0][:b], args.k), 20, 3) * 1e3
+        out["latency_21m"] = lat
     index.close()
 
     def run(name, docs, nnz, kind, store, val_law, steps, exact=False, columns="uniform"):
@@ -217,6 +220,8 @@ def secondary(index, batches, args, local_rank, device, headline_s):
     # one process, 8 row shards of the same index on this one device (vs_shard_group_*: per-shard searches on their own streams, the
     # B * k pairs gathered and merged on the first shard's device): what the in-process sharding adds to 8 x the single-shard step
     try:
+        if not want("shards"):
+            raise KeyError("skipped")
         from vsearch_amd.device_index import ShardGroup
         from vsearch_amd.distributed import shard_rows
         t0 = time.perf_counter()
@@ -238,9 +243,11 @@ def secondary(index, batches, args, local_rank, device, headline_s):
             sh.close()
     except Exception as e:                                       # (never lose the headline line to a secondary leg)
         out["shard_group_8_on_one_gpu"] = {"error": str(e)[:200]}
-    run("C3_1m_sparse", 1_000_000, NNZ_DOC, 0, nat.VS_F32, 0, 10)
-    for leg in (lambda: run("C5_bot_21m", N_DOCS, 86, synth.KIND_BOT, nat.VS_NONE, synth.VAL_DYADIC, 5, exact=True),
-                lambda: run("zipf_21m", N_DOCS, NNZ_DOC, synth.KIND_SKEW, nat.VS_F32, 0, 3, columns="zipf")):
+    for name, leg in (("C3", lambda: run("C3_1m_sparse", 1_000_000, NNZ_DOC, 0, nat.VS_F32, 0, 10)),
+                      ("C5", lambda: run("C5_bot_21m", N_DOCS, 86, synth.KIND_BOT, nat.VS_NONE, synth.VAL_DYADIC, 5, exact=True)),
+                      ("zipf", lambda: run("zipf_21m", N_DOCS, NNZ_DOC, synth.KIND_SKEW, nat.VS_F32, 0, 3, columns="zipf"))):
+        if not want(name):
+            continue
         try:
             leg()
         except Exception as e:
