@@ -1,6 +1,6 @@
 #!/bin/bash
 # PMC passes over the postings walk (tools/probe_walk.py, 21 M docs, 1024 queries): one rocprofv3 run per counter group
-# (SQ: 8 counters per pass; TCC: 4), outputs under gpurun_out/pmc_walk/<group>/.  Usage on the GPU box: bash tools/pmc_walk.sh [docs] [tag] [groups: all | sq1,sq2,...]
+# (VS_PMC_PROBE=probe_bot.py VS_PMC_ARGS=" " : the bag-of-token walk instead) (SQ: 8 counters per pass; TCC: 4), outputs under gpurun_out/pmc_walk/<group>/.  Usage on the GPU box: bash tools/pmc_walk.sh [docs] [tag] [groups: all | sq1,sq2,...]
 DOCS=${1:-21015324}
 TAG=${2:-pmc_walk}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -9,7 +9,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 run() {
   name=$1; shift
-  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$name -- python3 $ROOT/tools/probe_filter.py $DOCS ${VS_PMC_B:-1024} 100 fp32 filter > $OUT/$name.log 2>&1
+  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$name -- python3 $ROOT/tools/${VS_PMC_PROBE:-probe_filter.py} $DOCS ${VS_PMC_B:-1024} ${VS_PMC_ARGS:-100 fp32 filter} > $OUT/$name.log 2>&1
 }
 ONLY=${3:-all}
 want() { [ "$ONLY" = all ] || echo ",$ONLY," | grep -q ",$1,"; }
@@ -23,4 +23,5 @@ run_if tcc1 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum
 run_if tcc2 TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_DRAM_sum TCC_TAG_STALL_sum TCC_BUSY_sum
 run_if ta1 TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_FLAT_READ_WAVEFRONTS_sum
 run_if grbm GRBM_GUI_ACTIVE GRBM_COUNT
+run_if fetch FETCH_SIZE
 ls -R $OUT | head -50

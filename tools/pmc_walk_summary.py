@@ -24,7 +24,7 @@ for f in sorted(glob.glob(os.path.join(root, "*", "**", "*counter_collection.csv
     for (d, c), v in per.items():
         if d == big:
             out[c] = v
-lines = [f"# rocprofv3 --pmc passes (tools/pmc_walk.sh), largest launch of {kern} ({shape}: tools/probe_filter.py under rocprofv3); sums over all XCDs/SEs"]
+lines = [f"# rocprofv3 --pmc passes (tools/pmc_walk.sh), largest launch of {kern} ({shape}: the probe of tools/pmc_walk.sh under rocprofv3); sums over all XCDs/SEs"]
 for c in sorted(out):
     lines.append(f"{c:44s} {out[c]:24.0f}")
 g = out.get

@@ -321,6 +321,9 @@ __global__ __launch_bounds__(kScanThreads) void bp_bin_topk(BpArgs a) {
         if (a.timing && lane == 0) {
 #pragma unroll
             for (int i = 0; i < 6; ++i) atomicAdd(a.timing + i, (unsigned long long)tacc[i]);
+            // wave 0 (thresholds, lock step) against a plain wave: walk and barrier wait
+            if (wv_id == 0) { atomicAdd(a.timing + 12, (unsigned long long)tacc[1]); atomicAdd(a.timing + 13, (unsigned long long)tacc[2]); }
+            if (wv_id == 8) { atomicAdd(a.timing + 14, (unsigned long long)tacc[1]); atomicAdd(a.timing + 15, (unsigned long long)tacc[2]); }
         }
     }
     if (a.timing && threadIdx.x == 0) {        // per workgroup: 100 MHz ticks, shader cycles, where it ran (XCC_ID, HW_ID)

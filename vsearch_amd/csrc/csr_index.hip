@@ -1212,6 +1212,11 @@ int bp_filter_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64
             fprintf(stderr, "[vsearch_hip] pipe walk chunk anatomy, wave-cycles per block and wave: produce %.0f, item round trip %.0f, first record %.0f, adds %.0f\n",
                     (double)h[8] / bw, (double)h[9] / bw, (double)h[10] / bw, (double)h[11] / bw);
         }
+        if (h[12] | h[14]) {
+            const double bw = (double)std::max<unsigned long long>(1, h[5]) / 16.0;
+            fprintf(stderr, "[vsearch_hip] binary walk, cycles per block: wave 0 walk %.0f wait %.0f; wave 8 walk %.0f wait %.0f\n", (double)h[12] / bw, (double)h[13] / bw,
+                    (double)h[14] / bw, (double)h[15] / bw);
+        }
         if (bp_flat_ok<AM_FIX>(idx, a)) {        // the flat walk has no dense part: slot 3 carries 100 MHz ticks
             fprintf(stderr, "[vsearch_hip] flat walk: shader clock %.0f MHz\n", 100.0 * (double)(h[0] + h[1] + h[2] + h[4]) / (double)std::max<unsigned long long>(1, h[3]));
             h[3] = 0;
