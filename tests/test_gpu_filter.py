@@ -210,18 +210,23 @@ def test_signed_values_and_weights():
     compare.check_topk_valid(allsc, got[0], got[1], rtol=RTOL)
 
 
+@pytest.mark.parametrize("nnz", [86, 600], ids=["short-lists", "long-lists"])
 @pytest.mark.parametrize("law", [synth.VAL_DYADIC, synth.VAL_GRID], ids=["dyadic", "fp32-weights"])
-def test_binary_index_on_the_postings_walk(law):
+def test_binary_index_on_the_postings_walk(law, nnz):
     """Bag-of-token index (no values): dyadic weights are exact in fixed point (nothing to prove, scores and ids bit-equal to the
-    oracle); arbitrary fp32 weights go through the refine step."""
-    n = 30_000
-    ip, ix, _ = oracle.synth_csr(3, 0, n, V, 86, synth.KIND_BOT)
+    oracle); arbitrary fp32 weights go through the refine step.  600 tokens a document: lists of ~40 postings, five records --
+    the walk's path for lists beyond the two prefetched records (bp_bin.h) on every list; and the list walk (postings_walk = 0)."""
+    n = 30_000 if nnz == 86 else 12_000
+    ip, ix, _ = oracle.synth_csr(3, 0, n, V, nnz, synth.KIND_BOT)
     q = oracle.synth_queries(8, 21, val_law=law)
     idx = DeviceIndex.from_csr(ip, ix, None, V)
     ref = _search(idx, q, 100, blocked_postings=0)
     got = _search(idx, q, 100, blocked_postings=1)
     assert got[2].last_path == 3 and got[2].aux_bytes > 0
     assert (got[0] == ref[0]).all() and (got[1] == ref[1]).all()
+    lw = _search(idx, q, 100, blocked_postings=1, postings_walk=0)
+    idx.set_option("postings_walk", -1)
+    assert lw[2].last_path == 3 and (lw[0] == ref[0]).all() and (lw[1] == ref[1]).all()
     forced = _search(idx, q, 100, blocked_postings=1, postings_force_fallback=1)
     assert forced[2].last_fallbacks == q.shape[0]
     assert (forced[0] == ref[0]).all() and (forced[1] == ref[1]).all()
