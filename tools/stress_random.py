@@ -16,7 +16,7 @@ for it in range(iters):
     kind = int(rng.choice([synth.KIND_VDR, synth.KIND_BOT, synth.KIND_SKEW]))
     store = nat.VS_NONE if kind == 1 else int(rng.choice([nat.VS_F32, nat.VS_F16]))
     n = int(rng.choice([5000, 9000, 30000, 70000, 150000]))
-    nnz = 86 if kind == 1 else int(rng.choice([300, 768]))
+    nnz = int(rng.choice([86, 86, 400])) if kind == 1 else int(rng.choice([300, 768]))
     B = int(rng.choice([1, 3, 8, 9, 40, 129]))
     k = int(rng.choice([1, 10, 100, 300]))
     opts = dict(postings_align=int(rng.choice([0, 1])), postings_lanes=int(rng.choice([0, 4, 8])), postings_rows=int(rng.choice([0, 512, 1024, 1920])),
