@@ -114,6 +114,32 @@ def parity_check(device, kind=0, nnz_doc=NNZ_DOC, store=0, val_law=0, expect_pat
             "ids_bit_exact": bool((np.asarray(ids) == o_ids).all()) if exact else None}
 
 
+def parity_sharded(world, rank, local_rank, device, kind=0, n=40_000):
+    """N > 1: the same check THROUGH the sharded path -- every rank holds its row range of a small synthetic index, the query batch
+    goes through ShardedSearcher.search (local search, the one all-gather, merge), and rank 0 compares the merged result with the
+    CPU oracle's over the whole index (rows regenerated on the host: a pure function of (seed, row id))."""
+    import oracle
+    from oracle import compare
+    from vsearch_amd.device_index import DeviceIndex
+    from vsearch_amd.distributed import ShardedSearcher, shard_rows
+    row0, n_loc = shard_rows(n, world, rank)
+    idx = DeviceIndex.synthetic(INDEX_SEED, row0, n_loc, V, NNZ_DOC, kind, 0, 0, local_rank)
+    searcher = ShardedSearcher.from_device_index(idx, row0, n)
+    q = oracle.synth_queries(QUERY_SEED, 8, V, NNZ_Q, 0, kind=kind)
+    ids, sc = searcher.search(torch.from_numpy(q).to(device), K)
+    ids, sc = ids.cpu().numpy(), sc.cpu().numpy()
+    path = idx.info().last_path
+    idx.close()
+    if rank != 0:
+        return None
+    ip, ix, d = oracle.synth_csr(INDEX_SEED, 0, n, V, NNZ_DOC, kind)
+    o_ids, o_sc, allsc = oracle.csr_search(ip, ix.astype(np.int32), d, V, q, K, acc64=True, return_all=True)
+    compare.check_topk_valid(allsc, ids, sc, rtol=1e-4)
+    rel = float(np.max(np.abs(sc.astype(np.float64) - o_sc) / np.abs(o_sc)))
+    return {"docs": n, "docs_per_rank": n_loc, "queries": 8, "ranks": world, "scan_path_rank0": path, "through": "ShardedSearcher.search (all-gather + merge)",
+            "recall_at_100_vs_oracle": compare.recall_at_k(o_ids, ids), "max_rel_score_err": rel}
+
+
 def cpu_baseline(sample_docs, device, kind=0):
     """The reference's Index.search (index.py:89-92: cast, torch.matmul(q, csr.t()), topk) restated in
     oracle/torch_ref.py and timed on this box's host cores on a bounded sample of the same index."""
@@ -342,6 +368,8 @@ def main():
         per_rank["by_rank"] = [{n: float(m[r, i]) for i, n in enumerate(names)} for r in range(world)]
     if rank == 0 and args.dump_ids:
         np.savez(args.dump_ids, ids=ids.cpu().numpy(), scores=scores.cpu().numpy())
+    # N > 1: the oracle check through the sharded path (all ranks search, rank 0 compares); after the timed region
+    sharded_parity = parity_sharded(world, rank, local_rank, device, kind) if world > 1 else None
 
     if rank == 0:
         qps = args.steps * args.batch / elapsed
@@ -424,6 +452,8 @@ def main():
             "roofline": roofline,
         }
         line["roofline"]["kernel_source_hash"] = kernel_source_hash()
+        if world > 1:
+            line["parity"] = sharded_parity
         if world == 1:
             line["parity"] = parity_check(local_rank, kind, expect_path=info.last_path if n_local >= 20_000 and args.scan == "auto" else None)
             if not args.no_secondary and args.docs == N_DOCS and args.columns == "uniform" and args.scan == "auto":

@@ -324,6 +324,8 @@ def test_two_rank_bench_launch_on_one_gpu_equals_the_unsharded_search(tmp_path):
     assert line["n_gpus"] == 2 and line["exchange"]["world_size"] == 2 and line["exchange"]["process_group_backend"] == "gloo"
     pr = line["exchange"]["per_rank_ms_per_step"]
     assert len(pr["by_rank"]) == 2 and pr["walk_ms"]["max"] > 0 and pr["exchange_ms"]["max"] > 0 and pr["merge_ms"]["max"] > 0
+    par = line["parity"]                                             # the oracle check through the sharded path (all ranks search, rank 0 compares)
+    assert par["ranks"] == 2 and par["recall_at_100_vs_oracle"] == 1.0 and par["max_rel_score_err"] < 1e-4
     got = np.load(dump)
     idx = DeviceIndex.synthetic(bench.INDEX_SEED, 0, docs, V, bench.NNZ_DOC, 0, 0, nat.VS_F32)
     import torch
