@@ -199,8 +199,8 @@ VS_API int  vs_index_prepare(vs_index* index, void* stream);
  *   "postings_quant"    1 (default) = an fp32 index keeps fp16-rounded values in the postings copy (the filter only ranks
  *                       candidates; the refine step re-scores them from the fp32 CSR), 0 = fp32 values there too
  *   "postings_walk"     which kernel walks the postings for the filter: -1 / 0 = a list per 8-lane group (bp_walk.h, the default: the fastest
- *                       measured), 1 = flat per-wave worklists (bp_flat.h), 2 = flat worklists on two accumulator sets without block
- *                       barrier (bp_pipe.h), 3 = flat worklists with software-pipelined record loads (bp_stream.h).  All four return
+ *                       measured), 1 = flat per-wave worklists (bp_flat.h), 2 = the list walk on two accumulator sets without block
+ *                       barrier (bp_duo.h), 3 = flat worklists with software-pipelined record loads (bp_stream.h).  All four return
  *                       identical results; 1 - 3 are kept as measured experiments.  Valued indexes without head strips only.
  *   "postings_pace"     lock-step window of the walk's work items in blocks (-1 / 0 = free running, the default)
  *   "postings_arrange"  1 = bank-aware order inside each posting list at build time (off by default: no measured gain)

@@ -137,7 +137,7 @@ extern "C" int vs_index_set_option(vs_index* idx, const char* name, int value) {
         return VS_OK;
     }
     if (n == "postings_walk") {
-        if (value < -1 || value > 3) return fail(VS_EINVAL, "postings_walk: -1 = auto, 0 = a list per lane group, 1 = flat worklists, 2 = two accumulator sets, 3 = streamed flat walk");
+        if (value < -1 || value > 3) return fail(VS_EINVAL, "postings_walk: -1 = auto, 0 = a list per lane group, 1 = flat worklists, 2 = list walk on two accumulator sets, 3 = streamed flat walk");
         idx->bp_walk_pref = value;
         return VS_OK;
     }

@@ -6,9 +6,9 @@
 #include "bp_walk.h"
 #include "bp_refine.h"
 #include "bp_flat.h"
-#include "bp_pipe.h"
 #include "bp_stream.h"
 #include "bp_bin.h"
+#include "bp_duo.h"
 #include "synth_device.h"
 
 #include <algorithm>
@@ -756,7 +756,7 @@ void bp_release(vs_index* idx) {
 // binary index: filter walk only, one lane per (short) list
 constexpr int kFlRoundsF16 = 8, kFlRoundsF32 = 5;     // record loads in flight per lane (registers: 8 / 12 per record)
 // which walk serves the fixed-point filter of this index: 0 = a list per lane group (bp_walk.h), 1 = flat worklists (bp_flat.h),
-// 2 = flat worklists on two accumulator sets, no block barrier (bp_pipe.h), 3 = flat worklists, record loads software-pipelined (bp_stream.h)
+// 2 = the list walk on two accumulator sets, no block barrier (bp_duo.h), 3 = flat worklists, record loads software-pipelined (bp_stream.h)
 int bp_walk_kind(const vs_index* idx) {
     const bool can = idx->store_dtype != VS_NONE && idx->bp_n_head == 0 && idx->bp_max_block_recs < ((int64_t)1 << kFlRecBits) - 4096;
     if (!can) return 0;
@@ -764,21 +764,22 @@ int bp_walk_kind(const vs_index* idx) {
 }
 template <int AM>
 bool bp_flat_ok(const vs_index* idx, const BpArgs& a) { return AM == AM_FIX && !a.upper && bp_walk_kind(idx) >= 1; }
+// walk 2 (two accumulator sets, bp_duo.h) serves this call: 4 query slots per tile, K' within its candidate buffers
+bool bp_duo_ok(const vs_index* idx, int kp, const uint64_t* upper) { return bp_walk_kind(idx) == 2 && !upper && kp <= kDuoMaxK; }
 template <int QT, int AM>
 int launch_bp_walk(const vs_index* idx, const BpArgs& a, int grid, int ent_cap, hipStream_t s) {
     const int vm = bp_record_vm(idx);
     size_t lds = bp_lds_bytes<QT, AM, kBpRowsMax>(ent_cap, AM == AM_FIX ? a.n_head : 0);
     void (*kern)(BpArgs) = nullptr;
-    if (bp_flat_ok<AM>(idx, a) && bp_walk_kind(idx) == 3) {
+    if (AM == AM_FIX && bp_duo_ok(idx, a.k, a.upper) && ent_cap <= kDuoEntCap) {
+        if (vm == VM_F32) kern = bp_duo_topk<VM_F32, kBpNB, kBpRowsMax>;
+        else kern = bp_duo_topk<VM_F16, kBpNBWide, kBpRowsMax>;
+        lds = bp_duo_lds_bytes<kBpRowsMax>(ent_cap);
+    } else if (bp_flat_ok<AM>(idx, a) && bp_walk_kind(idx) == 3) {
         if (vm == VM_F32) kern = bp_stream_topk<VM_F32, 3, kBpRowsMax>;
         else kern = bp_stream_topk<VM_F16, 4, kBpRowsMax>;
         lds = bp_stream_lds_bytes<kBpRowsMax>(ent_cap);
-    } else if (bp_flat_ok<AM>(idx, a) && bp_walk_kind(idx) == 2) {
-        if (ent_cap > kPipeEntCap) return fail(VS_EINVAL, "pipelined walk: %d entries per tile, %d fit", ent_cap, kPipeEntCap);
-        if (vm == VM_F32) kern = bp_pipe_topk<VM_F32, 5, kBpRowsMax>;
-        else kern = bp_pipe_topk<VM_F16, 7, kBpRowsMax>;
-        lds = bp_pipe_lds_bytes<kBpRowsMax>(ent_cap);
-    } else if (bp_flat_ok<AM>(idx, a)) {
+    } else if (bp_flat_ok<AM>(idx, a) && bp_walk_kind(idx) != 2) {
         // valued records, no dense strips, fixed-point filter: the flat walk (bp_flat.h)
         if (vm == VM_F32) { kern = bp_flat_topk<VM_F32, kFlRoundsF32, kBpRowsMax>; lds = bp_flat_lds_bytes<kFlRoundsF32, kBpRowsMax>(ent_cap); }
         else { kern = bp_flat_topk<VM_F16, kFlRoundsF16, kBpRowsMax>; lds = bp_flat_lds_bytes<kFlRoundsF16, kBpRowsMax>(ent_cap); }
@@ -1051,9 +1052,11 @@ int bp_filter_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64
                      hipStream_t s, bool* done, int32_t out_ld) {
     const int V = idx->n_cols;
     const int kp = k + std::max(28, k / 4);
-    const int qt = idx->store_dtype == VS_NONE ? kBpBinQT : (bp_walk_kind(idx) == 2 ? kPipeQT : kQT);
+    const bool duo = bp_duo_ok(idx, kp, nullptr);
+    static const int qt_env = getenv("VS_BP_QT") ? atoi(getenv("VS_BP_QT")) : 0;                       // (developer: smaller tiles on the 8-slot walk)
+    const int qt = qt_env > 0 ? std::min(qt_env, kQT) : idx->store_dtype == VS_NONE ? kBpBinQT : (duo ? kDuoQT : kQT);
     // (dense strips: their weight matrix takes 16 KB of the LDS the entries would use)
-    const int vals_cap = std::min(mq_vals_cap(idx), bp_walk_kind(idx) == 2 ? kPipeEntCap : (idx->bp_n_head > 0 ? kBpEntCap - 512 : kBpEntCap));
+    const int vals_cap = std::min(mq_vals_cap(idx), duo ? kDuoEntCap : (idx->bp_n_head > 0 ? kBpEntCap - 512 : kBpEntCap));
     const int64_t qcap = (int64_t)B * vals_cap;                               // bound of the batch's (query, column) entries that enter a tile
     const int64_t n_blocks = ceil_div64(idx->n_rows, idx->bp_rows);
     if (idx->bp_rows > (idx->store_dtype == VS_NONE ? kBpRowsMaxBin : kBpRowsMax)) return fail(VS_EINVAL, "postings_rows beyond the walk's block capacity");
@@ -1206,11 +1209,6 @@ int bp_filter_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64
                             (hw >> 13) & 7, (hw >> 12) & 1, (hw >> 8) & 15, (hw >> 4) & 3);
                 }
             }
-        }
-        if (bp_walk_kind(idx) == 2) {
-            const double bw = (double)std::max<unsigned long long>(1, h[5]);
-            fprintf(stderr, "[vsearch_hip] pipe walk chunk anatomy, wave-cycles per block and wave: produce %.0f, item round trip %.0f, first record %.0f, adds %.0f\n",
-                    (double)h[8] / bw, (double)h[9] / bw, (double)h[10] / bw, (double)h[11] / bw);
         }
         if (h[12] | h[14]) {
             const double bw = (double)std::max<unsigned long long>(1, h[5]) / 16.0;
