@@ -422,6 +422,25 @@ def test_dense_index_large_k_multipass():
         compare.check_topk_valid(want.astype(np.float32), ids, sc, exact=True, canonical=True)
 
 
+def test_dense_index_tail_split_along_k():
+    """Dense index whose documents leave a few 128-document tiles after the full rounds of the grid (66 000 docs, B = 130: 1024
+    tiles in two rounds + 8): those are split along K over the idle slots and their partial sums added in slice order
+    (launch_dense_scores).  Scores of main and tail documents against an fp64 matmul; the integer-valued matrix makes every sum
+    exact, so ids and scores must be THE top-k whatever the summation order."""
+    import torch
+    n, v, b = 66_000, 2048, 130
+    g = torch.Generator(device="cuda").manual_seed(11)
+    mat = torch.randint(0, 8, (n, v), device="cuda", generator=g).float() / 4
+    q = torch.randint(0, 4, (b, v), device="cuda", generator=g).float() / 2
+    idx = DeviceIndex.from_dense(mat)
+    want = (q.double() @ mat.double().t()).float().cpu().numpy()
+    for k in (1, 100):
+        ids, sc = idx.search(q, k)
+        compare.check_topk_valid(want, ids.cpu().numpy(), sc.cpu().numpy(), exact=True, canonical=True)
+    allsc = idx.scores(q)
+    assert (np.asarray(allsc.cpu() if hasattr(allsc, "cpu") else allsc) == want).all()
+
+
 def _zipf_csr(rng, n, nnz, s, perm, binary=False, dyadic=False):
     """Rows with Zipf(s) column popularity, distinct sorted columns (numpy; the popular columns end up in most rows)."""
     w = 1.0 / np.arange(1, V + 1) ** s

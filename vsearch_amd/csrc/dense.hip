@@ -57,10 +57,12 @@ __global__ void unpad_rows_kernel(const float* src, int32_t ldp, int64_t n_rows,
 // (multiple of 32) with zeros.  Two-level summation: chains inside 512-column blocks, block sums added to `tot`.
 constexpr int kDPitch = kDenseKC + 4;
 
-template <int WM, int WN, int TM, int TN>
+// SK = 1 (split-K, the tail of a search: launch_dense_scores): blockIdx.z picks a slice of `cps` K chunks (a multiple of 16: whole
+// summation blocks); the block writes its partial sums to part[slice][B][n_tail] instead of keys / scores.
+template <int WM, int WN, int TM, int TN, int SK = 0>
 __global__ __launch_bounds__(256) void dense_scores_kernel(const float* __restrict__ Q, const float* __restrict__ P, int32_t B,
                                                            int64_t N, int64_t n_begin, int32_t ldp, uint64_t* keys, float* scores,
-                                                           int32_t pool_L, uint32_t* pool_out) {
+                                                           int32_t pool_L, uint32_t* pool_out, float* part, int32_t cps, int64_t n_tail) {
     // pool_L > 0: encoder-head mode (vdr.py:72-75).  Q = LayerNorm'ed hidden states [B * pool_L, ldp]; the block covers rows
     // of ONE sequence (blockIdx.y = sequence * l_tiles + l_tile); instead of scores it emits the column-wise max over the
     // sequence positions, as order keys merged with atomicMax (rows past the sequence end repeat its last row).
@@ -125,11 +127,13 @@ __global__ __launch_bounds__(256) void dense_scores_kernel(const float* __restri
         if constexpr (JB > 2) *reinterpret_cast<float4*>(Bs[buf] + wa + 64 * kDPitch) = rb2;           \
         if constexpr (JB > 3) *reinterpret_cast<float4*>(Bs[buf] + wa + 96 * kDPitch) = rb3;           \
     }
-    VS_DENSE_FETCH(0)
+    int c_lo = 0, c_hi = chunks;
+    if constexpr (SK != 0) { c_lo = (int)blockIdx.z * cps; c_hi = min(chunks, c_lo + cps); }      // (c_lo even: the buffer parity below holds)
+    VS_DENSE_FETCH(c_lo)
     VS_DENSE_STAGE(0)
-    VS_DENSE_FETCH(1)
+    VS_DENSE_FETCH(c_lo + 1)
     __syncthreads();
-    for (int c = 0; c < chunks; ++c) {
+    for (int c = c_lo; c < c_hi; ++c) {
         const float* a_rd = As[c & 1] + a_off;
         const float* b_rd = Bs[c & 1] + b_off;
 #pragma unroll
@@ -150,12 +154,12 @@ __global__ __launch_bounds__(256) void dense_scores_kernel(const float* __restri
                 }
         }
         // the other buffer was last read in iteration c-1 (every wave has passed that iteration's barrier)
-        if (c + 1 < chunks) {
+        if (c + 1 < c_hi) {
             if (c & 1) VS_DENSE_STAGE(0) else VS_DENSE_STAGE(1)
         }
         __syncthreads();
         VS_DENSE_FETCH(c + 2)
-        if ((c & 15) == 15 || c == chunks - 1) {
+        if ((c & 15) == 15 || c == c_hi - 1) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -190,15 +194,35 @@ __global__ __launch_bounds__(256) void dense_scores_kernel(const float* __restri
             for (int r = 0; r < 16; ++r) {
                 const int b = b_blk + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (b < B && n < N) {
-                    if (keys) keys[(size_t)b * N + n] = make_key(tot[i][j][r], (uint32_t)n);
-                    if (scores) scores[(size_t)b * N + n] = tot[i][j][r];
+                    if constexpr (SK != 0) {
+                        part[((size_t)blockIdx.z * B + b) * n_tail + (n - n_begin)] = tot[i][j][r];
+                    } else {
+                        if (keys) keys[(size_t)b * N + n] = make_key(tot[i][j][r], (uint32_t)n);
+                        if (scores) scores[(size_t)b * N + n] = tot[i][j][r];
+                    }
                 }
             }
         }
 }
 
-// Launch plan: full rounds of 128 x 128 blocks (2 co-resident per CU), then the remaining doc range with 32 x 128 blocks.
-int launch_dense_scores(const vs_index* idx, const float* dq, int B, int ldp, uint64_t* keys, float* scores, hipStream_t s) {
+// the slices' partial sums, added in slice order (a fixed order: results do not depend on the launch) -> keys / scores of the tail documents
+__global__ void splitk_reduce_kernel(const float* part, int32_t S, int32_t B, int64_t n_tail, int64_t n_begin, int64_t N, uint64_t* keys, float* scores) {
+    const int64_t total = (int64_t)B * n_tail;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / n_tail, t = i % n_tail;
+        float sum = part[i];
+        for (int z = 1; z < S; ++z) sum += part[(size_t)z * total + i];
+        const int64_t n = n_begin + t;
+        if (keys) keys[(size_t)b * N + n] = make_key(sum, (uint32_t)n);
+        if (scores) scores[(size_t)b * N + n] = sum;
+    }
+}
+
+// Launch plan: full rounds of 128 x 128 blocks (2 co-resident per CU); the remaining documents -- less than a round of blocks -- are
+// split along K over the idle slots (128 x 128 blocks on slices of whole 512-column summation blocks, partial sums added in slice
+// order), or, when K is too short to split, done by 32 x 128 blocks.  (C2, 100 k x 29 523, B = 256: 14 of 782 document tiles are
+// left after three rounds; as 112 quarter blocks they took 0.75 ms of 11.9.)
+int launch_dense_scores(vs_index* idx, const float* dq, int B, int ldp, uint64_t* keys, float* scores, hipStream_t s) {
     const int64_t N = idx->n_rows;
     const int64_t doc_tiles = ceil_div64(N, 128), q_tiles = ceil_div64(B, 128);
     const int64_t slots = (int64_t)idx->cu_count * 2;
@@ -207,13 +231,27 @@ int launch_dense_scores(const vs_index* idx, const float* dq, int B, int ldp, ui
     if (main_doc_tiles * 128 > N) main_doc_tiles = N / 128;
     if (main_doc_tiles > 0) {
         hipLaunchKernelGGL((dense_scores_kernel<2, 2, 2, 2>), dim3((unsigned)main_doc_tiles, (unsigned)q_tiles), dim3(256), 0, s, dq,
-                           idx->mat.as<float>(), B, N, (int64_t)0, ldp, keys, scores, 0, (uint32_t*)nullptr);
+                           idx->mat.as<float>(), B, N, (int64_t)0, ldp, keys, scores, 0, (uint32_t*)nullptr, (float*)nullptr, 0, (int64_t)0);
         VS_HIP(hipGetLastError());
     }
     const int64_t n_begin = main_doc_tiles * 128;
     if (n_begin < N) {
-        hipLaunchKernelGGL((dense_scores_kernel<1, 4, 1, 1>), dim3((unsigned)ceil_div64(N - n_begin, 128), (unsigned)ceil_div(B, 32)), dim3(256), 0, s,
-                           dq, idx->mat.as<float>(), B, N, n_begin, ldp, keys, scores, 0, (uint32_t*)nullptr);
+        const int64_t n_tail = N - n_begin, tail_tiles = ceil_div64(n_tail, 128) * q_tiles;
+        const int chunks = ldp / kDenseKC;
+        int S = (int)std::min<int64_t>(slots / std::max<int64_t>(tail_tiles, 1), chunks / 16);
+        if (main_doc_tiles > 0 && S >= 2) {
+            const int cps = ceil_div(ceil_div(chunks, S), 16) * 16;
+            S = ceil_div(chunks, cps);
+            VS_TRY(idx->ws_fb.reserve((size_t)S * B * n_tail * 4));
+            hipLaunchKernelGGL((dense_scores_kernel<2, 2, 2, 2, 1>), dim3((unsigned)ceil_div64(n_tail, 128), (unsigned)q_tiles, (unsigned)S), dim3(256), 0, s, dq,
+                               idx->mat.as<float>(), B, N, n_begin, ldp, (uint64_t*)nullptr, (float*)nullptr, 0, (uint32_t*)nullptr, idx->ws_fb.as<float>(), cps, n_tail);
+            VS_HIP(hipGetLastError());
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<int64_t>(ceil_div64((int64_t)B * n_tail, 256), 4096)), dim3(256), 0, s,
+                               (const float*)idx->ws_fb.as<float>(), S, B, n_tail, n_begin, N, keys, scores);
+        } else {
+            hipLaunchKernelGGL((dense_scores_kernel<1, 4, 1, 1>), dim3((unsigned)ceil_div64(n_tail, 128), (unsigned)ceil_div(B, 32)), dim3(256), 0, s,
+                               dq, idx->mat.as<float>(), B, N, n_begin, ldp, keys, scores, 0, (uint32_t*)nullptr, (float*)nullptr, 0, (int64_t)0);
+        }
         VS_HIP(hipGetLastError());
     }
     return VS_OK;
@@ -515,11 +553,11 @@ extern "C" int vs_head_project_pool(const float* hidden, const float* W, int32_t
         if (L > 64) {
             const int l_tiles = (L + 127) / 128;
             hipLaunchKernelGGL((dense_scores_kernel<2, 2, 2, 2>), dim3((unsigned)ceil_div64(V, 128), (unsigned)(B * l_tiles)), dim3(256), 0, s, hidden, W,
-                               B * L, (int64_t)V, (int64_t)0, H, (uint64_t*)nullptr, (float*)nullptr, L, keys.as<uint32_t>());
+                               B * L, (int64_t)V, (int64_t)0, H, (uint64_t*)nullptr, (float*)nullptr, L, keys.as<uint32_t>(), (float*)nullptr, 0, (int64_t)0);
         } else {
             const int l_tiles = (L + 31) / 32;
             hipLaunchKernelGGL((dense_scores_kernel<1, 4, 1, 1>), dim3((unsigned)ceil_div64(V, 128), (unsigned)(B * l_tiles)), dim3(256), 0, s, hidden, W,
-                               B * L, (int64_t)V, (int64_t)0, H, (uint64_t*)nullptr, (float*)nullptr, L, keys.as<uint32_t>());
+                               B * L, (int64_t)V, (int64_t)0, H, (uint64_t*)nullptr, (float*)nullptr, L, keys.as<uint32_t>(), (float*)nullptr, 0, (int64_t)0);
         }
     }
     VS_HIP(hipGetLastError());
