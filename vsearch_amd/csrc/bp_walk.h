@@ -73,7 +73,8 @@ __host__ __device__ inline uint32_t bp_dir_pack(uint32_t unit, uint32_t recs) { 
 template <int UNUSED>
 __global__ __launch_bounds__(kScanThreads) void bp_count_kernel(const uint32_t* pk_ptr, const uint4* cols, int64_t n_rows, int32_t n_cols, int32_t rows,
                                                                 uint32_t* dir, uint32_t* block_recs, unsigned long long* df_rec,
-                                                                unsigned long long* df_nnz, const uint16_t* hmap, int32_t al_shift, int32_t* overflow) {
+                                                                unsigned long long* df_nnz, const uint16_t* hmap, int32_t al_shift, int32_t* overflow,
+                                                                int32_t cell_shift) {          // postings per record: 2^cell_shift (8; quad chunks, bp_quad.h: 64)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint32_t* cnt = reinterpret_cast<uint32_t*>(smem);                  // [n_cols + 1]
     __shared__ int scratch[32];
@@ -100,7 +101,8 @@ __global__ __launch_bounds__(kScanThreads) void bp_count_kernel(const uint32_t* 
         __syncthreads();
         const int i0 = tid * seg, i1 = min(n_cols + 1, i0 + seg);
         // (head columns -- hmap[c] != 0xFFFF -- live in the dense strips: no records, empty lists)
-        auto recs_of = [&](int i) -> uint32_t { return (hmap && i < n_cols && hmap[i] != 0xFFFFu) ? 0u : (cnt[i] + 7u) >> 3; };
+        const uint32_t cell_mask = (1u << cell_shift) - 1u;
+        auto recs_of = [&](int i) -> uint32_t { return (hmap && i < n_cols && hmap[i] != 0xFFFFu) ? 0u : (cnt[i] + cell_mask) >> cell_shift; };
         // a list starts on a multiple of 2^al_shift records: the scan runs in those units
         const uint32_t al_mask = (1u << al_shift) - 1u;
         int mine = 0;
@@ -421,6 +423,7 @@ struct BpArgs {
     const __half* strip;      // fp16 values of the head columns, MFMA operand order (bp_strip_index)
     int32_t n_head;
     float head_pre, head_mul; // powers of two: weights enter the fp16 operand as w * scale * head_pre (< 2^15), the sums leave as C * head_mul
+    uint2* gent;              // quad walk (bp_quad.h): [grid][kBpEntCap] scratch, the work item's sorted entries
     uint32_t* pace;           // optional [nchunk][blocks_per_chunk], zeroed per search: work items that have finished a block (flat walk: lock-step window)
     int32_t pace_window;      // blocks an item may run ahead of the slowest item of its chunk
     int32_t knob;             // developer switches (VS_BP_KNOB)
@@ -809,7 +812,15 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
                     // the 8 postings of one record into the accumulators of slot / weight `e`
                     auto add_record = [&](const u32x4& idv, const u32x4& vav, const u32x4& vbv, const uint2 e) {
                         const float wq = __uint_as_float(e.y);
-                        const uint32_t so = (e.x >> 16) + lds0;                     // LDS byte address of [document 0][slot]
+                        uint32_t so = (e.x >> 16) + lds0;                           // LDS byte address of [document 0][slot]
+                        uint32_t pitchb = PITCHB;
+#ifdef VS_BP_EXPERIMENT
+                        // throw-away build #4 (WRONG results on purpose): every 32-lane half of a ds_add hits 32
+                        // different banks (lane -> bank, the slot picks the row), same instruction stream
+                        if (a.knob & 16) { pitchb = 0u; so = lds0 + (e.x >> 16) * 32u + (uint32_t)(tid & 31) * 4u; }
+                        // ... at most 2 lanes of a half per bank
+                        if (a.knob & 32) { pitchb = 0u; so = lds0 + (e.x >> 16) * 32u + (uint32_t)(tid & 15) * 4u + (uint32_t)(tid & 16) * 64u; }
+#endif
                         const uint32_t dw[4] = {idv.x, idv.y, idv.z, idv.w};
                         float vv[8];
                         if constexpr (VM == VM_F32) {
@@ -832,7 +843,7 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
                         if constexpr (VM == VM_BIN && AM == AM_F64) wd = (double)wq;
 #pragma unroll
                         for (int t = 0; t < 8; ++t) {
-                            const uint32_t off = (t & 1) ? acc_off_hi(dw[t >> 1], PITCHB, so) : acc_off_lo(dw[t >> 1], PITCHB, so);
+                            const uint32_t off = (t & 1) ? acc_off_hi(dw[t >> 1], pitchb, so) : acc_off_lo(dw[t >> 1], pitchb, so);
                             if constexpr (VM == VM_BIN) {
                                 // (pad postings of a binary list carry document id RMAX: the scratch row behind the accumulators)
                                 if constexpr (AM == AM_FIX) lds_add(off, wi);

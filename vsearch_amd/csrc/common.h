@@ -237,7 +237,9 @@ struct vs_index {
     int bp_pref = -1;    // option "blocked_postings": -1 auto, 0 never, 1 always
     int bp_rows_pref = 0;// option "postings_rows": 0 = auto, else documents per block (multiple of 64, 256..2048); applies at the next build
     int bp_chunks = 0;   // option "postings_chunks": 0 = auto, else block runs per tile on the postings path
-    int bp_walk_pref = -1;   // option "postings_walk": -1 auto (= 0 until the flat walk wins), 0 = one list per lane group (bp_walk.h), 1 = flat worklists (bp_flat.h), 2 = list walk on two accumulator sets (bp_duo.h), 3 = streamed flat walk (bp_stream.h)
+    int bp_walk_pref = -1;   // option "postings_walk": -1 auto (= 4 where it applies, else 0), 4 = quad chunks (bp_quad.h), 0 = one list per lane group (bp_walk.h), 1 = flat worklists (bp_flat.h), 2 = list walk on two accumulator sets (bp_duo.h), 3 = streamed flat walk (bp_stream.h)
+    bool bp_quad = false;       // bp_rec holds quad chunks (bp_quad.h): 64-cell chunks of one-dword postings; dir / base count chunks
+    bool bp_no_quad = false;    // bp_build restarting itself without quad chunks (head columns found): consumed by the next bp_build
     int bp_arrange_pref = -1;   // option "postings_arrange": 1 = bank-aware order inside the lists (bp_arrange_kernel), -1 / 0 = as filled
     int bp_pace = -1;        // option "postings_pace": blocks a work item may run ahead of the slowest item of its chunk (-1 auto, 0 = free running)
     int64_t bp_max_block_recs = 0;   // records of the fullest block (the flat walk's items address 2^19)
@@ -245,7 +247,7 @@ struct vs_index {
     // dense
     vs::DevBuf mat;      // [n_rows, n_cols] store_dtype
     // scratch owned by the handle (grow-only)
-    vs::DevBuf ws_q, ws_cand, ws_out_ids, ws_out_scores, ws_misc, ws_mq_meta, ws_mq_q, ws_mq_cand, ws_fb, ws_pace;
+    vs::DevBuf ws_q, ws_cand, ws_out_ids, ws_out_scores, ws_misc, ws_mq_meta, ws_mq_q, ws_mq_cand, ws_fb, ws_pace, ws_gent;
     bool logical_dense = false;   // dense Index stored as CSR packets (sparsity-aware dense index)
     int qt_pref = 0;     // 0 = auto (multi-query pass when the batch qualifies), 1 = force the dense-image pass
     int last_qt = 0;     // queries per pass of the most recent search

@@ -9,6 +9,7 @@
 #include "bp_stream.h"
 #include "bp_bin.h"
 #include "bp_duo.h"
+#include "bp_quad.h"
 #include "synth_device.h"
 
 #include <algorithm>
@@ -749,6 +750,7 @@ void bp_release(vs_index* idx) {
     idx->bp_dir.release(); idx->bp_base.release(); idx->bp_rec.release(); idx->bp_df.release(); idx->bp_vmax.release();
     idx->bp_hmap.release(); idx->bp_strip.release();
     idx->bp_n_head = 0;
+    idx->bp_quad = false;
     idx->bp_ready = false;
 }
 
@@ -758,7 +760,7 @@ constexpr int kFlRoundsF16 = 8, kFlRoundsF32 = 5;     // record loads in flight 
 // which walk serves the fixed-point filter of this index: 0 = a list per lane group (bp_walk.h), 1 = flat worklists (bp_flat.h),
 // 2 = the list walk on two accumulator sets, no block barrier (bp_duo.h), 3 = flat worklists, record loads software-pipelined (bp_stream.h)
 int bp_walk_kind(const vs_index* idx) {
-    const bool can = idx->store_dtype != VS_NONE && idx->bp_n_head == 0 && idx->bp_max_block_recs < ((int64_t)1 << kFlRecBits) - 4096;
+    const bool can = !idx->bp_quad && idx->store_dtype != VS_NONE && idx->bp_n_head == 0 && idx->bp_max_block_recs < ((int64_t)1 << kFlRecBits) - 4096;
     if (!can) return 0;
     return idx->bp_walk_pref < 0 ? 0 : idx->bp_walk_pref;
 }
@@ -771,7 +773,12 @@ int launch_bp_walk(const vs_index* idx, const BpArgs& a, int grid, int ent_cap, 
     const int vm = bp_record_vm(idx);
     size_t lds = bp_lds_bytes<QT, AM, kBpRowsMax>(ent_cap, AM == AM_FIX ? a.n_head : 0);
     void (*kern)(BpArgs) = nullptr;
-    if (AM == AM_FIX && bp_duo_ok(idx, a.k, a.upper) && ent_cap <= kDuoEntCap) {
+    if (idx->bp_quad) {
+        // quad chunks (bp_quad.h): the fixed-point filter walk only
+        if (AM != AM_FIX || a.upper || ent_cap > kBpEntCap || !a.gent) return fail(VS_EUNSUPPORTED, "quad postings serve the filter walk only");
+        kern = a.timing ? bp_quad_topk<1> : bp_quad_topk<0>;
+        lds = quad_lds_bytes();
+    } else if (AM == AM_FIX && bp_duo_ok(idx, a.k, a.upper) && ent_cap <= kDuoEntCap) {
         if (vm == VM_F32) kern = bp_duo_topk<VM_F32, kBpNB, kBpRowsMax>;
         else kern = bp_duo_topk<VM_F16, kBpNBWide, kBpRowsMax>;
         lds = bp_duo_lds_bytes<kBpRowsMax>(ent_cap);
@@ -817,10 +824,18 @@ int bp_build(vs_index* idx, hipStream_t s) {
     // a list is read by 8 lanes x 8 postings per round, and at 53 postings a list (2048 documents) 1 list in 15 needs a second
     // record per lane, at 50 (1920) 1 in 40: 152.2 vs 158.7 ms at 21 M docs (1792: 156.1) -- capped by what the accumulators
     // hold (2048) and kept a multiple of 128 (dense strips).  Binary index: 2048.
+    // Quad chunks (bp_quad.h) -- the default copy of a valued index searched by filter + refine: a list is cut into 64-cell chunks of
+    // one-dword postings (fp16 values).  Not for: a binary index; exact fp32 records ("postings_quant" = 0, signed / huge values);
+    // the fp64 walk ("postings_filter" = 0); a corpus with head columns (their dense strips belong to the list walk: bp_build starts
+    // over without quad when it finds any); the experimental walks 0 .. 3 ("postings_walk"), aligned or arranged records.
+    const bool quad_pref = idx->store_dtype != VS_NONE && idx->bp_filter != 0 && (idx->bp_walk_pref == -1 || idx->bp_walk_pref == 4) && !idx->bp_no_quad &&
+                           idx->bp_align_pref != 1 && idx->bp_arrange_pref != 1 && (idx->store_dtype == VS_F16 || idx->bp_quant_pref != 0);
+    idx->bp_no_quad = false;
     auto auto_rows = [&]() -> int {
         if (idx->store_dtype == VS_NONE) return kBpRowsMaxBin;
         const double avg = idx->n_rows > 0 ? (double)idx->nnz / (double)idx->n_rows : 1.0;
-        const int r = (int)(50.0 * (double)idx->n_cols / std::max(avg, 1.0)) / 128 * 128;
+        // (quad: ~ 54 postings a list -- 1 list in 15 spills into a second 64-cell chunk; 768-nnz documents: 2048)
+        const int r = (int)((quad_pref ? 54.0 : 50.0) * (double)idx->n_cols / std::max(avg, 1.0)) / 128 * 128;
         return std::max(256, std::min(r, kBpRowsMax));
     };
     idx->bp_rows = idx->bp_rows_pref > 0 ? std::min(idx->bp_rows_pref, idx->store_dtype == VS_NONE ? kBpRowsMaxBin : kBpRowsMax)
@@ -869,6 +884,8 @@ int bp_build(vs_index* idx, hipStream_t s) {
     float vmax_f;
     memcpy(&vmax_f, &hv[0], 4);
     const bool lossy_ok = hv[1] == 0u && vmax_f < 60000.f;       // fp16 copies of the values: non-negative, no overflow
+    const bool quad = quad_pref && (idx->store_dtype == VS_F16 || lossy_ok);
+    const int cell_shift = quad ? 6 : 3;                          // postings per directory unit: a 64-cell chunk | an 8-posting record
     // Lossy filter copy of an fp32 index: values rounded to fp16 (4 instead of 6 bytes per posting); needs the filter-and-refine
     // search, non-negative values and no fp16 overflow
     idx->bp_quant = idx->store_dtype == VS_F32 && idx->bp_filter != 0 && idx->bp_quant_pref != 0 && lossy_ok;
@@ -879,7 +896,7 @@ int bp_build(vs_index* idx, hipStream_t s) {
     VS_HIP(hipMemsetAsync(ovf.p, 0, 4, s));
     VS_HIP(hipFuncSetAttribute((const void*)bp_count_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(bp_count_kernel<0>, dim3(grid), dim3(kScanThreads), lds, s, idx->pk_ptr.as<uint32_t>(), idx->cols.as<uint4>(), idx->n_rows, V, idx->bp_rows,
-                       idx->bp_dir.as<uint32_t>(), block_recs.as<uint32_t>(), df_rec, df_nnz, (const uint16_t*)nullptr, idx->bp_al_shift, ovf.as<int32_t>());
+                       idx->bp_dir.as<uint32_t>(), block_recs.as<uint32_t>(), df_rec, df_nnz, (const uint16_t*)nullptr, idx->bp_al_shift, ovf.as<int32_t>(), cell_shift);
     VS_STAGE("bp_count", s);
     // Head columns (skewed vocabularies): present in >= 1/4 of the documents -> dense strips instead of posting lists.  Valued
     // indexes with the filter search only (the strips hold fp16 values: the fp64 walk cannot use them).
@@ -898,6 +915,10 @@ int bp_build(vs_index* idx, hipStream_t s) {
         VS_HIP(hipMemcpyAsync(&h_n, nh.p, 4, hipMemcpyDeviceToHost, s));
         VS_HIP(hipStreamSynchronize(s));
         idx->bp_n_head = h_n;
+        if (h_n > 0 && quad) {                                  // head columns: records + dense strips (the list walk)
+            idx->bp_no_quad = true;
+            return bp_build(idx, s);
+        }
         if (h_n > 0 && idx->bp_rows_pref <= 0 && idx->bp_rows < kBpRowsMax) {
             // a skewed corpus: its lists are long whatever the block size, and the dense strips and the per-block costs want the
             // largest blocks (zipf 21 M docs: 289 ms at 2048 documents per block, 301 at 1920) -- start over with those
@@ -909,7 +930,7 @@ int bp_build(vs_index* idx, hipStream_t s) {
             VS_HIP(hipMemsetAsync(idx->bp_df.p, 0, (size_t)V * 16, s));
             hipLaunchKernelGGL(bp_count_kernel<0>, dim3(grid), dim3(kScanThreads), lds, s, idx->pk_ptr.as<uint32_t>(), idx->cols.as<uint4>(), idx->n_rows, V,
                                idx->bp_rows, idx->bp_dir.as<uint32_t>(), block_recs.as<uint32_t>(), df_rec, df_nnz, (const uint16_t*)idx->bp_hmap.as<uint16_t>(),
-                               idx->bp_al_shift, ovf.as<int32_t>());
+                               idx->bp_al_shift, ovf.as<int32_t>(), cell_shift);
             VS_HIP(hipGetLastError());
             const size_t b_strip = (size_t)n_blocks * bp_head_pad(h_n) * idx->bp_rows * 2;
             VS_HIP(hipMemGetInfo(&free_b, &total_b));
@@ -938,13 +959,29 @@ int bp_build(vs_index* idx, hipStream_t s) {
         return VS_OK;
     }
     VS_STAGE("bp_vmax", s);
-    const int RS = bp_rec_bytes(bp_record_vm(idx));
+    const int RS = quad ? kQuadChunkBytes : bp_rec_bytes(bp_record_vm(idx));
     const size_t b_rec = ((size_t)n_rec + 2) * RS;                       // + one record: a lane past the last list's end re-reads "the record at the end"
     VS_HIP(hipMemGetInfo(&free_b, &total_b));
     if (free_b < b_rec + margin || idx->bp_rec.alloc(b_rec) != VS_OK) return no_room(b_rec);
     idx->bp_records = (int64_t)n_rec;
     VS_HIP(hipMemsetAsync(idx->bp_rec.p, 0, b_rec, s));                  // pad postings: document 0, value 0
-    {
+    if (quad) {
+        void (*fill)(const uint32_t*, const uint4*, const void*, int64_t, int32_t, int32_t, const uint32_t*, const unsigned long long*, uint32_t*) =
+            idx->store_dtype == VS_F32 ? quad_fill_kernel<VM_F32> : quad_fill_kernel<VM_F16>;
+        VS_HIP(hipFuncSetAttribute((const void*)fill, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(fill, dim3(grid), dim3(kScanThreads), lds, s, idx->pk_ptr.as<uint32_t>(), idx->cols.as<uint4>(), (const void*)idx->vals.p, idx->n_rows, V,
+                           idx->bp_rows, idx->bp_dir.as<uint32_t>(), idx->bp_base.as<unsigned long long>(), idx->bp_rec.as<uint32_t>());
+        VS_HIP(hipGetLastError());
+        VS_STAGE("quad_fill", s);
+        const size_t alds = (size_t)2 * 256 * (kQuadCells + 1) * 4;
+        VS_HIP(hipFuncSetAttribute((const void*)quad_arrange_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)alds));
+        hipLaunchKernelGGL(quad_arrange_kernel<0>, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div64((int64_t)n_rec, 256), (int64_t)idx->cu_count * 8))), dim3(256), alds, s,
+                           idx->bp_rec.as<uint32_t>(), n_rec);
+        VS_HIP(hipGetLastError());
+        VS_STAGE("quad_arrange", s);
+        idx->bp_quad = true;
+        idx->bp_quant = idx->store_dtype == VS_F32;                      // fp16-rounded values of an fp32 index: the refine step's bound accounts for them
+    } else {
         void (*fill)(const uint32_t*, const uint4*, const void*, int64_t, int32_t, int32_t, const uint32_t*, const unsigned long long*, char*, const uint16_t*, __half*, int32_t, int32_t) =
             idx->store_dtype == VS_F32 ? (idx->bp_quant ? bp_fill_kernel<VM_F32, VM_F16> : bp_fill_kernel<VM_F32, VM_F32>)
             : idx->store_dtype == VS_F16 ? bp_fill_kernel<VM_F16, VM_F16> : bp_fill_kernel<VM_BIN, VM_BIN>;
@@ -958,7 +995,7 @@ int bp_build(vs_index* idx, hipStream_t s) {
     VS_STAGE("bp_fill", s);
     // bank-aware order inside the lists (option "postings_arrange" = 1; off by default: 4 M docs, list walk 29.83 -> 29.58 ms for 55 ms more
     // build time -- the scatter-add's bank conflicts are not what the walk waits for)
-    if (idx->store_dtype != VS_NONE && idx->bp_arrange_pref == 1) {
+    if (!quad && idx->store_dtype != VS_NONE && idx->bp_arrange_pref == 1) {
         void (*arr)(const uint32_t*, const unsigned long long*, char*, int64_t, int32_t, int32_t) =
             bp_record_vm(idx) == VM_F32 ? bp_arrange_kernel<VM_F32> : bp_arrange_kernel<VM_F16>;
         const size_t alds = (size_t)256 * 64 * (2 + 4);
@@ -1125,6 +1162,10 @@ int bp_filter_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64
     a.gcand = idx->ws_mq_cand.as<uint64_t>();
     a.qscale = qscale;
     a.gtau = gtau;
+    if (idx->bp_quad) {
+        VS_TRY(idx->ws_gent.reserve((size_t)idx->cu_count * kBpEntCap * 8));
+        a.gent = idx->ws_gent.as<uint2>();
+    }
     a.df = idx->bp_df.p ? idx->bp_df.as<unsigned long long>() + V : nullptr;          // (second half of bp_df: non-zeros per column)
     a.hmap = idx->bp_n_head > 0 ? idx->bp_hmap.as<uint16_t>() : nullptr;
     a.strip = idx->bp_strip.as<__half>();
@@ -1137,7 +1178,7 @@ int bp_filter_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64
     }
     idx->last_path = 3;
     idx->last_plan_dev = dplan;
-    idx->last_plan_rs = bp_rec_bytes(bp_record_vm(idx));
+    idx->last_plan_rs = idx->bp_quad ? kQuadChunkBytes : bp_rec_bytes(bp_record_vm(idx));
     idx->last_plan_blocks = n_blocks;
     // lock-step window of the walk's work items (all walks; kernels ignore it when not every item is resident)
     static const int pace_env = getenv("VS_BP_PACE") ? atoi(getenv("VS_BP_PACE")) : -1;
@@ -1318,7 +1359,7 @@ int mq_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64_t id_o
     // kernel re-scores them exactly and proves the top k; unproven queries go through the fp64 walk.  Without it (option
     // "postings_filter" = 0, "search after" passes, k beyond the candidate buffers) every tile takes the fp64 walk.
     if (bp_filter_ok(idx, k, col0, upper)) return bp_filter_search(idx, dq, B, k, id_offset, d_ids, d_scores, plan, s, done, out_ld);
-    const bool filter_only = idx->bp_quant || idx->store_dtype == VS_NONE || idx->bp_n_head > 0;    // lossy / binary records, dense strips: the filter only
+    const bool filter_only = idx->bp_quant || idx->bp_quad || idx->store_dtype == VS_NONE || idx->bp_n_head > 0;    // lossy / binary records, quad chunks, dense strips: the filter only
     const bool use_bp = idx->bp_ready && !filter_only;                         // the fp64 walk over exact records
     const int qt_plan = use_bp ? kBpExactQT : kQT;
     const int bp_cap = kBpEntCap / 2;
@@ -1495,7 +1536,7 @@ int vs_csr_search(vs_index* idx, const void* q, int q_dtype, int64_t ldq, int32_
         // ranks one pass delivers: the whole k when the filter-and-refine search takes it (k + its margin within the candidate
         // buffers), else 1024 per pass of the fp64 postings walk (exact records only), else 512 per pass of the CSR scan
         const bool one_pass = idx->bp_ready && idx->bp_filter != 0 && k + std::max(28, k / 4) <= kBpMaxK;
-        const int max_k = one_pass ? k : (idx->bp_ready && !idx->bp_quant && idx->store_dtype != VS_NONE && idx->bp_n_head == 0) ? kBpMaxK : kMaxKMq;
+        const int max_k = one_pass ? k : (idx->bp_ready && !idx->bp_quant && !idx->bp_quad && idx->store_dtype != VS_NONE && idx->bp_n_head == 0) ? kBpMaxK : kMaxKMq;
         const int mq_passes = ceil_div(k, max_k);
         const int kk_mq = std::min<int>(k, max_k);
         DevBuf mq_upper;
