@@ -423,7 +423,7 @@ struct BpArgs {
     const __half* strip;      // fp16 values of the head columns, MFMA operand order (bp_strip_index)
     int32_t n_head;
     float head_pre, head_mul; // powers of two: weights enter the fp16 operand as w * scale * head_pre (< 2^15), the sums leave as C * head_mul
-    uint2* gent;              // quad walk (bp_quad.h): [grid][kBpEntCap] scratch, the work item's sorted entries
+    const uint32_t* ovf_bits; // quad walk: [n_blocks][quad_bitmap_words] columns of a block whose list overflows its main chunk
     uint32_t* pace;           // optional [nchunk][blocks_per_chunk], zeroed per search: work items that have finished a block (flat walk: lock-step window)
     int32_t pace_window;      // blocks an item may run ahead of the slowest item of its chunk
     int32_t knob;             // developer switches (VS_BP_KNOB)

@@ -207,6 +207,7 @@ struct vs_index {
     vs::DevBuf bp_dir;   // uint32 [n_blocks, n_cols + 1]: first record of a column inside its block
     vs::DevBuf bp_base;  // uint64 [n_blocks + 1]: first record of a block
     vs::DevBuf bp_rec;   // records: 8 x uint16 document-in-block + 8 values (fp32 | fp16 | none)
+    vs::DevBuf bp_ovf;   // quad chunks (bp_quad.h): uint32 [n_blocks][bitmap words]: columns of a block whose list overflows its main chunk
     vs::DevBuf bp_df;    // uint64 [2][n_cols]: records / non-zeros per column over all blocks -- what a query entry walks
     int64_t bp_records = 0;
     vs::DevBuf bp_hmap;  // uint16 [n_cols]: strip index of a head column (dense strip), 0xFFFF otherwise; valid when bp_n_head > 0
@@ -247,7 +248,7 @@ struct vs_index {
     // dense
     vs::DevBuf mat;      // [n_rows, n_cols] store_dtype
     // scratch owned by the handle (grow-only)
-    vs::DevBuf ws_q, ws_cand, ws_out_ids, ws_out_scores, ws_misc, ws_mq_meta, ws_mq_q, ws_mq_cand, ws_fb, ws_pace, ws_gent;
+    vs::DevBuf ws_q, ws_cand, ws_out_ids, ws_out_scores, ws_misc, ws_mq_meta, ws_mq_q, ws_mq_cand, ws_fb, ws_pace;
     bool logical_dense = false;   // dense Index stored as CSR packets (sparsity-aware dense index)
     int qt_pref = 0;     // 0 = auto (multi-query pass when the batch qualifies), 1 = force the dense-image pass
     int last_qt = 0;     // queries per pass of the most recent search

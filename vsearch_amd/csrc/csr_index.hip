@@ -488,7 +488,7 @@ extern "C" int vs_index_info(const vs_index* idx, vs_index_info_t* o) {
         VS_HIP(hipMemcpy(h.data(), idx->last_flags, h.size() * 4, hipMemcpyDeviceToHost));
         for (uint32_t f : h) o->last_fallbacks += f ? 1 : 0;
     }
-    o->aux_bytes = idx->bp_ready ? (int64_t)(idx->bp_dir.bytes + idx->bp_base.bytes + idx->bp_rec.bytes + idx->bp_strip.bytes) : 0;
+    o->aux_bytes = idx->bp_ready ? (int64_t)(idx->bp_dir.bytes + idx->bp_base.bytes + idx->bp_rec.bytes + idx->bp_strip.bytes + idx->bp_ovf.bytes) : 0;
     if (idx->kind == VS_KIND_CSR) {
         o->bytes_per_pass = csr_bytes_per_pass(idx);
         o->device_bytes = (int64_t)(idx->pk_ptr.bytes + idx->cols.bytes + idx->vals.bytes);
@@ -747,7 +747,7 @@ inline int bp_record_vm(const vs_index* idx) {
 }
 
 void bp_release(vs_index* idx) {
-    idx->bp_dir.release(); idx->bp_base.release(); idx->bp_rec.release(); idx->bp_df.release(); idx->bp_vmax.release();
+    idx->bp_dir.release(); idx->bp_base.release(); idx->bp_rec.release(); idx->bp_df.release(); idx->bp_vmax.release(); idx->bp_ovf.release();
     idx->bp_hmap.release(); idx->bp_strip.release();
     idx->bp_n_head = 0;
     idx->bp_quad = false;
@@ -775,9 +775,9 @@ int launch_bp_walk(const vs_index* idx, const BpArgs& a, int grid, int ent_cap, 
     void (*kern)(BpArgs) = nullptr;
     if (idx->bp_quad) {
         // quad chunks (bp_quad.h): the fixed-point filter walk only
-        if (AM != AM_FIX || a.upper || ent_cap > kBpEntCap || !a.gent) return fail(VS_EUNSUPPORTED, "quad postings serve the filter walk only");
+        if (AM != AM_FIX || a.upper || ent_cap > kBpEntCap || !a.ovf_bits) return fail(VS_EUNSUPPORTED, "quad postings serve the filter walk only");
         kern = a.timing ? bp_quad_topk<1> : bp_quad_topk<0>;
-        lds = quad_lds_bytes();
+        lds = quad_lds_bytes(idx->n_cols);
     } else if (AM == AM_FIX && bp_duo_ok(idx, a.k, a.upper) && ent_cap <= kDuoEntCap) {
         if (vm == VM_F32) kern = bp_duo_topk<VM_F32, kBpNB, kBpRowsMax>;
         else kern = bp_duo_topk<VM_F16, kBpNBWide, kBpRowsMax>;
@@ -828,7 +828,7 @@ int bp_build(vs_index* idx, hipStream_t s) {
     // one-dword postings (fp16 values).  Not for: a binary index; exact fp32 records ("postings_quant" = 0, signed / huge values);
     // the fp64 walk ("postings_filter" = 0); a corpus with head columns (their dense strips belong to the list walk: bp_build starts
     // over without quad when it finds any); the experimental walks 0 .. 3 ("postings_walk"), aligned or arranged records.
-    const bool quad_pref = idx->store_dtype != VS_NONE && idx->bp_filter != 0 && (idx->bp_walk_pref == -1 || idx->bp_walk_pref == 4) && !idx->bp_no_quad &&
+    const bool quad_pref = idx->store_dtype != VS_NONE && idx->bp_filter != 0 && idx->n_cols <= 32768 && (idx->bp_walk_pref == -1 || idx->bp_walk_pref == 4) && !idx->bp_no_quad &&
                            idx->bp_align_pref != 1 && idx->bp_arrange_pref != 1 && (idx->store_dtype == VS_F16 || idx->bp_quant_pref != 0);
     idx->bp_no_quad = false;
     auto auto_rows = [&]() -> int {
@@ -885,7 +885,6 @@ int bp_build(vs_index* idx, hipStream_t s) {
     memcpy(&vmax_f, &hv[0], 4);
     const bool lossy_ok = hv[1] == 0u && vmax_f < 60000.f;       // fp16 copies of the values: non-negative, no overflow
     const bool quad = quad_pref && (idx->store_dtype == VS_F16 || lossy_ok);
-    const int cell_shift = quad ? 6 : 3;                          // postings per directory unit: a 64-cell chunk | an 8-posting record
     // Lossy filter copy of an fp32 index: values rounded to fp16 (4 instead of 6 bytes per posting); needs the filter-and-refine
     // search, non-negative values and no fp16 overflow
     idx->bp_quant = idx->store_dtype == VS_F32 && idx->bp_filter != 0 && idx->bp_quant_pref != 0 && lossy_ok;
@@ -894,9 +893,19 @@ int bp_build(vs_index* idx, hipStream_t s) {
     DevBuf ovf;
     VS_TRY(ovf.alloc(4));
     VS_HIP(hipMemsetAsync(ovf.p, 0, 4, s));
-    VS_HIP(hipFuncSetAttribute((const void*)bp_count_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(bp_count_kernel<0>, dim3(grid), dim3(kScanThreads), lds, s, idx->pk_ptr.as<uint32_t>(), idx->cols.as<uint4>(), idx->n_rows, V, idx->bp_rows,
-                       idx->bp_dir.as<uint32_t>(), block_recs.as<uint32_t>(), df_rec, df_nnz, (const uint16_t*)nullptr, idx->bp_al_shift, ovf.as<int32_t>(), cell_shift);
+    const int bm_words = quad_bitmap_words(V);
+    if (quad) {
+        // quad chunks: main chunk of column c = chunk c of its block, overflow chunks behind; the directory and a bitmap describe the overflow
+        const size_t b_ovf = (size_t)n_blocks * bm_words * 4, b_main = (size_t)n_blocks * V * kQuadChunkBytes;
+        if (free_b < b_dir + b_ovf + b_main + margin || idx->bp_ovf.alloc(b_ovf) != VS_OK) return no_room(b_dir + b_ovf + b_main);
+        VS_HIP(hipFuncSetAttribute((const void*)quad_count_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(quad_count_kernel<0>, dim3(grid), dim3(kScanThreads), lds, s, idx->pk_ptr.as<uint32_t>(), idx->cols.as<uint4>(), idx->n_rows, V, idx->bp_rows,
+                           idx->bp_dir.as<uint32_t>(), idx->bp_ovf.as<uint32_t>(), bm_words, block_recs.as<uint32_t>(), df_rec, df_nnz, ovf.as<int32_t>());
+    } else {
+        VS_HIP(hipFuncSetAttribute((const void*)bp_count_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(bp_count_kernel<0>, dim3(grid), dim3(kScanThreads), lds, s, idx->pk_ptr.as<uint32_t>(), idx->cols.as<uint4>(), idx->n_rows, V, idx->bp_rows,
+                           idx->bp_dir.as<uint32_t>(), block_recs.as<uint32_t>(), df_rec, df_nnz, (const uint16_t*)nullptr, idx->bp_al_shift, ovf.as<int32_t>(), 3);
+    }
     VS_STAGE("bp_count", s);
     // Head columns (skewed vocabularies): present in >= 1/4 of the documents -> dense strips instead of posting lists.  Valued
     // indexes with the filter search only (the strips hold fp16 values: the fp64 walk cannot use them).
@@ -930,7 +939,7 @@ int bp_build(vs_index* idx, hipStream_t s) {
             VS_HIP(hipMemsetAsync(idx->bp_df.p, 0, (size_t)V * 16, s));
             hipLaunchKernelGGL(bp_count_kernel<0>, dim3(grid), dim3(kScanThreads), lds, s, idx->pk_ptr.as<uint32_t>(), idx->cols.as<uint4>(), idx->n_rows, V,
                                idx->bp_rows, idx->bp_dir.as<uint32_t>(), block_recs.as<uint32_t>(), df_rec, df_nnz, (const uint16_t*)idx->bp_hmap.as<uint16_t>(),
-                               idx->bp_al_shift, ovf.as<int32_t>(), cell_shift);
+                               idx->bp_al_shift, ovf.as<int32_t>(), 3);
             VS_HIP(hipGetLastError());
             const size_t b_strip = (size_t)n_blocks * bp_head_pad(h_n) * idx->bp_rows * 2;
             VS_HIP(hipMemGetInfo(&free_b, &total_b));
@@ -1163,8 +1172,7 @@ int bp_filter_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64
     a.qscale = qscale;
     a.gtau = gtau;
     if (idx->bp_quad) {
-        VS_TRY(idx->ws_gent.reserve((size_t)idx->cu_count * kBpEntCap * 8));
-        a.gent = idx->ws_gent.as<uint2>();
+        a.ovf_bits = idx->bp_ovf.as<uint32_t>();
     }
     a.df = idx->bp_df.p ? idx->bp_df.as<unsigned long long>() + V : nullptr;          // (second half of bp_df: non-zeros per column)
     a.hmap = idx->bp_n_head > 0 ? idx->bp_hmap.as<uint16_t>() : nullptr;
@@ -1251,6 +1259,12 @@ int bp_filter_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64
                             (hw >> 13) & 7, (hw >> 12) & 1, (hw >> 8) & 15, (hw >> 4) & 3);
                 }
             }
+        }
+        if (idx->bp_quad) {
+            const double bw = (double)std::max<unsigned long long>(1, h[5]);
+            fprintf(stderr, "[vsearch_hip] quad walk, cycles per block and wave: gathers back %.0f, scan %.0f, barrier %.0f, emit %.0f, barrier (+ rest of the plan) %.0f\n", (double)h[6] / bw, (double)h[7] / bw,
+                    (double)h[8] / bw, (double)h[9] / bw, (double)h[3] / bw);
+            h[12] = h[14] = 0;
         }
         if (h[12] | h[14]) {
             const double bw = (double)std::max<unsigned long long>(1, h[5]) / 16.0;
