@@ -54,23 +54,38 @@ def _oracle_pin(seed, n, q, ids, sc, k, kind=0, val_law=0, nnz=768, windows=48, 
             assert missing.size == 0, f"query {b}: rows {missing[:5]} beat the k-th score {kth} and were not returned"
 
 
+def _experimental_walks(idx):
+    """the experimental walks of round 3 (postings_walk = 1 .. 3) are compiled only with `make EXPERIMENTAL=1`"""
+    try:
+        idx.set_option("postings_walk", 1)
+    except Exception:
+        return False
+    idx.set_option("postings_walk", -1)
+    return True
+
+
 def _modes(idx, q, k, want_quant, tied_queries=0):
-    """-> results of {csr scan, filter, filter on exact records, forced fallback x 2, filter on the flat walk (bp_flat.h) x 2,
-    fp64 walk}; checks paths and bit-equality."""
+    """-> results of {csr scan, filter on the default walk (quad chunks where they apply), filter on the list walk, both on exact records,
+    forced fallback x 2, the experimental walks when the library has them, fp64 walk}; checks paths and bit-equality."""
     ref_ids, ref_sc, info = _search(idx, q, k, blocked_postings=0)
     assert info.last_path == 1
     out = {}
-    for name, opts in [("filter", dict(postings_filter=1, postings_quant=-1, postings_force_fallback=0)),
-                       ("filter-exact-records", dict(postings_filter=1, postings_quant=0, postings_force_fallback=0)),
-                       ("fallback", dict(postings_filter=1, postings_quant=-1, postings_force_fallback=1)),
-                       ("fallback-exact-records", dict(postings_filter=1, postings_quant=0, postings_force_fallback=1)),
-                       ("filter-flat-walk", dict(postings_filter=1, postings_quant=-1, postings_force_fallback=0, postings_walk=1)),
-                       ("filter-flat-walk-exact-records", dict(postings_filter=1, postings_quant=0, postings_force_fallback=0, postings_walk=1)),
-                       ("filter-pipe-walk", dict(postings_filter=1, postings_quant=-1, postings_force_fallback=0, postings_walk=2)),
-                       ("filter-pipe-walk-exact-records", dict(postings_filter=1, postings_quant=0, postings_force_fallback=0, postings_walk=2)),
-                       ("filter-stream-walk", dict(postings_filter=1, postings_quant=-1, postings_force_fallback=0, postings_walk=3)),
-                       ("filter-stream-walk-exact-records", dict(postings_filter=1, postings_quant=0, postings_force_fallback=0, postings_walk=3)),
-                       ("fp64-walk", dict(postings_filter=0, postings_force_fallback=0, postings_walk=-1))]:
+    modes = [("filter", dict(postings_filter=1, postings_quant=-1, postings_force_fallback=0, postings_walk=-1)),
+             ("filter-quad-walk", dict(postings_filter=1, postings_quant=-1, postings_force_fallback=0, postings_walk=4)),
+             ("filter-list-walk", dict(postings_filter=1, postings_quant=-1, postings_force_fallback=0, postings_walk=0)),
+             ("filter-exact-records", dict(postings_filter=1, postings_quant=0, postings_force_fallback=0, postings_walk=-1)),
+             ("fallback", dict(postings_filter=1, postings_quant=-1, postings_force_fallback=1, postings_walk=-1)),
+             ("fallback-list-walk", dict(postings_filter=1, postings_quant=-1, postings_force_fallback=1, postings_walk=0)),
+             ("fallback-exact-records", dict(postings_filter=1, postings_quant=0, postings_force_fallback=1, postings_walk=-1))]
+    if _experimental_walks(idx):
+        modes += [("filter-flat-walk", dict(postings_filter=1, postings_quant=-1, postings_force_fallback=0, postings_walk=1)),
+                  ("filter-flat-walk-exact-records", dict(postings_filter=1, postings_quant=0, postings_force_fallback=0, postings_walk=1)),
+                  ("filter-pipe-walk", dict(postings_filter=1, postings_quant=-1, postings_force_fallback=0, postings_walk=2)),
+                  ("filter-pipe-walk-exact-records", dict(postings_filter=1, postings_quant=0, postings_force_fallback=0, postings_walk=2)),
+                  ("filter-stream-walk", dict(postings_filter=1, postings_quant=-1, postings_force_fallback=0, postings_walk=3)),
+                  ("filter-stream-walk-exact-records", dict(postings_filter=1, postings_quant=0, postings_force_fallback=0, postings_walk=3))]
+    modes += [("fp64-walk", dict(postings_filter=0, postings_force_fallback=0, postings_walk=-1))]
+    for name, opts in modes:
         ids, sc, info = _search(idx, q, k, blocked_postings=1, **opts)
         if name == "fp64-walk":
             assert info.last_path == 2
@@ -178,7 +193,7 @@ def test_short_and_dominant_weight_queries(quant):
     idx = DeviceIndex.from_csr(ip, ix, d, V)
     ref_ids, ref_sc, info = _search(idx, q, 100, blocked_postings=0)
     assert info.last_path == 1
-    for walk in (0, 1, 3):
+    for walk in (-1, 4, 0) + ((1, 2, 3) if _experimental_walks(idx) else ()):
         ids, sc, info = _search(idx, q, 100, blocked_postings=1, postings_quant=quant, postings_walk=walk)
         assert info.last_path == 3
         assert (ids == ref_ids).all() and (sc == ref_sc).all(), f"walk {walk}: differs from the CSR scan"

@@ -21,11 +21,16 @@ constexpr size_t kRegion = (size_t)kCols * kQuadChunkBytes;
 #define QD 4
 #endif
 
-__global__ __launch_bounds__(1024) void walk(const char* post, const uint2* tabs, int n_desc, int nblk, int mode, long long* cycles, int* acc_out) {
+constexpr int kListCap = 48;                      // descriptors of a wave's link list (+ 4 * kQuadOverRead null descriptors behind it)
+constexpr int kListBytes = (kListCap + 4 * kQuadOverRead) * 8;
+__global__ __launch_bounds__(1024) void walk(const char* post, const uint2* tabs, int n_desc, int nblk, int mode, long long* cycles, int* acc_out, int* dropped) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* acc = reinterpret_cast<int*>(smem);
     uint2* desc = reinterpret_cast<uint2*>(smem + (size_t)kAccDw * 4);
-    const int tid = threadIdx.x, w = tid >> 6;
+    const uint32_t desc_lds = (uint32_t)((size_t)kAccDw * 4), lists_lds = desc_lds + (uint32_t)(n_desc + 64 * kQuadOverRead) * 8u;
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    uint2* listA = reinterpret_cast<uint2*>(smem + lists_lds + (size_t)w * 2 * kListBytes);
+    const uint32_t la = lists_lds + (uint32_t)w * 2u * kListBytes, lb = la + kListBytes;
     for (int i = tid; i < kAccDw; i += 1024) acc[i] = 0;
     __syncthreads();
     const long long t0 = clock64();
@@ -38,10 +43,20 @@ __global__ __launch_bounds__(1024) void walk(const char* post, const uint2* tabs
         const unsigned long long pb = (unsigned long long)base;
         const char* ub = (const char*)(((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(pb >> 32)) << 32) |
                                        (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)pb));
+        const uint32_t g8 = (uint32_t)(lane >> 4) * 8u, s16 = (uint32_t)(lane & 15) * 16u;
 #ifdef QUAD_CXX
-        if (mode == 0) quad_walk<QD, 16>(desc, n_desc / 4, w, tid & 63, ub);
+        if (mode == 0) quad_walk<QD, 16>(desc, n_desc / 4, w, lane, ub);
 #else
-        if (mode == 0) quad_walk_asm((uint32_t)((size_t)kAccDw * 4 + ((size_t)w * 4 + ((tid & 63) >> 4)) * 8), (uint32_t)(n_desc / 64), ub, (uint32_t)(tid & 15) * 16u);
+        if (mode == 0) {
+            const uint32_t n_link = quad_walk_asm(desc_lds + (uint32_t)w * 32u + g8, (uint32_t)(n_desc / 64), ub, s16, la, (uint32_t)kListCap);
+            // the overflow chunks the wave's chunks linked to (the links of THOSE chunks are dropped here: capacity 0)
+            const int n_ovf = (int)min(n_link, (uint32_t)kListCap);
+            if (n_link > (uint32_t)kListCap && lane == 0) atomicAdd(dropped, (int)n_link - kListCap);
+            const int n_pad = (n_ovf + 3) & ~3;
+            if (lane < n_pad - n_ovf + 4 * kQuadOverRead) listA[n_ovf + lane] = make_uint2(0u, 0u);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (n_pad > 0) (void)quad_list_asm(la + g8, (uint32_t)(n_pad / 4), ub, s16, lb, 0u);
+        }
 #endif
         __syncthreads();
     }
@@ -60,7 +75,7 @@ static uint16_t f2h(float f) {
     if (rem > 0x1000 || (rem == 0x1000 && (h & 1))) ++h;
     return (uint16_t)h;
 }
-static float h2f(uint16_t h) { if (!h) return 0.f; uint32_t x = ((uint32_t)((h >> 10) & 31) - 15 + 127) << 23 | (uint32_t)(h & 1023) << 13; float f; memcpy(&f, &x, 4); return f; }
+static float h2f(uint16_t h) { if (!(h & 0x7FFF)) return 0.f; uint32_t x = ((uint32_t)((h >> 10) & 31) - 15 + 127) << 23 | (uint32_t)(h & 1023) << 13; float f; memcpy(&f, &x, 4); return f; }
 
 int main(int argc, char** argv) {
     const int nblk = argc > 1 ? atoi(argv[1]) : 24;
@@ -68,6 +83,7 @@ int main(int argc, char** argv) {
     const bool l1 = argc > 3 && !strcmp(argv[3], "l1");
     const bool rndbank = argc > 4 && !strcmp(argv[4], "rnd");      // documents at random: what an un-arranged list looks like
     const int nwg = 256;
+    const int link_pct = argc > 5 ? atoi(argv[5]) : 7;       // chunks that continue in an overflow chunk
     std::vector<uint32_t> post((size_t)nblk * kRegion / 4);
     for (size_t c = 0; c < post.size() / 64; ++c) {
         uint32_t* P = post.data() + c * 64;
@@ -81,6 +97,11 @@ int main(int argc, char** argv) {
                 const float v = 0.01f + 3.0f * (float)(rnd() & 0xFFFF) / 65536.f;
                 P[l * 4 + j] = quad_acc_index(doc) | ((pad ? 0u : (uint32_t)f2h(v)) << 16);
             }
+        }
+        if ((int)(rnd() % 100) < link_pct) {
+            const uint32_t link = (uint32_t)((c % kCols + 7919) % kCols);        // (a chunk of the same block)
+            P[62] = (link >> 14) & 0x3FFFu;
+            P[63] = 0x80000000u | (link & 0x3FFFu);
         }
     }
     const int n_desc = (n_list + 63) / 64 * 64;
@@ -102,11 +123,12 @@ int main(int argc, char** argv) {
             T[i] = make_uint2(chunk * 256u | slot * 16u, wb);
         }
     }
-    char* d_post; uint2* d_tabs; long long* d_cyc; int* d_acc;
+    char* d_post; uint2* d_tabs; long long* d_cyc; int* d_acc; int* d_drop;
+    (void)hipMalloc(&d_drop, 4); (void)hipMemset(d_drop, 0, 4);
     (void)hipMalloc(&d_post, post.size() * 4); (void)hipMalloc(&d_tabs, tabs.size() * 8); (void)hipMalloc(&d_cyc, nwg * 8); (void)hipMalloc(&d_acc, kAccDw * 4);
     (void)hipMemcpy(d_post, post.data(), post.size() * 4, hipMemcpyHostToDevice);
     (void)hipMemcpy(d_tabs, tabs.data(), tabs.size() * 8, hipMemcpyHostToDevice);
-    const size_t lds = (size_t)kAccDw * 4 + (size_t)(n_desc + 64 * kQuadOverRead) * 8;
+    const size_t lds = (size_t)kAccDw * 4 + (size_t)(n_desc + 64 * kQuadOverRead) * 8 + (size_t)16 * 2 * kListBytes;
     (void)hipFuncSetAttribute((const void*)walk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     std::vector<int> want(kAccDw, 0);
     for (int b = 0; b < nblk; ++b) {
@@ -116,13 +138,18 @@ int main(int argc, char** argv) {
             const uint32_t slot = (T[i].x & 0xFF) / 16;
             const uint32_t* p = post.data() + (size_t)b * kRegion / 4 + (size_t)(T[i].x >> 8) * 64;
             for (int l = 0; l < 64; ++l) want[(p[l] & 0xFFFF) + slot * 16] += (int)(wq * h2f((uint16_t)(p[l] >> 16)));
+            if (p[63] >> 31) {                                              // a link: the overflow chunk's cells count too
+                const uint32_t link = (p[63] & 0x3FFFu) | ((p[62] & 0x3FFFu) << 14);
+                const uint32_t* o = post.data() + (size_t)b * kRegion / 4 + (size_t)link * 64;
+                for (int l = 0; l < 64; ++l) want[(o[l] & 0xFFFF) + slot * 16] += (int)(wq * h2f((uint16_t)(o[l] >> 16)));
+            }
         }
     }
     for (int mode = 0; mode < 2; ++mode)
         for (int rep = 0; rep < 2; ++rep) {
             hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
             (void)hipEventRecord(e0);
-            hipLaunchKernelGGL(walk, dim3(nwg), dim3(1024), lds, 0, d_post, d_tabs, n_desc, nblk, mode, d_cyc, d_acc);
+            hipLaunchKernelGGL(walk, dim3(nwg), dim3(1024), lds, 0, d_post, d_tabs, n_desc, nblk, mode, d_cyc, d_acc, d_drop);
             (void)hipEventRecord(e1);
             (void)hipDeviceSynchronize();
             float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
@@ -131,6 +158,8 @@ int main(int argc, char** argv) {
             (void)hipMemcpy(got.data(), d_acc, kAccDw * 4, hipMemcpyDeviceToHost);
             double avg = 0; for (auto x : c) avg += (double)x; avg /= nwg;
             size_t bad = 0; for (int i = 0; i < kAccDw; ++i) bad += got[i] != want[i];
+            int drop = 0; (void)hipMemcpy(&drop, d_drop, 4, hipMemcpyDeviceToHost); (void)hipMemset(d_drop, 0, 4);
+            if (drop) printf("(%d links beyond a wave's list capacity dropped)\n", drop);
             printf("%s: %.3f ms, %.0f cycles per block and CU, %.2f cycles per list and CU (%d lists, %d blocks, D = %d); sums of workgroup 0: %zu of %d differ\n",
                    mode == 0 ? "walk" : "table copy only", ms, avg / nblk, avg / nblk / n_list, n_list, nblk, QD, bad, kAccDw);
         }

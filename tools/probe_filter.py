@@ -22,6 +22,7 @@ idx.set_option("postings_lanes", lanes)
 idx.set_option("postings_align", align)
 idx.set_option("postings_walk", int(os.environ.get("VS_PROBE_WALK", "-1")))
 idx.set_option("postings_arrange", int(os.environ.get("VS_PROBE_ARRANGE", "-1")))
+if os.environ.get("VS_PROBE_ROWS"): idx.set_option("postings_rows", int(os.environ["VS_PROBE_ROWS"]))
 for mode, chunks in [(m, c) for m in modes for c in (chunk_list if m != "csr" else [0])]:
     idx.set_option("postings_chunks", chunks)
     idx.set_option("blocked_postings", 0 if mode == "csr" else 1)
@@ -33,7 +34,7 @@ for mode, chunks in [(m, c) for m in modes for c in (chunk_list if m != "csr" el
     torch.cuda.synchronize(); first = time.time() - t
     Profile.enable(True); Profile.reset()
     torch.cuda.synchronize(); t = time.time()
-    reps = 3
+    reps = int(os.environ.get("VS_PROBE_REPS", "3"))
     for _ in range(reps):
         ids, sc = idx.search(q, k)
     torch.cuda.synchronize(); dt = (time.time() - t) / reps

@@ -75,6 +75,7 @@ __global__ __launch_bounds__(kScanThreads) void bp_duo_topk(BpArgs a) {
     uint64_t* my_gcand = a.gcand + (size_t)blockIdx.x * QT * kDuoCap;
     const int64_t n_blocks = (a.n_rows + a.rows - 1) / a.rows;
     const int64_t items = (int64_t)(a.n_tiles_dev ? a.n_tiles_dev[0] : a.n_tiles) * a.nchunk;
+    bool pace_off = false;                      // the lock-step wait timed out once (pace_wait): this workgroup runs free from then on
     const size_t dir_ld = (size_t)a.n_cols + 1;
     const unsigned long long k_rt0 = a.timing ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
@@ -270,14 +271,14 @@ __global__ __launch_bounds__(kScanThreads) void bp_duo_topk(BpArgs a) {
             }
             // lock step with the chunk's other items (BpArgs::pace, bp_walk.h): without a block barrier the workgroups lose their common
             // pace, and with it the L2 copies the pack leaves behind
-            if (a.pace && p == 0 && wv_id == 0 && items <= (int64_t)gridDim.x) {
+            if (a.pace && p == 0 && wv_id == 0 && items <= (int64_t)gridDim.x && !pace_off) {
                 if (lane == 0) {
                     uint32_t* pc = a.pace + (size_t)c * a.blocks_per_chunk;
                     const int rel = j >> 1;
                     __hip_atomic_fetch_add(pc + rel, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (rel >= a.pace_window) {
                         const uint32_t need = (uint32_t)(items / a.nchunk);
-                        while (__hip_atomic_load(pc + rel - a.pace_window, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(8);
+                        if (!pace_wait(pc + rel - a.pace_window, need)) pace_off = true;
                     }
                 }
             }

@@ -8,10 +8,11 @@
 // Here a list is stored in CHUNKS of 256 bytes = 16 lanes x 4 postings, zero-padded; a posting is ONE dword (accumulator index of
 // the document | fp16 value << 16); a wave step serves four chunks (one per 16-lane group) with one ds_read_b64 (descriptor), one
 // global_load_dwordx4 and 4 x (v_fma_mix_f32, v_cvt_i32_f32, v_mad_u32_u16, ds_add_u32): 15 VALU instructions per step, nothing
-// predicated (bp_quad_loop.h has the layout, tools/gen_quad_asm.py the loop).  Per (block, tile) the workgroup first PLANS: every
-// thread turns its 7 (query, column) entries and the block's directory words (fetched a block ahead) into chunk descriptors
-// {chunk offset | slot, weight} in LDS -- a prefix sum, no list is longer than one descriptor's 64 cells -- then the waves
-// take steps w, w + 16, ...: equal work by construction (the list walk needed a dynamic queue).  The builder deals the postings
+// predicated (bp_quad_loop.h has the layout, tools/gen_quad_asm.py the loop).  The main chunk of column c is chunk c of every block, so
+// a tile's descriptor table {column x 256 | slot row, weight} is built ONCE per work item and serves all its blocks; the waves take
+// steps w, w + 16, ... of it: equal work by construction (the list walk needed a dynamic queue), and no directory is read at search
+// time.  A list longer than its chunk goes on in an overflow chunk of its block that the chunk itself links to (its last two cells);
+// a wave collects the links it meets in a small list of its own and walks that right after the table.  The builder deals the postings
 // of a chunk so that the 16 a list adds in one instruction fall into 16 different LDS banks; two lists share a 32-lane half, so a
 // bank takes at most 2 lanes = the cost of a conflict-free atomic (tools/microbench/lds_conflicts.hip).
 // Measured on the inner loop alone (tools/microbench/quad_walk.hip): 6.3 - 6.7 cycles per chunk and CU against 8.9 per list
@@ -32,27 +33,31 @@ constexpr int kQuadPer = kBpEntCap / kScanThreads;                // entries a t
 constexpr size_t kQuadAccBytes = (size_t)(kQuadRows / 16) * kQuadGroupDw * 4;      // 73 728: accumulators, at LDS address 0
 static_assert(kBpEntCap % kScanThreads == 0, "a thread owns a fixed number of entries");
 static_assert(kQuadAccBytes >= kBpSortBytes, "the accumulator area holds the 8192-slot entry sort");
-// LDS: accumulators | candidate sort buffer | thresholds, bounds, scratch, counters | overflow bitmap of a block | descriptors (+ the
-// null steps the loop over-reads)
+// LDS: accumulators | candidate sort buffer (during a walk: the waves' link lists) | thresholds, bounds, scratch, counters | descriptors
+// (+ the null steps the loop over-reads)
 __host__ __device__ constexpr size_t quad_fixed_lds() { return kQuadAccBytes + (size_t)kBpCap * 8 + (size_t)kQuadQT * 16 + 64 * 4; }
-__host__ __device__ inline int quad_bitmap_words(int n_cols) { return ((n_cols + 31) / 32 + 15) & ~15; }
-__host__ __device__ inline int quad_desc_cap(int n_cols) {
-    return (int)((((size_t)160 * 1024 - quad_fixed_lds() - (size_t)quad_bitmap_words(n_cols) * 4) / 8 - 64 * kQuadOverRead) / 64 * 64);
-}
-__host__ __device__ inline size_t quad_lds_bytes(int n_cols) {
-    return quad_fixed_lds() + (size_t)quad_bitmap_words(n_cols) * 4 + (size_t)(quad_desc_cap(n_cols) + 64 * kQuadOverRead) * 8;
-}
+__host__ __device__ constexpr size_t quad_lds_bytes() { return quad_fixed_lds() + (size_t)(kBpEntCap + 64 + 64 * kQuadOverRead) * 8; }
+static_assert(quad_lds_bytes() <= (size_t)160 * 1024, "the quad walk's LDS");
+// a wave's two link lists live in its 1 KB of the sort buffer: 48 descriptors + the 16 null ones a walk over-reads, twice
+constexpr int kQuadListCap = 48, kQuadListBytes = (kQuadListCap + 4 * kQuadOverRead) * 8;
+static_assert(2 * kQuadListBytes * kScanWaves <= kBpCap * 8, "the link lists fit the sort buffer");
+// postings a chunk holds when its list goes on in another chunk (the last two cells are the link), overflow chunks of a list of n postings
+constexpr int kQuadLinked = kQuadCells - 2;
+constexpr int kQuadPaceDefault = 8;                                // lock-step window in blocks (see the walk)
+__host__ __device__ constexpr uint32_t quad_overflow_chunks(uint32_t n) { return n > (uint32_t)kQuadCells ? (n - (uint32_t)kQuadCells + (uint32_t)kQuadLinked - 1u) / (uint32_t)kQuadLinked : 0u; }
 
 // ---- builder --------------------------------------------------------------------------------------------------------
-// A block's chunks: one MAIN chunk per column at chunk index = column (the first 64 postings of the column's list: 19 lists in 20 end
-// there on 768-nnz documents), then the block's OVERFLOW chunks.  The main chunks need no directory -- a tile's descriptors for them
-// are the same in every block -- and a bitmap says which columns of a block have overflow; only for those a directory word
-// dir[b][c] = first overflow chunk (from the block's first overflow chunk) << 12 | overflow chunks is looked up.
-// pass 1, one workgroup per block: postings per column -> overflow chunks, directory, bitmap, block total (V + overflow chunks)
+// A block's chunks: one MAIN chunk per column at chunk index = column -- a tile's descriptors for them are the same in every block,
+// no directory is read at search time -- then the block's OVERFLOW chunks.  A list of more than 64 postings keeps 62 in its main
+// chunk; the chunk's last two cells are a LINK to the overflow chunk that continues it (and so on): the last cell has the sign bit
+// set -- postings have non-negative values -- and 14 payload bits, the cell before it 14 more, both with value 0 (as postings they
+// add nothing, to a valid accumulator).  19 lists in 20 end in their main chunk on 768-nnz documents.
+// pass 1, one workgroup per block: postings per column -> overflow chunks, directory (first overflow chunk << 12 | overflow chunks:
+// the fill pass needs it, the search does not), block total (V + overflow chunks)
 template <int UNUSED>
 __global__ __launch_bounds__(kScanThreads) void quad_count_kernel(const uint32_t* pk_ptr, const uint4* cols, int64_t n_rows, int32_t n_cols, int32_t rows,
-                                                                  uint32_t* dir, uint32_t* ovf_bits, int32_t bm_words, uint32_t* block_recs,
-                                                                  unsigned long long* df_rec, unsigned long long* df_nnz, int32_t* overflow) {
+                                                                  uint32_t* dir, uint32_t* block_recs, unsigned long long* df_rec, unsigned long long* df_nnz,
+                                                                  int32_t* overflow) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint32_t* cnt = reinterpret_cast<uint32_t*>(smem);                  // [n_cols + 1]
     __shared__ int scratch[32];
@@ -75,15 +80,14 @@ __global__ __launch_bounds__(kScanThreads) void quad_count_kernel(const uint32_t
             }
         }
         __syncthreads();
-        auto ovf_of = [&](int i) -> uint32_t { return cnt[i] > (uint32_t)kQuadCells ? (cnt[i] - 1u) / (uint32_t)kQuadCells : 0u; };
         const int i0 = min(n_cols, tid * seg), i1 = min(n_cols, i0 + seg);
         int mine = 0;
-        for (int i = i0; i < i1; ++i) mine += (int)ovf_of(i);
+        for (int i = i0; i < i1; ++i) mine += (int)quad_overflow_chunks(cnt[i]);
         int tot = 0;
         int off = block_excl_scan(mine, scratch, tid, &tot);
         uint32_t* d = dir + (size_t)b * (n_cols + 1);
         for (int i = i0; i < i1; ++i) {
-            const uint32_t c = cnt[i], r = ovf_of(i);
+            const uint32_t c = cnt[i], r = quad_overflow_chunks(c);
             d[i] = bp_dir_pack((uint32_t)off, r);
             if (r > kBpDirRecMask || (uint32_t)off > kBpDirUnitMax) overflow[0] = 1;
             off += (int)r;
@@ -91,15 +95,6 @@ __global__ __launch_bounds__(kScanThreads) void quad_count_kernel(const uint32_t
                 atomicAdd(&df_rec[i], (unsigned long long)(1u + r));
                 atomicAdd(&df_nnz[i], (unsigned long long)c);
             }
-        }
-        uint32_t* bm = ovf_bits + (size_t)b * bm_words;
-        for (int w = tid; w < bm_words; w += kScanThreads) {
-            uint32_t bits = 0;
-            for (int k = 0; k < 32; ++k) {
-                const int c = 32 * w + k;
-                if (c < n_cols && cnt[c] > (uint32_t)kQuadCells) bits |= 1u << k;
-            }
-            bm[w] = bits;
         }
         if (tid == 0) { d[n_cols] = bp_dir_pack((uint32_t)tot, 0u); block_recs[b] = (uint32_t)n_cols + (uint32_t)tot; }
     }
@@ -144,12 +139,26 @@ __global__ __launch_bounds__(kScanThreads) void quad_fill_kernel(const uint32_t*
                     const uint32_t c = (i & 1) ? (cwv[i >> 1] >> 16) : (cwv[i >> 1] & 0xFFFFu);
                     if (c < (uint32_t)n_cols) {
                         const uint32_t pos = atomicAdd(&cur[c], 1u);
-                        // the main chunk of column c is chunk c; posting 64 + o sits in overflow chunk first + o / 64 behind the main chunks
-                        const size_t cell = pos < (uint32_t)kQuadCells ? (size_t)c * kQuadCells + pos
-                                                                       : ((size_t)n_cols + (d[c] >> 12)) * kQuadCells + (pos - (uint32_t)kQuadCells);
-                        brec[cell] = ai | (hb[i] << 16);
+                        // chunk k of the list (0: the main chunk = chunk c, k >= 1: overflow chunk first + k - 1 behind the main chunks)
+                        // holds 62 postings when another follows it, up to 64 when it is the last
+                        const uint32_t w = d[c], m = w & kBpDirRecMask;
+                        const uint32_t k = m ? min(pos / (uint32_t)kQuadLinked, m) : 0u;
+                        const size_t chunk = k == 0 ? (size_t)c : (size_t)n_cols + (w >> 12) + (k - 1);
+                        const uint32_t hv = (hb[i] & 0x7FFFu) ? hb[i] : 0u;       // (-0 -> +0: the sign bit marks a link)
+                        brec[chunk * kQuadCells + (pos - k * (uint32_t)kQuadLinked)] = ai | (hv << 16);
                     }
                 }
+            }
+        }
+        // the links: chunk k of a list with overflow points at its overflow chunk k
+        __syncthreads();
+        for (int c = tid; c < n_cols; c += kScanThreads) {
+            const uint32_t w = d[c], m = w & kBpDirRecMask;
+            for (uint32_t k = 0; k < m; ++k) {
+                const size_t chunk = k == 0 ? (size_t)c : (size_t)n_cols + (w >> 12) + (k - 1);
+                const uint32_t link = (uint32_t)n_cols + (w >> 12) + k;
+                brec[chunk * kQuadCells + 62] = (link >> 14) & 0x3FFFu;
+                brec[chunk * kQuadCells + 63] = 0x80000000u | (link & 0x3FFFu);
             }
         }
     }
@@ -181,8 +190,14 @@ __global__ __launch_bounds__(256) void quad_arrange_kernel(uint32_t* rec, unsign
         if (tid < nc) {
             const uint32_t* mi = in + tid * LD;
             uint32_t* mo = out + tid * LD;
-            uint32_t mask[4] = {0u, 0u, 0u, 0u}, fill[4] = {0u, 0u, 0u, 0u};
-            for (int i = 0; i < kQuadCells; ++i) {
+            uint32_t mask[4] = {0u, 0u, 0u, 0u}, fill[4] = {0u, 0u, 0u, 0u}, room[4] = {16u, 16u, 16u, 16u};
+            const bool linked = (mi[63] >> 31) != 0u;                   // the last two cells are a link: they stay where they are
+            if (linked) {
+                mo[62] = mi[62]; mo[63] = mi[63];
+                mask[2] |= 1u << (mi[62] & 31u); mask[3] |= 1u << (mi[63] & 31u);
+                room[2] = 15u; room[3] = 15u;
+            }
+            for (int i = 0; i < (linked ? kQuadLinked : kQuadCells); ++i) {
                 const uint32_t p = mi[i];
                 if ((p & 0x7FFF0000u) == 0u) continue;                  // unused cell, or an explicit zero: adds nothing either way
                 const uint32_t bit = 1u << (p & 31u);
@@ -190,8 +205,8 @@ __global__ __launch_bounds__(256) void quad_arrange_kernel(uint32_t* rec, unsign
                 uint32_t best = 17u, best_any = 17u;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    if (fill[j] < 16u && fill[j] < best_any) { best_any = fill[j]; any = j; }
-                    if (fill[j] < 16u && !(mask[j] & bit) && fill[j] < best) { best = fill[j]; pick = j; }
+                    if (fill[j] < room[j] && fill[j] < best_any) { best_any = fill[j]; any = j; }
+                    if (fill[j] < room[j] && !(mask[j] & bit) && fill[j] < best) { best = fill[j]; pick = j; }
                 }
                 if (pick < 0) pick = any;
 #pragma unroll
@@ -200,7 +215,7 @@ __global__ __launch_bounds__(256) void quad_arrange_kernel(uint32_t* rec, unsign
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                while (fill[j] < 16u) {
+                while (fill[j] < room[j]) {
                     const uint32_t freeb = ~mask[j];
                     const uint32_t bk = freeb ? (uint32_t)(__ffs((int)freeb) - 1) : 0u;
                     mo[fill[j] * 4 + j] = quad_acc_index(bk);           // value 0
@@ -219,56 +234,43 @@ __global__ __launch_bounds__(256) void quad_arrange_kernel(uint32_t* rec, unsign
 
 // ---- walk -----------------------------------------------------------------------------------------------------------
 // Work items, tiles, candidate handling and thresholds as bp_walk_topk (AM_FIX, 8 slots).  BpArgs::rec = the chunks, base[b] = first
-// chunk of block b, dir / ovf_bits as the builder wrote them; BpArgs::gent = [grid][kBpEntCap] scratch for the item's sorted entries.
+// chunk of block b.
 //
-// Per item: the tile's entries are sorted by column and turned into the STATIC part of the descriptor table (main chunks: the same
-// in every block).  Per block: the overflow descriptors of this block are appended behind it (`plan`: a prefix sum over the ~ 7 % of
-// the entries whose bitmap bit is set), the waves walk the table (quad_walk_asm), then -- behind one LDS barrier -- the next block's
-// bitmap goes to LDS, every thread tests its 7 entries and gathers the directory words of the flagged ones (they land under the
-// epilogue), and the epilogue turns the block's sums into candidates.
+// Per item: the tile's entries are sorted by column and become the descriptor table {column x 256 | slot row, weight} -- the main chunk
+// of column c is chunk c of EVERY block, so the table serves all blocks of the item and nothing is planned per block.  Per block: the
+// waves walk the table (quad_walk_asm: wave w takes steps w, w + 16, ...); chunks that link to an overflow chunk leave a descriptor in
+// the wave's own list, which the wave walks right after (quad_list_asm), and so on down the chain; one LDS barrier; the epilogue turns
+// the block's sums into candidates.  The only global loads of a block are its chunks (and one scalar load of the next block's base).
 template <int TM>          // TM = 1: phase clocks (VS_BP_TIMING)
 __global__ __launch_bounds__(kScanThreads) void bp_quad_topk(BpArgs a) {
     constexpr int QT = kQuadQT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int32_t* acc = reinterpret_cast<int32_t*>(smem);                                        // LDS address 0 (no static LDS in this kernel)
-    uint64_t* sortbuf = reinterpret_cast<uint64_t*>(smem + kQuadAccBytes);                  // [kBpCap]
+    uint64_t* sortbuf = reinterpret_cast<uint64_t*>(smem + kQuadAccBytes);                  // [kBpCap]; during a walk: the link lists
     unsigned long long* tau = reinterpret_cast<unsigned long long*>(sortbuf + kBpCap);      // [QT]
     unsigned long long* upper_sh = tau + QT;                                                // [QT]
     int* scratch = reinterpret_cast<int*>(upper_sh + QT);                                   // [48]
     unsigned int* ccnt = reinterpret_cast<unsigned int*>(scratch + 48);                     // [QT]
-    uint32_t* bitmap = reinterpret_cast<uint32_t*>(scratch + 64);                           // [bm_words] overflow bits of a block
-    const int bm_words = quad_bitmap_words(a.n_cols);
-    uint2* desc = reinterpret_cast<uint2*>(bitmap + bm_words);                              // [desc_cap + 64 * kQuadOverRead]
-    const uint32_t desc_lds = (uint32_t)(quad_fixed_lds() + (size_t)bm_words * 4);          // its LDS byte address
-    const int desc_cap = quad_desc_cap(a.n_cols);
+    uint2* desc = reinterpret_cast<uint2*>(scratch + 64);                                   // [n_static + 64 * kQuadOverRead]
+    const uint32_t desc_lds = (uint32_t)quad_fixed_lds();                                   // its LDS byte address
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int K = a.k;
     uint64_t* my_gcand = a.gcand + (size_t)blockIdx.x * QT * kBpCap;
     const int64_t n_blocks = (a.n_rows + a.rows - 1) / a.rows;
     const int64_t items = (int64_t)(a.n_tiles_dev ? a.n_tiles_dev[0] : a.n_tiles) * a.nchunk;
-    const size_t dir_ld = (size_t)a.n_cols + 1;
     const unsigned long long k_rt0 = TM ? __builtin_amdgcn_s_memrealtime() : 0ull;
-    // a barrier that orders LDS only: global loads stay in flight across it (a __syncthreads() waits for them: a DRAM round trip)
+    // a barrier that orders LDS only (a __syncthreads() also waits for every global access in flight)
     auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-    // exclusive prefix sum over the wave's lanes on the VALU (DPP row shifts and broadcasts: no LDS traffic); *tot = the wave's sum
-    auto wave_excl_scan = [&](int v, int* tot) {
-        int x = v;
-        x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);       // row_shr:1
-        x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);       // row_shr:2
-        x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);       // row_shr:4
-        x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);       // row_shr:8: inclusive sums inside every row of 16
-        x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);      // row_bcast:15 -> rows 1, 3
-        x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);      // row_bcast:31 -> rows 2, 3
-        *tot = __builtin_amdgcn_readlane(x, 63);
-        return x - v;
-    };
+    // the wave's two link lists
+    const uint32_t list_a = (uint32_t)kQuadAccBytes + (uint32_t)wv * 2u * kQuadListBytes, list_b = list_a + kQuadListBytes;
+    const uint32_t g8 = (uint32_t)(lane >> 4) * 8u, s16 = (uint32_t)(lane & 15) * 16u;
 
     for (int64_t item = blockIdx.x; item < items; item += gridDim.x) {
         const int tile = (int)(item / a.nchunk), c = (int)(item % a.nchunk);
         const int q0 = a.tiles[tile].x, nq = a.tiles[tile].y;
         [[maybe_unused]] long long tm = TM ? (long long)__builtin_readcyclecounter() : 0;
-        [[maybe_unused]] uint32_t tacc[12] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};      // 6 .. 11: sub-phases of the plan
+        [[maybe_unused]] uint32_t tacc[6] = {0u, 0u, 0u, 0u, 0u, 0u};
         auto lap = [&](int phase) {
             if constexpr (TM != 0) {
                 const long long now = (long long)__builtin_readcyclecounter();
@@ -281,8 +283,7 @@ __global__ __launch_bounds__(kScanThreads) void bp_quad_topk(BpArgs a) {
         const int64_t e0 = a.qptr[q0], e1 = a.qptr[q0 + nq];
         const int n_ent = (int)(e1 - e0);
         const int n_static = (n_ent + 63) & ~63;
-        // the tile's entries sorted by column (the accumulator area doubles as the sort buffer) -> the static descriptors (main chunk
-        // of column c = chunk c of every block) and, for the overflow lookups, the global scratch
+        // the tile's entries sorted by column (the accumulator area doubles as the sort buffer) -> the descriptor table
         {
             uint64_t* skey = reinterpret_cast<uint64_t*>(acc);
             for (int i = tid; i < 8192; i += kScanThreads) {
@@ -311,116 +312,60 @@ __global__ __launch_bounds__(kScanThreads) void bp_quad_topk(BpArgs a) {
         for (int i = tid; i < (int)(kQuadAccBytes / 4); i += kScanThreads) acc[i] = 0;
         if (tid < QT) { tau[tid] = 0ull; ccnt[tid] = 0u; }
         if (tid < QT) upper_sh[tid] = (a.upper && tid < nq) ? a.upper[q0 + tid] : ~0ull;
-        // Entry ownership for the overflow lookups, the same for every block of the item: wave w owns the `per` x 64 consecutive
-        // entries from w * per * 64, lane l the entries  w * per * 64 + 64 i + l  (i < per).  What a thread needs of an entry -- column,
-        // slot, weight -- it re-reads from the entry's static descriptor in LDS: nothing is held in registers across the walk.
-        const int per = (n_ent + kScanThreads - 1) / kScanThreads;
-        const int ebase = wv * per * 64 + lane;
-        // directory words of the thread's entries that overflow in block bb (its bitmap is in LDS), 0 for the others
-        // (two blocks ahead: under load a directory gather takes ~ 15 k cycles to come back -- more than an epilogue hides)
-        uint32_t nd[kQuadPer], nd2[kQuadPer];                            // of the next block to walk, of the one after
-        auto fetch_dir = [&](int64_t bb, uint32_t (&nd)[kQuadPer]) {
-            const uint32_t* dirn = a.dir + (size_t)bb * dir_ld;
-#pragma unroll
-            for (int i = 0; i < kQuadPer; ++i) {
-                const int e = ebase + 64 * i;
-                const uint32_t col = desc[min(e, n_static)].x >> 8;         // (beyond the tile: a null descriptor, never used)
-                const bool flagged = i < per && e < n_ent && ((bitmap[col >> 5] >> (col & 31u)) & 1u);
-                nd[i] = flagged ? dirn[col] : 0u;
-            }
-        };
-        uint32_t bm_next = 0;                                            // the thread's word of a coming block's bitmap, fetched a block before it is needed
-#pragma unroll
-        for (int i = 0; i < kQuadPer; ++i) { nd[i] = 0u; nd2[i] = 0u; }
-        if (b0 < b1) {
-            for (int w = tid; w < bm_words; w += kScanThreads) bitmap[w] = a.ovf_bits[(size_t)b0 * bm_words + w];
-            __syncthreads();
-            fetch_dir(b0, nd);
-            if (b0 + 1 < b1) {
-                __syncthreads();
-                for (int w = tid; w < bm_words; w += kScanThreads) bitmap[w] = a.ovf_bits[(size_t)(b0 + 1) * bm_words + w];
-                __syncthreads();
-                fetch_dir(b0 + 1, nd2);
-            }
-            if (b0 + 2 < b1 && tid < bm_words) bm_next = a.ovf_bits[(size_t)(b0 + 2) * bm_words + tid];
-        }
         __syncthreads();
-        // (the first chunk of a block is fetched a block ahead: a scalar load's DRAM round trip would otherwise sit in front of the first
-        //  LDS barrier of the plan -- s_waitcnt lgkmcnt(0) waits for scalar loads too)
+        const uint32_t trips = (uint32_t)(n_static / 64);
+        bool pace_off = false;                                           // (thread 0's: the lock step timed out once)
+        // (the first chunk of a block is fetched a block ahead: s_waitcnt lgkmcnt(0) -- every LDS barrier -- waits for scalar loads too)
         unsigned long long base_cur = b0 < b1 ? a.base[b0] : 0ull;
-        // One block: `ndb` holds the directory words gathered for it two blocks ago and, once the plan has read them, takes the gathers
-        // of block b + 2.  The loop below alternates between two such arrays: neither is touched while its gathers are in flight.
-        auto one_block = [&](const int64_t b, uint32_t (&ndb)[kQuadPer]) {
+        for (int64_t b = b0; b < b1 || b == b0; ++b) {
             const bool have = b < b1;
             const int rows_b = have ? (int)min((int64_t)a.rows, a.n_rows - b * a.rows) : 0;
-            if (have) {
+            if (have && trips > 0) {
                 const char* brec = a.rec + (size_t)base_cur * kQuadChunkBytes;
-                // plan: this block's overflow descriptors behind the static part.  A thread's descriptors are numbered by a prefix sum;
-                // round r of the walk takes numbers [r C, (r + 1) C) -- normally there is one round
-                uint32_t cd[kQuadPer];
-                int mine = 0;
-#pragma unroll
-                for (int i = 0; i < kQuadPer; ++i) { cd[i] = ndb[i]; mine += (int)(cd[i] & kBpDirRecMask); }      // (gathered two blocks ago)
-                lap(6);
-                int wtot = 0;
-                int first_no = wave_excl_scan(mine, &wtot);
-                if (lane == 0) scratch[wv] = wtot;
-                lap(7);
-                lds_barrier();
-                lap(8);
-                int n_ovf = 0;
-#pragma unroll
-                for (int u = 0; u < kScanWaves; ++u) { const int t = scratch[u]; first_no += u < wv ? t : 0; n_ovf += t; }
-                const int C = (desc_cap - n_static) & ~63;
-                // descriptors number [lo, hi) of the block's overflow -> the table behind the static part, null steps behind them
-                auto emit = [&](int lo, int hi) {
-                    int no = first_no;
-#pragma unroll
-                    for (int i = 0; i < kQuadPer; ++i) {
-                        const int nch = (int)(cd[i] & kBpDirRecMask);
-                        if (nch > 0 && no < hi && no + nch > lo) {
-                            const uint2 sd = desc[ebase + 64 * i];         // the entry's static descriptor: slot row and weight
-                            const uint32_t first = (uint32_t)a.n_cols + (cd[i] >> 12), so = sd.x & 0xFFu;
-                            for (int j = max(0, lo - no); j < nch && no + j < hi; ++j)
-                                desc[n_static + (no + j - lo)] = make_uint2(((first + (uint32_t)j) << 8) | so, sd.y);
-                        }
-                        no += nch;
+                // the overflow chunks a walk found: the wave's list `cur` holds n of them; their own links go to the other list
+                auto chain = [&](uint32_t n, uint32_t cur, uint32_t nxt) {
+                    // (a list has at most kQuadRows / 62 + 1 chunks: the bound keeps a corrupt link from hanging the GPU)
+                    for (int depth = 0; n > 0 && depth < kQuadRows / kQuadLinked + 2; ++depth) {
+                        const uint32_t n_pad = (n + 3u) & ~3u;
+                        if ((uint32_t)lane < n_pad - n + 4u * kQuadOverRead)
+                            reinterpret_cast<uint2*>(smem + cur)[n + (uint32_t)lane] = make_uint2(0u, 0u);      // null descriptors behind the list (smem = LDS address 0)
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        n = quad_list_asm(cur + g8, n_pad / 4u, brec, s16, nxt, (uint32_t)kQuadListCap);       // (n links out of n chunks at most: they fit)
+                        const uint32_t t = cur; cur = nxt; nxt = t;
                     }
-                    const int n_end = n_static + (hi - lo), n_pad = (n_end + 63) & ~63;
-                    for (int i = n_end + tid; i < n_pad + 64 * kQuadOverRead; i += kScanThreads) desc[i] = make_uint2(0u, 0u);
-                    return n_pad;
                 };
-                if (n_ovf <= C) {
-                    // the normal case: one walk over the static part and all of the block's overflow
-                    const int n_pad = emit(0, n_ovf);
-                    lap(9);
-                    lds_barrier();
-                    lap(3);                                              // (phase 3 = the plan, phase 1 = the walk proper)
-                    if (n_pad > 0) quad_walk_asm(desc_lds + (uint32_t)(wv * 4 + (lane >> 4)) * 8u, (uint32_t)(n_pad / 64), brec, (uint32_t)(lane & 15) * 16u);
-                    lap(1);
+                const uint32_t n_link = quad_walk_asm(desc_lds + (uint32_t)wv * 32u + g8, trips, brec, s16, list_a, (uint32_t)kQuadListCap);
+                if (n_link <= (uint32_t)kQuadListCap) {
+                    chain(n_link, list_a, list_b);
                 } else {
-                    // more overflow than the table holds (a tile of very long lists): the static part, then the overflow C descriptors at a time
-                    for (int lo = 0; lo < n_ovf; lo += C) {
-                        if (lo > 0) lds_barrier();                       // (the walk of the round before has read the table)
-                        const int n_pad = emit(lo, min(n_ovf, lo + C));
-                        lds_barrier();
-                        const int from = lo == 0 ? 0 : n_static;
-                        quad_walk_asm(desc_lds + (uint32_t)(from + wv * 4 + (lane >> 4)) * 8u, (uint32_t)((n_pad - from) / 64), brec, (uint32_t)(lane & 15) * 16u);
+                    // more links than the list holds (a tile of very long lists): the postings of the table's chunks are added, their links
+                    // are collected again, as many steps at a time as the list has room for
+                    constexpr uint32_t kSeg = kQuadListCap / 4;
+                    for (uint32_t t0 = 0; t0 < trips; t0 += kSeg) {
+                        const uint32_t n = quad_collect_asm(desc_lds + (uint32_t)wv * 32u + g8 + t0 * 512u, min(kSeg, trips - t0), brec, s16, list_a, (uint32_t)kQuadListCap);
+                        chain(n, list_a, list_b);
                     }
-                    lap(1);
                 }
-                // the next block's bitmap -> LDS (its words were fetched a block ago)
-                if (b + 2 < b1 && tid < bm_words) bitmap[tid] = bm_next;
             }
-            if (a.gtau && tid < nq) { const unsigned long long g = a.gtau[q0 + tid]; if (g > tau[tid]) tau[tid] = g; }
-            lds_barrier();                                               // the block's sums are complete; the bitmap is in place
-            lap(2);
+            lap(1);
+            // Lock step (BpArgs::pace): the tiles of a chunk of blocks sweep the same blocks; a workgroup that falls behind the pack loses
+            // the L2 / Infinity Cache copies the others left behind and falls further behind (21 M docs: most workgroups take 133 ms,
+            // a handful 165 - 170, and the launch ends with the last).  An item counts its arrival at the end of block j and waits while
+            // the slowest item of its chunk has not reached block j - window (bounded: pace_wait, bp_walk.h).  Window 2 - 8 blocks: 141 - 143 ms,
+            // 16: 152, 32: 161, free running: 134 - 166 (run to run).
+            if (a.pace && items <= (int64_t)gridDim.x && tid == 0 && have && !pace_off) {
+                uint32_t* pc = a.pace + (size_t)c * a.blocks_per_chunk;
+                const int64_t rel = b - b0;
+                __hip_atomic_fetch_add(pc + rel, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (rel >= a.pace_window) {
+                    const uint32_t need = (uint32_t)(items / a.nchunk);
+                    if (!pace_wait(pc + rel - a.pace_window, need)) pace_off = true;
+                }
+            }
             if (b + 1 < b1) base_cur = a.base[b + 1];
-            if (have && b + 2 < b1) {
-                fetch_dir(b + 2, ndb);                                   // gathers of the flagged entries: a whole block to land
-                if (b + 3 < b1 && tid < bm_words) bm_next = a.ovf_bits[(size_t)(b + 3) * bm_words + tid];
-            }
-            lap(0);                                                      // (phase 0 = issuing the directory gathers)
+            if (a.gtau && tid < nq) { const unsigned long long g = a.gtau[q0 + tid]; if (g > tau[tid]) tau[tid] = g; }
+            lds_barrier();                                               // the block's sums are complete
+            lap(2);
             // epilogue: 1024 documents at a time, one per thread: its QT sums -> order keys -> candidates; prune when a buffer could overflow
             for (int d0 = 0; d0 < rows_b || d0 == 0; d0 += kScanThreads) {
                 const int d = d0 + tid;
@@ -480,17 +425,12 @@ __global__ __launch_bounds__(kScanThreads) void bp_quad_topk(BpArgs a) {
             }
             lap(4);
             if constexpr (TM != 0) tacc[5] += 1u;
-        };
-        for (int64_t b = b0;; b += 2) {
-            one_block(b, nd);
             if (b + 1 >= b1) break;
-            one_block(b + 1, nd2);
-            if (b + 2 >= b1) break;
         }
         if constexpr (TM != 0) {
             if ((tid & 63) == 0) {
 #pragma unroll
-                for (int i = 0; i < 12; ++i) atomicAdd(a.timing + i, (unsigned long long)tacc[i]);
+                for (int i = 0; i < 6; ++i) atomicAdd(a.timing + i, (unsigned long long)tacc[i]);
             }
         }
     }

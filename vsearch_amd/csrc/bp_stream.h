@@ -60,6 +60,7 @@ __global__ __launch_bounds__(kScanThreads) void bp_stream_topk(BpArgs a) {
     uint64_t* my_gcand = a.gcand + (size_t)blockIdx.x * QT * kFlCap;
     const int64_t n_blocks = (a.n_rows + a.rows - 1) / a.rows;
     const int64_t items = (int64_t)(a.n_tiles_dev ? a.n_tiles_dev[0] : a.n_tiles) * a.nchunk;
+    bool pace_off = false;                      // the lock-step wait timed out once (pace_wait): this workgroup runs free from then on
     const size_t dir_ld = (size_t)a.n_cols + 1;
     const unsigned long long k_rt0 = a.timing ? __builtin_amdgcn_s_memrealtime() : 0ull;
     const long long k_c0 = a.timing ? (long long)__builtin_readcyclecounter() : 0;
@@ -321,13 +322,13 @@ __global__ __launch_bounds__(kScanThreads) void bp_stream_topk(BpArgs a) {
         auto finish_block = [&](const int b, const bool real) {
             if (a.gtau && tid < nq) { const unsigned long long g = a.gtau[q0 + tid]; if (g > tau[tid]) tau[tid] = g; }
             lap(1);
-            if (real && a.pace && items <= (int64_t)gridDim.x && tid == 0) {
+            if (real && a.pace && items <= (int64_t)gridDim.x && tid == 0 && !pace_off) {
                 uint32_t* pc = a.pace + (size_t)c * a.blocks_per_chunk;
                 const int rel = b - b0;
                 __hip_atomic_fetch_add(pc + rel, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (rel >= a.pace_window) {
                     const uint32_t need = (uint32_t)(items / a.nchunk);
-                    while (__hip_atomic_load(pc + rel - a.pace_window, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(8);
+                    if (!pace_wait(pc + rel - a.pace_window, need)) pace_off = true;
                 }
             }
             __syncthreads();

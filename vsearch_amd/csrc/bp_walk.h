@@ -394,6 +394,19 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_kernel(const uint32_t* c
 }
 
 // ---- walk ---------------------------------------------------------------------------------------------------------
+// Lock-step wait of the walks (BpArgs::pace): polls until *p >= need.  BOUNDED: lock step is a performance hint that assumes
+// every work item of the launch is resident; when another kernel shares the GPU -- several shards of a shard group on one device, two
+// processes, masked CUs -- the peers may never be scheduled, and an unbounded wait is a GPU hang.  After kPaceSpins polls (~ 20 ms) the
+// caller gives up lock step for the rest of the launch (returns false).
+constexpr int kPaceSpins = 1 << 16;
+__device__ __forceinline__ bool pace_wait(const uint32_t* p, uint32_t need) {
+    for (int spins = 0; spins < kPaceSpins; ++spins) {
+        if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) return true;
+        __builtin_amdgcn_s_sleep(8);
+    }
+    return false;
+}
+
 struct BpArgs {
     int32_t rows;             // documents per block (<= the kernel's RMAX)
     const uint32_t* dir;      // [n_blocks, n_cols + 1] one word per list (bp_dir_pack)
@@ -423,7 +436,6 @@ struct BpArgs {
     const __half* strip;      // fp16 values of the head columns, MFMA operand order (bp_strip_index)
     int32_t n_head;
     float head_pre, head_mul; // powers of two: weights enter the fp16 operand as w * scale * head_pre (< 2^15), the sums leave as C * head_mul
-    const uint32_t* ovf_bits; // quad walk: [n_blocks][quad_bitmap_words] columns of a block whose list overflows its main chunk
     uint32_t* pace;           // optional [nchunk][blocks_per_chunk], zeroed per search: work items that have finished a block (flat walk: lock-step window)
     int32_t pace_window;      // blocks an item may run ahead of the slowest item of its chunk
     int32_t knob;             // developer switches (VS_BP_KNOB)
@@ -557,6 +569,7 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
     uint64_t* my_gcand = a.gcand + (size_t)blockIdx.x * QT * kBpCap;
     const int64_t n_blocks = (a.n_rows + a.rows - 1) / a.rows;
     const int64_t items = (int64_t)(a.n_tiles_dev ? a.n_tiles_dev[0] : a.n_tiles) * a.nchunk;
+    bool pace_off = false;                      // the lock-step wait timed out once (pace_wait): this workgroup runs free from then on
     const size_t dir_ld = (size_t)a.n_cols + 1;
 
     const unsigned long long k_rt0 = a.timing ? __builtin_amdgcn_s_memrealtime() : 0ull;
@@ -912,13 +925,13 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
             // Infinity-Cache copies the pack left behind and falls further behind (per-workgroup clocks of a 4 M-doc run: 250 of 256
             // at 31 ms, a handful at 41 ms -- and the launch ends with the last).  An item counts its arrival at the end of block j
             // and waits while the slowest item of its chunk has not reached block j - window.  Only when every item is resident.
-            if (a.pace && items <= (int64_t)gridDim.x && tid == 0 && have) {
+            if (a.pace && items <= (int64_t)gridDim.x && tid == 0 && have && !pace_off) {
                 uint32_t* pc = a.pace + (size_t)c * a.blocks_per_chunk;
                 const int64_t rel = b - b0;
                 __hip_atomic_fetch_add(pc + rel, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (rel >= a.pace_window) {
                     const uint32_t need = (uint32_t)(items / a.nchunk);
-                    while (__hip_atomic_load(pc + rel - a.pace_window, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(8);
+                    if (!pace_wait(pc + rel - a.pace_window, need)) pace_off = true;
                 }
             }
             __syncthreads();

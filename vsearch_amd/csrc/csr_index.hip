@@ -5,10 +5,16 @@
 #include "csr_scan_mq.h"
 #include "bp_walk.h"
 #include "bp_refine.h"
-#include "bp_flat.h"
-#include "bp_stream.h"
 #include "bp_bin.h"
+// The three experimental walks of round 3 (flat worklists, streamed flat walk, two accumulator sets: all correct, all slower than the
+// list walk -- docs/EXPERIMENTS.md) are lab results, not components: compiled only with -DVS_EXPERIMENTAL_WALKS (make EXPERIMENTAL=1).
+// (bp_flat.h itself stays in: the bag-of-token walk, bp_bin.h, shares its candidate handling)
+#ifdef VS_EXPERIMENTAL_WALKS
+#include "bp_stream.h"
 #include "bp_duo.h"
+#else
+namespace vs { constexpr int kDuoMaxK = 0, kDuoEntCap = 0, kDuoQT = 4; }
+#endif
 #include "bp_quad.h"
 #include "synth_device.h"
 
@@ -760,9 +766,14 @@ constexpr int kFlRoundsF16 = 8, kFlRoundsF32 = 5;     // record loads in flight 
 // which walk serves the fixed-point filter of this index: 0 = a list per lane group (bp_walk.h), 1 = flat worklists (bp_flat.h),
 // 2 = the list walk on two accumulator sets, no block barrier (bp_duo.h), 3 = flat worklists, record loads software-pipelined (bp_stream.h)
 int bp_walk_kind(const vs_index* idx) {
+#ifdef VS_EXPERIMENTAL_WALKS
     const bool can = !idx->bp_quad && idx->store_dtype != VS_NONE && idx->bp_n_head == 0 && idx->bp_max_block_recs < ((int64_t)1 << kFlRecBits) - 4096;
     if (!can) return 0;
-    return idx->bp_walk_pref < 0 ? 0 : idx->bp_walk_pref;
+    return idx->bp_walk_pref < 0 || idx->bp_walk_pref > 3 ? 0 : idx->bp_walk_pref;
+#else
+    (void)idx;
+    return 0;
+#endif
 }
 template <int AM>
 bool bp_flat_ok(const vs_index* idx, const BpArgs& a) { return AM == AM_FIX && !a.upper && bp_walk_kind(idx) >= 1; }
@@ -775,9 +786,10 @@ int launch_bp_walk(const vs_index* idx, const BpArgs& a, int grid, int ent_cap, 
     void (*kern)(BpArgs) = nullptr;
     if (idx->bp_quad) {
         // quad chunks (bp_quad.h): the fixed-point filter walk only
-        if (AM != AM_FIX || a.upper || ent_cap > kBpEntCap || !a.ovf_bits) return fail(VS_EUNSUPPORTED, "quad postings serve the filter walk only");
+        if (AM != AM_FIX || a.upper || ent_cap > kBpEntCap) return fail(VS_EUNSUPPORTED, "quad postings serve the filter walk only");
         kern = a.timing ? bp_quad_topk<1> : bp_quad_topk<0>;
-        lds = quad_lds_bytes(idx->n_cols);
+        lds = quad_lds_bytes();
+#ifdef VS_EXPERIMENTAL_WALKS
     } else if (AM == AM_FIX && bp_duo_ok(idx, a.k, a.upper) && ent_cap <= kDuoEntCap) {
         if (vm == VM_F32) kern = bp_duo_topk<VM_F32, kBpNB, kBpRowsMax>;
         else kern = bp_duo_topk<VM_F16, kBpNBWide, kBpRowsMax>;
@@ -790,6 +802,7 @@ int launch_bp_walk(const vs_index* idx, const BpArgs& a, int grid, int ent_cap, 
         // valued records, no dense strips, fixed-point filter: the flat walk (bp_flat.h)
         if (vm == VM_F32) { kern = bp_flat_topk<VM_F32, kFlRoundsF32, kBpRowsMax>; lds = bp_flat_lds_bytes<kFlRoundsF32, kBpRowsMax>(ent_cap); }
         else { kern = bp_flat_topk<VM_F16, kFlRoundsF16, kBpRowsMax>; lds = bp_flat_lds_bytes<kFlRoundsF16, kBpRowsMax>(ent_cap); }
+#endif
     } else if (vm == VM_BIN && AM == AM_FIX && idx->bp_walk_pref != 0 && !a.upper && ent_cap <= kBpEntCap) {
         // bag-of-token index: the walk with the next block's records prefetched across the barrier (bp_bin.h); postings_walk = 0: the list walk
         kern = bp_bin_topk<kBpRowsMaxBin>;
@@ -834,8 +847,8 @@ int bp_build(vs_index* idx, hipStream_t s) {
     auto auto_rows = [&]() -> int {
         if (idx->store_dtype == VS_NONE) return kBpRowsMaxBin;
         const double avg = idx->n_rows > 0 ? (double)idx->nnz / (double)idx->n_rows : 1.0;
-        // (quad: ~ 54 postings a list -- 1 list in 15 spills into a second 64-cell chunk; 768-nnz documents: 2048)
-        const int r = (int)((quad_pref ? 54.0 : 50.0) * (double)idx->n_cols / std::max(avg, 1.0)) / 128 * 128;
+        // (quad chunks: at 50 postings a list 1 list in 40 goes on in an overflow chunk; 2048 documents per block measured the same)
+        const int r = (int)(50.0 * (double)idx->n_cols / std::max(avg, 1.0)) / 128 * 128;
         return std::max(256, std::min(r, kBpRowsMax));
     };
     idx->bp_rows = idx->bp_rows_pref > 0 ? std::min(idx->bp_rows_pref, idx->store_dtype == VS_NONE ? kBpRowsMaxBin : kBpRowsMax)
@@ -884,7 +897,7 @@ int bp_build(vs_index* idx, hipStream_t s) {
     float vmax_f;
     memcpy(&vmax_f, &hv[0], 4);
     const bool lossy_ok = hv[1] == 0u && vmax_f < 60000.f;       // fp16 copies of the values: non-negative, no overflow
-    const bool quad = quad_pref && (idx->store_dtype == VS_F16 || lossy_ok);
+    const bool quad = quad_pref && lossy_ok;                        // (non-negative values: a set sign bit marks a link)
     // Lossy filter copy of an fp32 index: values rounded to fp16 (4 instead of 6 bytes per posting); needs the filter-and-refine
     // search, non-negative values and no fp16 overflow
     idx->bp_quant = idx->store_dtype == VS_F32 && idx->bp_filter != 0 && idx->bp_quant_pref != 0 && lossy_ok;
@@ -893,14 +906,13 @@ int bp_build(vs_index* idx, hipStream_t s) {
     DevBuf ovf;
     VS_TRY(ovf.alloc(4));
     VS_HIP(hipMemsetAsync(ovf.p, 0, 4, s));
-    const int bm_words = quad_bitmap_words(V);
     if (quad) {
-        // quad chunks: main chunk of column c = chunk c of its block, overflow chunks behind; the directory and a bitmap describe the overflow
-        const size_t b_ovf = (size_t)n_blocks * bm_words * 4, b_main = (size_t)n_blocks * V * kQuadChunkBytes;
-        if (free_b < b_dir + b_ovf + b_main + margin || idx->bp_ovf.alloc(b_ovf) != VS_OK) return no_room(b_dir + b_ovf + b_main);
+        // quad chunks: main chunk of column c = chunk c of its block, overflow chunks behind (the directory is the builder's only)
+        const size_t b_main = (size_t)n_blocks * V * kQuadChunkBytes;
+        if (free_b < b_dir + b_main + margin) return no_room(b_dir + b_main);
         VS_HIP(hipFuncSetAttribute((const void*)quad_count_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(quad_count_kernel<0>, dim3(grid), dim3(kScanThreads), lds, s, idx->pk_ptr.as<uint32_t>(), idx->cols.as<uint4>(), idx->n_rows, V, idx->bp_rows,
-                           idx->bp_dir.as<uint32_t>(), idx->bp_ovf.as<uint32_t>(), bm_words, block_recs.as<uint32_t>(), df_rec, df_nnz, ovf.as<int32_t>());
+                           idx->bp_dir.as<uint32_t>(), block_recs.as<uint32_t>(), df_rec, df_nnz, ovf.as<int32_t>());
     } else {
         VS_HIP(hipFuncSetAttribute((const void*)bp_count_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(bp_count_kernel<0>, dim3(grid), dim3(kScanThreads), lds, s, idx->pk_ptr.as<uint32_t>(), idx->cols.as<uint4>(), idx->n_rows, V, idx->bp_rows,
@@ -932,6 +944,7 @@ int bp_build(vs_index* idx, hipStream_t s) {
             // a skewed corpus: its lists are long whatever the block size, and the dense strips and the per-block costs want the
             // largest blocks (zipf 21 M docs: 289 ms at 2048 documents per block, 301 at 1920) -- start over with those
             idx->bp_rows_forced = kBpRowsMax;
+            idx->bp_no_quad = true;                               // (head columns: the restart must not try quad chunks again)
             return bp_build(idx, s);
         }
         if (h_n > 0) {
@@ -989,6 +1002,8 @@ int bp_build(vs_index* idx, hipStream_t s) {
         VS_HIP(hipGetLastError());
         VS_STAGE("quad_arrange", s);
         idx->bp_quad = true;
+        VS_HIP(hipStreamSynchronize(s));
+        idx->bp_dir.release();                                           // (the chunks link to their overflow themselves)
         idx->bp_quant = idx->store_dtype == VS_F32;                      // fp16-rounded values of an fp32 index: the refine step's bound accounts for them
     } else {
         void (*fill)(const uint32_t*, const uint4*, const void*, int64_t, int32_t, int32_t, const uint32_t*, const unsigned long long*, char*, const uint16_t*, __half*, int32_t, int32_t) =
@@ -1171,9 +1186,6 @@ int bp_filter_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64
     a.gcand = idx->ws_mq_cand.as<uint64_t>();
     a.qscale = qscale;
     a.gtau = gtau;
-    if (idx->bp_quad) {
-        a.ovf_bits = idx->bp_ovf.as<uint32_t>();
-    }
     a.df = idx->bp_df.p ? idx->bp_df.as<unsigned long long>() + V : nullptr;          // (second half of bp_df: non-zeros per column)
     a.hmap = idx->bp_n_head > 0 ? idx->bp_hmap.as<uint16_t>() : nullptr;
     a.strip = idx->bp_strip.as<__half>();
@@ -1194,7 +1206,7 @@ int bp_filter_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64
     //  NEEDS it: free running 81 ms, window 16: 66.7, 32: 56.5, 48: 57.2, 64: 58.7, 128: 73 -- the list walk: 61.3)
     const bool bin_walk = idx->store_dtype == VS_NONE && idx->bp_walk_pref != 0;
     // (the two-set walk has no block barrier to keep its workgroups at one pace: 4 M docs 56.9 ms free running, window 1: 39.8, 2: 37.9, 4: 42.2)
-    const int pace_w = pace_env >= 0 ? pace_env : (idx->bp_pace >= 0 ? idx->bp_pace : (bin_walk ? 32 : (duo ? 2 : 0)));
+    const int pace_w = pace_env >= 0 ? pace_env : (idx->bp_pace >= 0 ? idx->bp_pace : (bin_walk ? 32 : (duo ? 2 : (idx->bp_quad ? kQuadPaceDefault : 0))));
     if (pace_w > 0) {
         VS_TRY(idx->ws_pace.reserve((size_t)nchunk * a.blocks_per_chunk * 4));
         VS_HIP(hipMemsetAsync(idx->ws_pace.p, 0, (size_t)nchunk * a.blocks_per_chunk * 4, s));
