@@ -36,6 +36,8 @@ K = 100
 INDEX_SEED, QUERY_SEED = 0, 1
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 LDS_ADD_U32_PEAK = 5.0e12    # ds_add_u32 at random addresses, all 256 CUs (profiles/r02_lds_scatter.txt)
+MFMA_F32_PEAK_TF = 157.3     # fp32-input MFMA = the fp32 vector peak (MI355X_MICROARCH.md)
+WALK_KERNEL = {-1: "csr_scan_topk_mq", 0: "bp_walk_topk", 4: "bp_quad_topk", 5: "bp_bin_topk"}     # vs_index_info_t.postings_walk -> the filter's kernel
 
 
 def parse():
@@ -65,13 +67,37 @@ KIND = {"uniform": 0, "zipf": 2}
 
 
 def kernel_source_hash():
-    """sha256 over the sources of the scan kernels: a PMC profile under profiles/ is only quoted for the build it was taken on."""
+    """sha256 over the library's sources: a PMC profile under profiles/ is only quoted for the build it was taken on."""
+    import glob
     import hashlib
     h = hashlib.sha256()
-    for f in ("bp_walk.h", "bp_refine.h", "csr_scan.h", "csr_scan_mq.h", "csr_index.hip", "common.h"):
-        with open(os.path.join(REPO, "vsearch_amd", "csrc", f), "rb") as fh:
+    src = os.path.join(REPO, "vsearch_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(src, "*.h")) + glob.glob(os.path.join(src, "*.hip"))):
+        with open(f, "rb") as fh:
             h.update(fh.read())
+    return hexd(h)
+
+
+def hexd(h):
     return h.hexdigest()[:16]
+
+
+def roof(bound, achieved, peak, unit, **extra):
+    """a `roofline` object of a secondary leg: achieved / peak of the resource that bounds the dominant kernel of the leg"""
+    return dict({"bound": bound, "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak}, **extra)
+
+
+def event_ms(fn, reps, warmup=2):
+    """average GPU time of fn() in ms (events on torch's current stream -- the stream the library launches on)"""
+    for _ in range(warmup):
+        fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
 
 
 def make_query_batches(n_batches, batch, device, kind=0):
@@ -114,7 +140,7 @@ def parity_check(device, kind=0, nnz_doc=NNZ_DOC, store=0, val_law=0, expect_pat
             "ids_bit_exact": bool((np.asarray(ids) == o_ids).all()) if exact else None}
 
 
-def parity_sharded(world, rank, local_rank, device, kind=0, n=40_000):
+def parity_sharded(world, rank, local_rank, device, kind=0, n=None, expect_path=None):
     """N > 1: the same check THROUGH the sharded path -- every rank holds its row range of a small synthetic index, the query batch
     goes through ShardedSearcher.search (local search, the one all-gather, merge), and rank 0 compares the merged result with the
     CPU oracle's over the whole index (rows regenerated on the host: a pure function of (seed, row id))."""
@@ -122,6 +148,7 @@ def parity_sharded(world, rank, local_rank, device, kind=0, n=40_000):
     from oracle import compare
     from vsearch_amd.device_index import DeviceIndex
     from vsearch_amd.distributed import ShardedSearcher, shard_rows
+    n = n or 20_000 * world              # every rank's shard is big enough for the path the measured run takes (the postings filter)
     row0, n_loc = shard_rows(n, world, rank)
     idx = DeviceIndex.synthetic(INDEX_SEED, row0, n_loc, V, NNZ_DOC, kind, 0, 0, local_rank)
     searcher = ShardedSearcher.from_device_index(idx, row0, n)
@@ -130,6 +157,8 @@ def parity_sharded(world, rank, local_rank, device, kind=0, n=40_000):
     ids, sc = ids.cpu().numpy(), sc.cpu().numpy()
     path = idx.info().last_path
     idx.close()
+    if expect_path is not None and path != expect_path:
+        raise AssertionError(f"rank {rank}: the sharded parity index took scan path {path}, the measured run took {expect_path}")
     if rank != 0:
         return None
     ip, ix, d = oracle.synth_csr(INDEX_SEED, 0, n, V, NNZ_DOC, kind)
@@ -235,10 +264,20 @@ def secondary(index, batches, args, local_rank, device, headline_s):
         Profile.enable(False)
         scan_ms, launches = Profile.read("csr_scan_topk")
         info = idx.info()
+        launch_s = scan_ms / 1e3 / max(1, launches)                      # one scan launch per search
+        algo = info.last_scan_bytes / launch_s / 1e9 if launch_s > 0 else 0.0
         rec = {"docs": docs, "nnz_per_doc": nnz, "columns": columns, "batch": B, "k": args.k, "steps": steps, "ms_per_step": dt * 1e3, "queries_per_sec": B / dt,
-               "scan_path": info.last_path, "scan_kernel_ms": scan_ms / max(1, launches), "fallback_queries": info.last_fallbacks, "head_columns": info.head_columns,
-               "walk_adds_per_s": (info.last_walk_postings * launches / (steps + 1) / (scan_ms / 1e3)) if scan_ms > 0 and info.last_path >= 2 else None,
-               "bound": "on-chip (LDS scatter-adds / matrix cores for head strips), not HBM", "index_build_s": round(build_s, 2)}
+               "scan_path": info.last_path, "kernel": WALK_KERNEL.get(info.postings_walk, "?"), "scan_kernel_ms": launch_s * 1e3,
+               "fallback_queries": info.last_fallbacks, "head_columns": info.head_columns,
+               "walk_adds_per_s": (info.last_walk_postings / launch_s) if launch_s > 0 and info.last_path >= 2 else None,
+               # HBM roofline on the kernel's ALGORITHMIC bytes (chunks / records of the batch's posting lists): on the postings paths
+               # most of them are served by L2 / Infinity Cache, so the fraction can exceed 1 and is not HBM utilisation; the second figure
+               # is the one-pass bound of SURVEY 8(d) (Qt = B: the index streamed once per batch at the HBM peak)
+               "roofline": roof("hbm", algo, HBM_PEAK_GBS, "GB/s", achieved_is="algorithmic bytes of the scan kernel / its time (L2 / Infinity-Cache served: not HBM utilisation)",
+                                one_pass_lower_bound_ms=info.bytes_per_pass / (HBM_PEAK_GBS * 1e9) * 1e3,
+                                frac_of_one_pass_lower_bound=info.bytes_per_pass / (HBM_PEAK_GBS * 1e9) / launch_s if launch_s > 0 else None,
+                                frac_of_lds_add_peak=(info.last_walk_postings / launch_s / LDS_ADD_U32_PEAK) if launch_s > 0 and info.last_path >= 2 else None),
+               "index_build_s": round(build_s, 2)}
         idx.close()
         rec["parity"] = parity_check(local_rank, kind, nnz, store, val_law, expect_path=info.last_path, n=80_000 if kind == synth.KIND_BOT else 20_000, exact=exact)
         out[name] = rec
@@ -261,12 +300,19 @@ def secondary(index, batches, args, local_rank, device, headline_s):
         build_s = time.perf_counter() - t0
         t_one = _timed(lambda: shards[3].search(batches[0], args.k), 3)
         t_grp = _timed(lambda: grp.search(batches[0], args.k), 2)
+        grp.close()
+        # the same 8 row shards through the reference's API: SparseIndex(..., devices=[...]) keeps a shard group behind Index.search
+        fs = SparseIndex()
+        fs._dtype, fs._shape = torch.float32, (N_DOCS, V)
+        fs._adopt_shards(shards)
+        t_fac = _timed(lambda: fs.search(batches[0], args.k), 2)
         out["shard_group_8_on_one_gpu"] = {"shards": 8, "docs_per_shard": shard_rows(N_DOCS, 8, 0)[1], "ms_per_step": t_grp * 1e3, "single_shard_ms_per_step": t_one * 1e3,
                                            "overhead_ms_per_step": (t_grp - 8 * t_one) * 1e3, "queries_per_sec": B / t_grp, "index_build_s": round(build_s, 2),
                                            "note": "all 8 shards share ONE GPU here: the searches serialise; on 8 GPUs a step is the slowest shard's step + the exchange"}
-        grp.close()
-        for sh in shards:
-            sh.close()
+        out["facade_sharded"] = {"api": "vsearch_amd.ir.retriever.index.SparseIndex(index_file='shard*.npz', devices=[...]).search -> vs_shard_group_search "
+                                        "(reference: src/ir/retriever/index.py:88-94 on the vstack of its shards, :172-175)", "shards": 8, "devices": "8 x this one GPU",
+                                 "ms_per_step": t_fac * 1e3, "shard_group_ms_per_step": t_grp * 1e3, "overhead_frac": t_fac / t_grp - 1.0, "queries_per_sec": B / t_fac}
+        fs._drop_device()                                            # closes the group and the shards
     except Exception as e:                                       # (never lose the headline line to a secondary leg)
         out["shard_group_8_on_one_gpu"] = {"error": str(e)[:200]}
     for name, leg in (("C3", lambda: run("C3_1m_sparse", 1_000_000, NNZ_DOC, 0, nat.VS_F32, 0, 10)),
@@ -278,6 +324,96 @@ def secondary(index, batches, args, local_rank, device, headline_s):
             leg()
         except Exception as e:
             out.setdefault("errors", []).append(str(e)[:300])
+    # ---- the rest of the path under the same clock: dense index (C2), sparsify kernels, fused encoder head, rerank
+    def c2_dense():
+        n, b = 100_000, 256
+        g = torch.Generator(device=device).manual_seed(0)
+        mat = torch.zeros((n, V), device=device)
+        for s0 in range(0, n, 10000):
+            c = torch.rand((min(10000, n - s0), V), device=device, generator=g).topk(NNZ_DOC, dim=1).indices
+            mat[s0:s0 + c.shape[0]].scatter_(1, c, 0.01 + 3 * torch.rand(c.shape, device=device, generator=g))
+        q = torch.zeros((b, V), device=device)
+        qc = torch.rand((b, V), device=device, generator=g).topk(NNZ_Q, dim=1).indices
+        q.scatter_(1, qc, 0.01 + 3 * torch.rand(qc.shape, device=device, generator=g))
+        idx = DeviceIndex.from_dense(mat)
+        ids, sc = idx.search(q, args.k)
+        Profile.enable(True)
+        Profile.reset()
+        dt = _timed(lambda: idx.search(q, args.k), 5)
+        Profile.enable(False)
+        gemm_ms, launches = Profile.read("dense_scores")
+        flops = 2.0 * b * V * n
+        ref = (q @ mat.t()).topk(args.k)
+        rel = float(((ref.values - sc).abs() / ref.values).max().item())
+        same = float((ref.indices == ids).float().mean().item())
+        idx.close()
+        out["C2_dense_100k"] = {"docs": n, "batch": b, "k": args.k, "ms_per_step": dt * 1e3, "queries_per_sec": b / dt, "kernel": "dense_scores_kernel (v_mfma_f32_32x32x2_f32)",
+                                "dense_kernels_ms_per_step": gemm_ms / 5.0,
+                                "roofline": roof("mfma", flops / (gemm_ms / 5.0 * 1e9), MFMA_F32_PEAK_TF, "TFLOP/s", achieved_is="2 B V N flop / time of the step's dense kernels (fp32 in, fp32 accumulate)"),
+                                "parity": {"vs": "torch.matmul(q, P.t()).topk(k) on this GPU (index.py:91-92)", "max_rel_score_err": rel, "ids_equal_frac": same}}
+
+    def sparsify():
+        from vsearch_amd.ir.utils import sparse as sp
+        VOC, SHIFT, L = 30522, 999, 128
+        g = torch.Generator(device=device).manual_seed(0)
+        emb = torch.rand((B, V), device=device, generator=g) * 3
+        tok = torch.randint(SHIFT, VOC, (B, L), device=device, generator=g)
+        e2 = emb.clone()
+        ms = event_ms(lambda: sp.apply_embed_mask_(e2, tok, VOC, SHIFT, NNZ_DOC, True), 50)
+        byts = 2.0 * B * V * 4
+        out["embed_mask_B1024"] = {"what": "VDREncoder.embed mask stage (vdr.py:152-169): top-768 | lexical mask applied in place to [1024, 29523] fp32", "ms": ms,
+                                   "kernel": "mask_rows_kernel", "roofline": roof("hbm", byts / (ms * 1e6), HBM_PEAK_GBS, "GB/s", achieved_is="one read + one write of [B, V] fp32 / time")}
+        sparse = sp.topk_sparsify(emb, NNZ_DOC)
+        ms = event_ms(lambda: sp.dense_to_csr(sparse), 50)
+        byts = B * V * 4.0 + B * NNZ_DOC * 8.0
+        out["dense_to_csr_B1024"] = {"what": "Tensor.to_sparse_csr() of the sparsified batch (retriever.py:304)", "ms": ms, "kernel": "count_nz / scan_counts / fill_csr",
+                                     "roofline": roof("hbm", byts / (ms * 1e6), HBM_PEAK_GBS, "GB/s", achieved_is="one read of [B, V] fp32 + the CSR written / time (the kernels read the matrix twice)")}
+        Bh, Lh, H = 64, 256, 768
+        hid = torch.randn((Bh, Lh, H), device=device, generator=g)
+        w = torch.randn((V, H), device=device, generator=g) * 0.05
+        ms = event_ms(lambda: sp.head_project_pool(hid, w), 5, 1)
+        flops = 2.0 * Bh * Lh * H * V
+        out["head_project_pool_64x256"] = {"what": "fused encoder head (vdr.py:70-75): LN(hidden) . W^T -> max over positions -> elu1p, [64, 256, 768] x [29523, 768]", "ms": ms,
+                                           "kernel": "dense_scores_kernel (pool mode)", "roofline": roof("mfma", flops / (ms * 1e9), MFMA_F32_PEAK_TF, "TFLOP/s", achieved_is="2 B L H V flop / time (fp32 MFMA)")}
+
+    def rerank():
+        import ctypes as C
+        from vsearch_amd.device_index import current_stream
+        k, chunk = args.k, 8192
+        g = torch.Generator(device=device).manual_seed(0)
+        q = torch.zeros((B, V), device=device)
+        qc = torch.rand((B, V), device=device, generator=g).topk(NNZ_Q, dim=1).indices
+        q.scatter_(1, qc, 0.01 + 3 * torch.rand(qc.shape, device=device, generator=g))
+        p_emb = torch.zeros((chunk, V), device=device)
+        pc = torch.rand((chunk, V), device=device, generator=g).topk(NNZ_DOC, dim=1).indices
+        p_emb.scatter_(1, pc, 0.01 + 3 * torch.rand(pc.shape, device=device, generator=g))
+        scores = torch.empty((B, k), dtype=torch.float32, device=device)
+        ids = torch.arange(B * k, device=device, dtype=torch.int64).reshape(B, k)
+        o_ids, o_sc = torch.empty_like(ids), torch.empty_like(scores)
+        dev = device.index or 0
+
+        def run_all():
+            st = current_stream(dev)
+            for r0 in range(0, B * k, chunk):
+                rows = min(chunk, B * k - r0)
+                nat.check(nat.lib().vs_rerank_scores(C.c_void_p(p_emb.data_ptr()), nat.VS_F32, V, rows, r0, C.c_void_p(q.data_ptr()), V, B, k, V,
+                                                     C.c_void_p(scores.data_ptr()), dev, st))
+            nat.check(nat.lib().vs_rerank_topk(C.c_void_p(scores.data_ptr()), C.c_void_p(ids.data_ptr()), B, k, C.c_void_p(o_ids.data_ptr()),
+                                               C.c_void_p(o_sc.data_ptr()), dev, st))
+        ms = event_ms(run_all, 3, 1)
+        byts = float(B) * k * V * 4
+        out["rerank_1024x100"] = {"what": "retrieve(rerank=True) scoring stage (retriever.py:137-147): 102 400 re-embedded passages [.., 29523] fp32 against their queries + stable top-k",
+                                  "ms": ms, "kernel": "rerank_scores_kernel + rerank_topk_kernel",
+                                  "roofline": roof("hbm", byts / (ms * 1e6), HBM_PEAK_GBS, "GB/s", achieved_is="the dense passage rows read once / time")}
+
+    for name, leg in (("C2", c2_dense), ("sparsify", sparsify), ("rerank", rerank)):
+        if not want(name):
+            continue
+        try:
+            leg()
+        except Exception as e:
+            out.setdefault("errors", []).append(f"{name}: {str(e)[:300]}")
+        torch.cuda.empty_cache()
     out["headline_ms_per_step"] = headline_s * 1e3
     return out
 
@@ -369,7 +505,7 @@ def main():
     if rank == 0 and args.dump_ids:
         np.savez(args.dump_ids, ids=ids.cpu().numpy(), scores=scores.cpu().numpy())
     # N > 1: the oracle check through the sharded path (all ranks search, rank 0 compares); after the timed region
-    sharded_parity = parity_sharded(world, rank, local_rank, device, kind) if world > 1 else None
+    sharded_parity = parity_sharded(world, rank, local_rank, device, kind, expect_path=index.info().last_path if n_local >= 20_000 and args.scan == "auto" else None) if world > 1 else None
 
     if rank == 0:
         qps = args.steps * args.batch / elapsed
@@ -384,8 +520,8 @@ def main():
         avg_launch_s = scan_ms / 1e3 / max(1, scan_launches)
         achieved = algo_bytes_per_launch / avg_launch_s / 1e9
         path = {0: "csr scan, one query per pass", 1: "csr scan, 8 queries per pass", 2: "blocked postings, fp64 walk, 4 queries per tile",
-                3: "blocked postings: int32 fixed-point filter walk (8 queries per tile) + exact refine of k+28 candidates"}[info.last_path]
-        kernel = {0: "csr_scan_topk_wave", 1: "csr_scan_topk_mq", 2: "bp_walk_topk", 3: "bp_walk_topk"}[info.last_path]
+                3: ("quad chunks" if info.postings_walk == 4 else "blocked postings") + ": int32 fixed-point filter walk (8 queries per tile) + exact refine of k+28 candidates"}[info.last_path]
+        kernel = {0: "csr_scan_topk_wave", 1: "csr_scan_topk_mq", 2: "bp_walk_topk", 3: WALK_KERNEL.get(info.postings_walk, "bp_walk_topk")}[info.last_path]
         csr_equiv = -(-args.batch // qt) * info.bytes_per_pass / launches_per_step / avg_launch_s / 1e9
         traffic, traffic_src = None, None
         pmc = os.path.join(REPO, "profiles", "pmc_summary.json")
@@ -406,7 +542,8 @@ def main():
         hbm_frac = (traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS) if traffic else None
         adds_per_s = info.last_walk_postings / launches_per_step / avg_launch_s if info.last_path >= 2 else None
         if info.last_path >= 2:
-            bound = "hbm" if (hbm_frac or 0.0) > 0.5 else "on-chip: LDS scatter-adds into random document slots (bank conflicts; ds_add_u32) + the L2->L1 record loads they overlap with"
+            bound = "hbm" if (hbm_frac or 0.0) > 0.5 else ("on-chip: the walk's VALU / LDS-atomic / L1 issue together (each ~ 2/3 busy; DESIGN 4) under the board's "
+                                                           "sustained-power clock, not HBM")
         else:
             bound = "hbm"
         # `achieved` / `frac`: the HBM rate the counters evidence when a matching PMC profile exists (the honest HBM fraction);

@@ -92,6 +92,10 @@ typedef struct vs_index_info_t {
     int32_t postings_state;  /* the blocked-postings copy: 0 = not attempted yet, 1 = built, 2 = NOT built: no room in HBM (sparse
                               * queries take the ~10x slower CSR scan), 3 = NOT built: a block holds more records than a directory
                               * word addresses, 4 = not wanted (small / short-row index, or option "blocked_postings" = 0)          */
+    int32_t postings_walk;   /* which walk serves the filter on the copy that was built: 0 = list walk over 8-posting records,
+                              * 4 = quad walk over 64-cell chunks (the default of a valued index), 5 = bag-of-token walk;
+                              * -1 = no copy                                                                                     */
+    int32_t reserved0;
 } vs_index_info_t;
 
 /* ---- library ------------------------------------------------------------------------------- */

@@ -489,3 +489,67 @@ def test_mean_pooling_with_pooling_topk():
         torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-6)
     with pytest.raises(RuntimeError):
         sp.head_pool_mean_topk(logits[:, :8], 9)
+
+
+# ---- row shards over several GPUs through the reference's API --------------------------------------------
+def _write_shard_files(tmp_path, n_files, rows_per_file, binary=False, seed=11):
+    """`n_files` scipy .npz shards of one synthetic corpus (the reference's per-shard build, examples/inference_sparse/README.md:90-107)"""
+    from scipy.sparse import csr_array, save_npz
+    n = n_files * rows_per_file
+    ip, ix, d = oracle.synth_csr(seed, 0, n, V, 86 if binary else 768, 1 if binary else 0)
+    if binary:
+        d = np.ones(len(ix), dtype=np.float32)
+    for s in range(n_files):
+        r0, r1 = s * rows_per_file, (s + 1) * rows_per_file
+        sl = slice(ip[r0], ip[r1])
+        save_npz(tmp_path / f"shard{s:02d}.npz", csr_array((d[sl], ix[sl].astype(np.int64), (ip[r0:r1 + 1] - ip[r0]).astype(np.int64)), shape=(rows_per_file, V)))
+    return ip, ix, d
+
+
+@pytest.mark.parametrize("n_files,n_devices", [(2, 2), (8, 8), (8, 3)])
+def test_sparse_index_row_sharded_over_devices_equals_the_unsharded_index(tmp_path, n_files, n_devices):
+    """SparseIndex(index_file="shard*.npz", devices=[...]): the shard files are dealt to the GPUs in row order (here: all the same
+    GPU -- the box has one), search goes through vs_shard_group_*: ids and scores equal the unsharded facade's bit for bit."""
+    rows = 24_000 // n_files
+    ip, ix, d = _write_shard_files(tmp_path, n_files, rows)
+    pattern = str(tmp_path / "shard*.npz")
+    one = SparseIndex(pattern, None, fp16=False, device="cuda")
+    many = SparseIndex(pattern, None, fp16=False, device="cuda", devices=[0] * n_devices)
+    assert many.shards is not None and len(many.shards) == min(n_files, n_devices) and one.shards is None
+    assert sum(s.info().n_rows for s in many.shards) == n_files * rows
+    q = torch.from_numpy(oracle.synth_queries(3, 16))
+    a, b = one.search(q, 100), many.search(q, 100)
+    assert (a.ids.cpu() == b.ids.cpu()).all() and (a.scores.cpu() == b.scores.cpu()).all()
+    o_ids, o_sc, allsc = oracle.csr_search(ip, ix, d, V, q.numpy(), 100, acc64=True, return_all=True)
+    compare.check_topk_valid(allsc, b.ids.cpu().numpy(), b.scores.float().cpu().numpy(), rtol=RTOL)
+    # the `vector` of a sharded index is the shards' rows re-joined (index.py:175)
+    v = many.vector
+    assert tuple(v.shape) == (n_files * rows, V) and (v.crow_indices().cpu().numpy() == ip).all()
+    # Retriever.load_index(devices=...) builds the same thing
+    rt = Retriever.__new__(Retriever)
+    torch.nn.Module.__init__(rt)
+    rt._dummy = torch.nn.Parameter(torch.zeros(1, device="cuda"))
+    Retriever.load_index(rt, index_file=pattern, devices=[0, 0])
+    assert isinstance(rt.index, SparseIndex) and len(rt.index.shards) == 2
+    c = rt.index.search(q.to(torch.float16), 100)                       # (load_index keeps the reference's fp16=True default)
+    assert c.scores.dtype == torch.float16
+
+
+def test_bot_index_row_sharded_two_shards_on_one_device_with_lock_step():
+    """Two bag-of-token shards on ONE device, B >= 16: their walks run concurrently on two streams with the lock-step window on
+    (an unbounded lock-step wait hangs the GPU when the peers are not resident).  Bit-equal to the unsharded index."""
+    from vsearch_amd import _native as nat
+    from vsearch_amd.device_index import DeviceIndex, ShardGroup
+    n = 2 * 70_000
+    whole = DeviceIndex.synthetic(5, 0, n, V, 86, synth.KIND_BOT, 0, nat.VS_NONE)
+    halves = [DeviceIndex.synthetic(5, r0, n // 2, V, 86, synth.KIND_BOT, 0, nat.VS_NONE) for r0 in (0, n // 2)]
+    for h in halves + [whole]:
+        h.set_option("blocked_postings", 1)
+    grp = ShardGroup(halves)
+    q = torch.from_numpy(oracle.synth_queries(1, 64, V, 776, synth.VAL_DYADIC)).cuda()
+    ids, sc = whole.search(q, 100)
+    for _ in range(3):
+        g_ids, g_sc = grp.search(q, 100)
+        assert (g_ids.cpu() == ids.cpu()).all() and (g_sc.cpu() == sc.cpu()).all()
+    assert halves[0].info().last_path == 3
+    grp.close()

@@ -479,6 +479,8 @@ extern "C" int vs_index_info(const vs_index* idx, vs_index_info_t* o) {
     o->last_walk_postings = idx->last_walk_postings;
     o->head_columns = idx->bp_ready ? idx->bp_n_head : 0;
     o->postings_state = idx->bp_ready ? 1 : idx->bp_state;
+    o->postings_walk = !idx->bp_ready ? -1 : idx->bp_quad ? 4 : (idx->store_dtype == VS_NONE && idx->bp_walk_pref != 0) ? 5 : 0;
+    o->reserved0 = 0;
     if (idx->last_path == 3 && idx->last_plan_dev) {               // the filter search keeps its plan on the device: read it now
         int64_t hp[6] = {0, 0, 0, 0, 0, 0};
         VS_HIP(hipSetDevice(idx->device));

@@ -114,8 +114,14 @@ class DeviceIndex:
 
     def append_npz(self, path: str, shift: int = 0):
         """Append a scipy.sparse.save_npz CSR shard read natively (zip + npy parsed in the library): columns below `shift` dropped,
-        ids moved down by `shift`, sorted within a row.  NotImplementedError for non-CSR files."""
-        nat.check(nat.lib().vs_index_append_npz(self._h, str(path).encode(), int(shift)))
+        ids moved down by `shift`, sorted within a row.  NotImplementedError for non-CSR files; NotBinaryError when a binary
+        (bag-of-token) index meets a value other than 1."""
+        try:
+            nat.check(nat.lib().vs_index_append_npz(self._h, str(path).encode(), int(shift)))
+        except ValueError as e:
+            if "expects a binary matrix" in str(e):
+                raise NotBinaryError(str(e)) from None
+            raise
 
     def save_npz(self, path: str, compressed: bool = False):
         """Write the index as a scipy.sparse.save_npz file (CSR, int64 ids, fp32 data) without scipy."""
@@ -239,6 +245,10 @@ class DeviceIndex:
         out = np.empty((info.n_rows, info.n_cols), dtype=dtype)
         nat.check(nat.lib().vs_index_export_dense(self._h, C.c_void_p(out.ctypes.data), _NP2VS[np.dtype(dtype)], info.n_cols))
         return out
+
+
+class NotBinaryError(ValueError):
+    """a binary (bag-of-token) index was given a stored value other than 1"""
 
 
 class ShardGroup:

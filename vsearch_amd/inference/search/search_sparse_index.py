@@ -1,5 +1,5 @@
 """python -m vsearch_amd.inference.search.search_sparse_index --checkpoint=... --query_file=q.jsonl
-       --index_file='index*.npz' --save_file=results.json [--batch_size_q=32] [--topk=100] [--device=cuda]
+       --index_file='index*.npz' --save_file=results.json [--batch_size_q=32] [--topk=100] [--device=cuda] [--num_gpus=N]
 (examples/inference_sparse/README.md:115-128).  Output: JSON list of {"question", "ids", "scores"}."""
 import argparse
 import json
@@ -12,7 +12,9 @@ def run(args, index_type, rerank=False):
     logging.basicConfig(level=logging.INFO)
     queries = read_jsonl(args.query_file)
     model = load_retriever(args.checkpoint, args.device)
-    model.load_index(index_file=args.index_file, data_file=getattr(args, "text_file", None), index_type=index_type)
+    n_gpus = int(getattr(args, "num_gpus", 0) or 0)
+    model.load_index(index_file=args.index_file, data_file=getattr(args, "text_file", None), index_type=index_type,
+                     devices=n_gpus if n_gpus > 1 else None)
     t = Timer()
     out = []
     for s in range(0, len(queries), args.batch_size_q):
@@ -37,6 +39,7 @@ def parser(doc):
     ap.add_argument("--batch_size_q", type=int, default=32)
     ap.add_argument("--topk", type=int, default=100)
     ap.add_argument("--device", default="cuda")
+    ap.add_argument("--num_gpus", type=int, default=0, help="row-shard the index over this many GPUs of the node (0 / 1: one device); the shard files are dealt to the GPUs in row order")
     return ap
 
 

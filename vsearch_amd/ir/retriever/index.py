@@ -22,7 +22,7 @@ import numpy as np
 import torch
 
 from ... import _native as nat
-from ...device_index import DeviceIndex
+from ...device_index import DeviceIndex, NotBinaryError, ShardGroup
 
 logger = logging.getLogger(__name__)
 
@@ -36,6 +36,21 @@ class IndexType(Enum):
     DENSE = "dense"
     SPARSE = "sparse"
     BAG_OF_TOKEN = "bag_of_token"
+
+
+def _resolve_devices(devices):
+    """`devices` of SparseIndex / BoTIndex / Retriever.load_index -> list of GPU ordinals to shard over, or None (one device).
+    None: the index lives on `device` (the reference's behaviour); "all": every visible GPU; an int n: GPUs 0 .. n-1; a list."""
+    if devices is None:
+        return None
+    if isinstance(devices, str):
+        if devices != "all":
+            raise ValueError('devices: None, "all", a count or a list of GPU ordinals')
+        devices = torch.cuda.device_count()
+    if isinstance(devices, int):
+        devices = list(range(devices))
+    out = [_gpu_ordinal(d) if not isinstance(d, int) else int(d) for d in devices]
+    return out if len(out) > 1 else None
 
 
 def _gpu_ordinal(device) -> int:
@@ -229,6 +244,8 @@ class Index:
             info = self._dev.info()
             layout = torch.strided if info.kind == nat.VS_KIND_DENSE else torch.sparse_csr
             return torch.Size([info.n_rows, info.n_cols]), self._dtype, layout
+        if getattr(self, "_shards", None):
+            return torch.Size(self._shape), self._dtype, torch.sparse_csr
         return None, None, None
 
     def __str__(self):
@@ -242,9 +259,65 @@ class SparseIndex(Index):
     index_type = IndexType.SPARSE
 
     def __init__(self, index_file: Optional[str] = None, data_file: Optional[str] = None, fp16: bool = True,
-                 device: str = "cpu", low_memory: bool = False, shift: int = 0):
+                 device: str = "cpu", low_memory: bool = False, shift: int = 0, devices=None):
+        """`devices` (not in the reference: its index lives on one device) row-shards the index over several GPUs of this process:
+        the shard files matched by `index_file` are dealt to the GPUs in row order (whole files; the reference builds Wiki21M as
+        per-shard .npz files, examples/inference_sparse/README.md:90-107, and re-joins them with vstack at index.py:172-175),
+        `search` scores the batch on every GPU and merges the per-shard top-k on the first (vs_shard_group_*).  Results are
+        identical to the unsharded index."""
         self.shift = shift
+        self._devices = _resolve_devices(devices)
+        self._shards: Optional[List[DeviceIndex]] = None
+        self._group: Optional[ShardGroup] = None
         super().__init__(index_file, data_file, fp16, device, low_memory)
+
+    # -- row shards over several GPUs ------------------------------------------------------------------
+    def _drop_device(self):
+        if self._group is not None:
+            self._group.close()
+        for sh in (self._shards or []):
+            sh.close()
+        self._group, self._shards = None, None
+        super()._drop_device()
+
+    def _adopt_shards(self, shards: List[DeviceIndex]):
+        self._shards = shards
+        self._group = ShardGroup(shards)
+        self._dev = None
+        if self.EAGER_POSTINGS:
+            for sh in shards:
+                sh.prepare()
+        self.device = f"cuda:{shards[0].device}"
+
+    @property
+    def shards(self):
+        """the DeviceIndex of every row shard, in row order (None: the index is not sharded)"""
+        return list(self._shards) if self._shards else None
+
+    @property
+    def shard_devices(self):
+        """GPU ordinal of every row shard (None: the index is not sharded)"""
+        return [sh.device for sh in self._shards] if self._shards else None
+
+    def search(self, q_embs: torch.Tensor, k: int) -> SearchResults:
+        if self._group is None:
+            return super().search(q_embs, k)
+        if isinstance(q_embs, np.ndarray):
+            q_embs = torch.from_numpy(q_embs)
+        gpu = torch.device("cuda", self._shards[0].device)
+        q = q_embs.detach().to(gpu)
+        q = q.to(self._dtype) if self._dtype in (torch.float16, torch.float32) else q.float()
+        if q.dim() == 1:
+            q = q.unsqueeze(0)
+        ids, scores = self._group.search(q.contiguous(), int(k))
+        return SearchResults(ids, scores.to(self._dtype))
+
+    def move_to_device(self, device: str):
+        if self._group is not None:
+            if torch.device(device).type == "cuda" and _gpu_ordinal(device) in self.shard_devices:
+                return                                              # (already there: the shards stay where they are)
+            raise NotImplementedError("a row-sharded index stays on its GPUs; reload it with device= / devices= to move it")
+        super().move_to_device(device)
 
     # -- conversions ---------------------------------------------------------------------------------
     @staticmethod
@@ -276,11 +349,30 @@ class SparseIndex(Index):
         return DeviceIndex.from_csr(indptr, indices, data, shape[1], store_dtype=store, device=_gpu_ordinal(self.device))
 
     def _export_vector(self):
-        indptr, indices, data = self._dev.export_csr(np.float16 if self._dtype == torch.float16 else np.float32)
-        info = self._dev.info()
-        t = torch.sparse_csr_tensor(torch.from_numpy(indptr), torch.from_numpy(indices), torch.from_numpy(data),
-                                    size=(info.n_rows, info.n_cols))
+        parts = self._shards if self._shards else [self._dev]
+        ip_all, ix_all, d_all, rows, nnz0, n_cols = [np.zeros(1, np.int64)], [], [], 0, 0, 0
+        for dev in parts:
+            indptr, indices, data = dev.export_csr(np.float16 if self._dtype == torch.float16 else np.float32)
+            info = dev.info()
+            ip_all.append(indptr[1:] + nnz0)
+            ix_all.append(indices)
+            d_all.append(data)
+            rows += info.n_rows
+            nnz0 += int(indptr[-1])
+            n_cols = info.n_cols
+        t = torch.sparse_csr_tensor(torch.from_numpy(np.concatenate(ip_all)), torch.from_numpy(np.concatenate(ix_all)),
+                                    torch.from_numpy(np.concatenate(d_all)), size=(rows, n_cols))
         return t.to(self.device)
+
+    @property
+    def vector(self):
+        if self._vector is None and (self._dev is not None or self._shards):
+            self._vector = self._export_vector()
+        return self._vector
+
+    @vector.setter
+    def vector(self, value):
+        Index.vector.fset(self, value)
 
     def _scipy_csr_to_torch_csr(self, mat) -> torch.Tensor:
         t = torch.sparse_csr_tensor(torch.from_numpy(mat.indptr), torch.from_numpy(mat.indices), torch.from_numpy(mat.data), size=mat.shape)
@@ -295,45 +387,60 @@ class SparseIndex(Index):
         if not files:
             raise FileNotFoundError(f"no index file matches {index_file!r}")
         logger.info("***** Loading %s Index from %d files *****", self.index_type.value, len(files))
-        if len(files) == 1 and files[0].endswith(".vsx"):           # native shard file: the device format verbatim
-            self._drop_device()
-            self._vector = None
-            self._dev = DeviceIndex.load_native(files[0], device=_gpu_ordinal(self.device))
-            self._prepare()
-            info = self._dev.info()
-            # the file holds the device format verbatim: it must be the kind of index this class searches
-            if info.kind != nat.VS_KIND_CSR:
-                self._drop_device()
-                raise ValueError(f"{files[0]} holds a dense index (sparsity-aware dense store): load it with Index, not {type(self).__name__}")
-            if not self._binary() and info.store_dtype == nat.VS_NONE:   # (a BoTIndex may hold a valued matrix, like the reference's)
-                kind = "binary (bag-of-token)" if info.store_dtype == nat.VS_NONE else "valued"
-                self._drop_device()
-                raise ValueError(f"{files[0]} holds a {kind} index: it cannot be loaded as {type(self).__name__}")
+        if all(f.endswith(".vsx") for f in files) and (len(files) == 1 or self._devices):
+            # native shard files: the device format verbatim.  One file -> this device; several (with `devices`) -> one row shard each,
+            # dealt to the GPUs in order
             if self.shift:
-                self._drop_device()
                 raise ValueError("a native .vsx shard stores the columns after the shift was applied: load it with shift=0 "
                                  f"(got shift={self.shift}); convert from .npz shards to change it")
+            self._drop_device()
+            self._vector = None
+            gpus = self._devices or [_gpu_ordinal(self.device)]
+            loaded = []
+            try:
+                for i, f in enumerate(files):
+                    dev = DeviceIndex.load_native(f, device=gpus[i * len(gpus) // len(files)])
+                    loaded.append(dev)
+                    info = dev.info()
+                    # the file holds the device format verbatim: it must be the kind of index this class searches
+                    if info.kind != nat.VS_KIND_CSR:
+                        raise ValueError(f"{f} holds a dense index (sparsity-aware dense store): load it with Index, not {type(self).__name__}")
+                    if not self._binary() and info.store_dtype == nat.VS_NONE:   # (a BoTIndex may hold a valued matrix, like the reference's)
+                        raise ValueError(f"{f} holds a binary (bag-of-token) index: it cannot be loaded as {type(self).__name__}")
+                    if loaded[0].info().store_dtype != info.store_dtype or loaded[0].info().n_cols != info.n_cols:
+                        raise ValueError(f"{f}: shards of one index must agree in value type and column count")
+            except Exception:
+                for dev in loaded:
+                    dev.close()
+                raise
+            info = loaded[0].info()
             if not fp16 and info.store_dtype == nat.VS_F16:
                 logger.warning("%s stores fp16 values; fp16=False cannot restore fp32 precision", files[0])
             self._dtype = torch.float32 if info.store_dtype == nat.VS_F32 else torch.float16
-            self._shape = (info.n_rows, info.n_cols)
+            self._shape = (sum(d.info().n_rows for d in loaded), info.n_cols)
+            if len(loaded) == 1:
+                self._dev = loaded[0]
+                self._prepare()                                     # (after the checks: a rejected file costs no second copy in HBM)
+            else:
+                self._adopt_shards(loaded)
             return
         # pass 1: sizes only.  CSR shards are inspected by the library (zip + npy parsed natively, the column shift applied);
         # other scipy formats go through scipy (bound by nnz).
         from vsearch_amd.device_index import npz_inspect
         rows_total, packets_cap, n_cols = 0, 0, None
-        native = {}
+        native, f_rows, f_packets = {}, {}, {}
         for f in files:
             try:
                 n_r, n_c, _, pk = npz_inspect(f, self.shift)
                 native[f] = True
                 shape = (n_r, n_c + self.shift)
-                packets_cap += pk
             except NotImplementedError:                             # not a CSR file
                 native[f] = False
                 with np.load(f) as z:
                     shape = tuple(int(x) for x in z["shape"])
-                    packets_cap += int(z["data"].shape[0]) if "data" in z.files else shape[0] * shape[1]
+                    pk = int(z["data"].shape[0]) if "data" in z.files else shape[0] * shape[1]
+            f_rows[f], f_packets[f] = shape[0], pk
+            packets_cap += pk
             rows_total += shape[0]
             if n_cols is None:
                 n_cols = shape[1]
@@ -345,50 +452,70 @@ class SparseIndex(Index):
         self._shape = (rows_total, n_cols - self.shift)
         logger.info("***** Converting Sparse index to the device CSR format *****")
 
-        # pass 2: one shard at a time -- the reference's vstack(shards) (index.py:175) never exists on the host
+        # pass 2: one shard at a time -- the reference's vstack(shards) (index.py:175) never exists on the host.  With `devices` the
+        # files are dealt to the GPUs in row order, whole files, as evenly in rows as their boundaries allow.
+        gpus = self._devices or [_gpu_ordinal(self.device)]
+        groups, start = [[] for _ in gpus], 0
+        for f in files:
+            groups[min(len(gpus) - 1, start * len(gpus) // max(rows_total, 1))].append(f)
+            start += f_rows[f]
+        plan = [(g, fs) for g, fs in zip(gpus, groups) if fs]
+
         def convert(store):
-            dev = DeviceIndex.reserved(rows_total, packets_cap, n_cols - self.shift, store, device=_gpu_ordinal(self.device))
-            for f in files:
-                if native[f]:
-                    dev.append_npz(f, self.shift)                   # file -> rows, no scipy object in between
-                    continue
-                mat = load_npz(f).tocsr()[:, self.shift:]
-                mat.sort_indices()
-                data = mat.data.astype(np.float32, copy=False)
-                if store == nat.VS_NONE:
-                    if not bool((data == 1).all()):
-                        dev.close()
-                        raise ValueError("BoTIndex expects a binary matrix (every stored value == 1)")
-                    data = None
-                dev.append_csr(mat.indptr, mat.indices, data)
-            return dev
+            built = []
+            try:
+                for gpu, fs in plan:
+                    dev = DeviceIndex.reserved(sum(f_rows[f] for f in fs), sum(f_packets[f] for f in fs), n_cols - self.shift, store, device=gpu)
+                    built.append(dev)
+                    for f in fs:
+                        if native[f]:
+                            dev.append_npz(f, self.shift)           # file -> rows, no scipy object in between
+                            continue
+                        mat = load_npz(f).tocsr()[:, self.shift:]
+                        mat.sort_indices()
+                        data = mat.data.astype(np.float32, copy=False)
+                        if store == nat.VS_NONE:
+                            if not bool((data == 1).all()):
+                                raise NotBinaryError("BoTIndex expects a binary matrix (every stored value == 1)")
+                            data = None
+                        dev.append_csr(mat.indptr, mat.indices, data)
+            except Exception:
+                for dev in built:                                   # (nothing reserved survives a failed conversion)
+                    dev.close()
+                raise
+            return built
 
         valued = nat.VS_F16 if fp16 else nat.VS_F32                  # fp32 -> fp16 happens on the device
         if self._binary():
             try:
-                dev = convert(nat.VS_NONE)
-            except ValueError as e:
-                if "binary matrix" not in str(e):
-                    raise
+                built = convert(nat.VS_NONE)
+            except NotBinaryError:
+                built = None
+            if built is None:
                 # shards with values other than 1: the reference's BoTIndex searches them like any sparse index (index.py:205-218)
                 logger.info("%s: the shards hold values other than 1 -- stored as a valued sparse index", type(self).__name__)
-                dev = convert(valued)
+                built = convert(valued)
         else:
-            dev = convert(valued)
-        self._dev = dev
-        self._prepare()
+            built = convert(valued)
+        if len(built) == 1:
+            self._dev = built[0]
+            self._prepare()
+        else:
+            self._adopt_shards(built)
 
     # -- persistence (index.py:181-202) --------------------------------------------------------------
     def save(self, path):
         """CSR index -> scipy ``.npz`` (keys indices, indptr, data, shape, format; int64 indices)."""
         from scipy.sparse import csr_array, save_npz
         if str(path).endswith(".vsx"):                              # native shard file (loads without a CSR round trip)
+            if self._shards:
+                raise NotImplementedError("a row-sharded index is saved shard by shard: index.shards[i].save_native(path_i)")
             self._device_index().save_native(path)
             logger.info("Index successfully saved to %s", path)
             return
         try:
             # values go to disk as float32: scipy.sparse has no float16, and the loader re-applies fp16 (fp16=True)
-            if self._dev is not None:
+            if self._dev is not None and not self._shards:
                 # written by the library (csrc/npz.hip): the same keys / dtypes scipy.sparse.save_npz writes for the reference's
                 # int64 torch CSR, stored (uncompressed) members; numpy's savez appends ".npz" to a bare name, so does this
                 target = str(path) if str(path).endswith(".npz") else str(path) + ".npz"
@@ -396,7 +523,7 @@ class SparseIndex(Index):
                 logger.info("Index successfully saved to %s", target)
                 return
             else:
-                ip, ix, d, shape = self._csr_parts(self._vector)
+                ip, ix, d, shape = self._csr_parts(self.vector)        # (a row-sharded index: its shards' rows re-joined)
                 indptr, indices, data = ip.cpu().numpy(), ix.cpu().numpy(), d.float().cpu().numpy()
             save_npz(path, csr_array((data, indices, indptr), shape=shape))
             logger.info("Index successfully saved to %s", path)
@@ -409,8 +536,8 @@ class BoTIndex(SparseIndex):
     index_type = IndexType.BAG_OF_TOKEN
 
     def __init__(self, index_file: Optional[str] = None, data_file: Optional[str] = None, fp16: bool = True,
-                 device: str = "cpu", low_memory: bool = False, shift: int = 0):
-        super().__init__(index_file, data_file, fp16, device, low_memory, shift)
+                 device: str = "cpu", low_memory: bool = False, shift: int = 0, devices=None):
+        super().__init__(index_file, data_file, fp16, device, low_memory, shift, devices)
 
     def _binary(self) -> bool:
         return True

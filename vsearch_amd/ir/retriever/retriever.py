@@ -212,7 +212,9 @@ class Retriever(BiEncoder):
     def save_index(self, path):
         self.index.save(path)
 
-    def load_index(self, index_file=None, data_file=None, index_type=None):
+    def load_index(self, index_file=None, data_file=None, index_type=None, devices=None):
+        """retriever.py:322-348.  `devices` (not in the reference): row-shard a sparse / bag-of-token index over several GPUs of this
+        process -- None (one device, the reference's behaviour), "all", a count, or a list of GPU ordinals (SparseIndex docstring)."""
         if index_type is None:
             if index_file.endswith(".pt"):
                 index_type = IndexType.DENSE
@@ -226,4 +228,6 @@ class Retriever(BiEncoder):
             raise TypeError("index_type must be an instance of IndexType, int, or str.")
         self.index_type = index_type
         cls = {IndexType.DENSE: Index, IndexType.SPARSE: SparseIndex, IndexType.BAG_OF_TOKEN: BoTIndex}[index_type]
-        self.index = cls(index_file, data_file, device=self.device)
+        if devices is not None and index_type == IndexType.DENSE:
+            raise NotImplementedError("devices=: row sharding serves the sparse and bag-of-token indexes")
+        self.index = cls(index_file, data_file, device=self.device) if devices is None else cls(index_file, data_file, device=self.device, devices=devices)
