@@ -441,6 +441,27 @@ def test_dense_index_tail_split_along_k():
     assert (np.asarray(allsc.cpu() if hasattr(allsc, "cpu") else allsc) == want).all()
 
 
+def test_dense_scores_do_not_depend_on_tail_position_or_batch_size():
+    """the split-K tail must add a document's 512-column block sums in the main kernel's order.  Non-dyadic values (every
+    fp32 sum rounds): rows copied into the tail of the grid score bit-identically to their originals in a main round, and a batch of
+    128 queries scores bit-identically to the same queries inside a batch of 256 (another tile plan)."""
+    import torch
+    n_main, n_copy, v = 65_536, 700, 2048
+    g = torch.Generator(device="cuda").manual_seed(5)
+    mat = torch.rand((n_main + n_copy, v), device="cuda", generator=g) * 3 + 0.01
+    mat[n_main:] = mat[:n_copy]                                        # the tail documents are copies of main-round documents
+    q = torch.rand((256, v), device="cuda", generator=g) * 3 + 0.01
+    idx = DeviceIndex.from_dense(mat)
+    s256 = idx.scores(q)
+    s256 = s256.cpu().numpy() if hasattr(s256, "cpu") else np.asarray(s256)
+    assert (s256[:, n_main:] == s256[:, :n_copy]).all(), "a tail document scores differently from its copy in a main round"
+    s128 = idx.scores(q[:128])
+    s128 = s128.cpu().numpy() if hasattr(s128, "cpu") else np.asarray(s128)
+    assert (s128 == s256[:128]).all(), "scores depend on the batch size"
+    want = (q.double() @ mat.double().t()).cpu().numpy()
+    assert np.abs(s256 - want).max() / np.abs(want).max() < 1e-5
+
+
 def _zipf_csr(rng, n, nnz, s, perm, binary=False, dyadic=False):
     """Rows with Zipf(s) column popularity, distinct sorted columns (numpy; the popular columns end up in most rows)."""
     w = 1.0 / np.arange(1, V + 1) ** s

@@ -58,7 +58,7 @@ __global__ void unpad_rows_kernel(const float* src, int32_t ldp, int64_t n_rows,
 constexpr int kDPitch = kDenseKC + 4;
 
 // SK = 1 (split-K, the tail of a search: launch_dense_scores): blockIdx.z picks a slice of `cps` K chunks (a multiple of 16: whole
-// summation blocks); the block writes its partial sums to part[slice][B][n_tail] instead of keys / scores.
+// summation blocks); the block writes the sum of every 512-column summation block to part[block][B][n_tail] instead of keys / scores.
 template <int WM, int WN, int TM, int TN, int SK = 0>
 __global__ __launch_bounds__(256) void dense_scores_kernel(const float* __restrict__ Q, const float* __restrict__ P, int32_t B,
                                                            int64_t N, int64_t n_begin, int32_t ldp, uint64_t* keys, float* scores,
@@ -160,12 +160,31 @@ __global__ __launch_bounds__(256) void dense_scores_kernel(const float* __restri
         __syncthreads();
         VS_DENSE_FETCH(c + 2)
         if ((c & 15) == 15 || c == c_hi - 1) {
+            if constexpr (SK != 0) {
+                // split-K: the block sum itself goes out -- part[summation block][B][n_tail] -- and splitk_reduce_kernel adds the blocks in
+                // block order from zero: the SAME association as `tot += acc` below, so a document's score does not depend on whether
+                // it fell into a main round or the tail, on the batch size, on the CU count or on how the index is sharded
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) { tot[i][j] += acc[i][j]; acc[i][j] = zero; }
+                    for (int j = 0; j < TN; ++j) {
+                        const int64_t n = n_blk + (wn * TN + j) * 32 + l31;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int b = b_blk + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                            if (b < B && n < N) part[((size_t)(c >> 4) * B + b) * n_tail + (n - n_begin)] = acc[i][j][r];
+                        }
+                        acc[i][j] = zero;
+                    }
+            } else {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) { tot[i][j] += acc[i][j]; acc[i][j] = zero; }
+            }
         }
     }
+    if constexpr (SK != 0) return;
 #undef VS_DENSE_FETCH
 #undef VS_DENSE_STAGE
     if (pool_L > 0) {
@@ -194,24 +213,20 @@ __global__ __launch_bounds__(256) void dense_scores_kernel(const float* __restri
             for (int r = 0; r < 16; ++r) {
                 const int b = b_blk + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (b < B && n < N) {
-                    if constexpr (SK != 0) {
-                        part[((size_t)blockIdx.z * B + b) * n_tail + (n - n_begin)] = tot[i][j][r];
-                    } else {
-                        if (keys) keys[(size_t)b * N + n] = make_key(tot[i][j][r], (uint32_t)n);
-                        if (scores) scores[(size_t)b * N + n] = tot[i][j][r];
-                    }
+                    if (keys) keys[(size_t)b * N + n] = make_key(tot[i][j][r], (uint32_t)n);
+                    if (scores) scores[(size_t)b * N + n] = tot[i][j][r];
                 }
             }
         }
 }
 
-// the slices' partial sums, added in slice order (a fixed order: results do not depend on the launch) -> keys / scores of the tail documents
-__global__ void splitk_reduce_kernel(const float* part, int32_t S, int32_t B, int64_t n_tail, int64_t n_begin, int64_t N, uint64_t* keys, float* scores) {
+// the 512-column block sums of the tail documents, added from zero in block order -- exactly what the main kernel's `tot += acc` does
+__global__ void splitk_reduce_kernel(const float* part, int32_t n_blocks, int32_t B, int64_t n_tail, int64_t n_begin, int64_t N, uint64_t* keys, float* scores) {
     const int64_t total = (int64_t)B * n_tail;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t b = i / n_tail, t = i % n_tail;
-        float sum = part[i];
-        for (int z = 1; z < S; ++z) sum += part[(size_t)z * total + i];
+        float sum = 0.f;
+        for (int z = 0; z < n_blocks; ++z) sum += part[(size_t)z * total + i];
         const int64_t n = n_begin + t;
         if (keys) keys[(size_t)b * N + n] = make_key(sum, (uint32_t)n);
         if (scores) scores[(size_t)b * N + n] = sum;
@@ -219,8 +234,8 @@ __global__ void splitk_reduce_kernel(const float* part, int32_t S, int32_t B, in
 }
 
 // Launch plan: full rounds of 128 x 128 blocks (2 co-resident per CU); the remaining documents -- less than a round of blocks -- are
-// split along K over the idle slots (128 x 128 blocks on slices of whole 512-column summation blocks, partial sums added in slice
-// order), or, when K is too short to split, done by 32 x 128 blocks.  (C2, 100 k x 29 523, B = 256: 14 of 782 document tiles are
+// split along K over the idle slots (128 x 128 blocks on slices of whole 512-column summation blocks; the block sums are added in
+// block order by splitk_reduce_kernel: the main kernel's association), or, when K is too short to split, done by 32 x 128 blocks.  (C2, 100 k x 29 523, B = 256: 14 of 782 document tiles are
 // left after three rounds; as 112 quarter blocks they took 0.75 ms of 11.9.)
 int launch_dense_scores(vs_index* idx, const float* dq, int B, int ldp, uint64_t* keys, float* scores, hipStream_t s) {
     const int64_t N = idx->n_rows;
@@ -242,12 +257,13 @@ int launch_dense_scores(vs_index* idx, const float* dq, int B, int ldp, uint64_t
         if (main_doc_tiles > 0 && S >= 2) {
             const int cps = ceil_div(ceil_div(chunks, S), 16) * 16;
             S = ceil_div(chunks, cps);
-            VS_TRY(idx->ws_fb.reserve((size_t)S * B * n_tail * 4));
+            const int n_sum_blocks = ceil_div(chunks, 16);
+            VS_TRY(idx->ws_fb.reserve((size_t)n_sum_blocks * B * n_tail * 4));
             hipLaunchKernelGGL((dense_scores_kernel<2, 2, 2, 2, 1>), dim3((unsigned)ceil_div64(n_tail, 128), (unsigned)q_tiles, (unsigned)S), dim3(256), 0, s, dq,
                                idx->mat.as<float>(), B, N, n_begin, ldp, (uint64_t*)nullptr, (float*)nullptr, 0, (uint32_t*)nullptr, idx->ws_fb.as<float>(), cps, n_tail);
             VS_HIP(hipGetLastError());
             hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<int64_t>(ceil_div64((int64_t)B * n_tail, 256), 4096)), dim3(256), 0, s,
-                               (const float*)idx->ws_fb.as<float>(), S, B, n_tail, n_begin, N, keys, scores);
+                               (const float*)idx->ws_fb.as<float>(), n_sum_blocks, B, n_tail, n_begin, N, keys, scores);
         } else {
             hipLaunchKernelGGL((dense_scores_kernel<1, 4, 1, 1>), dim3((unsigned)ceil_div64(n_tail, 128), (unsigned)ceil_div(B, 32)), dim3(256), 0, s,
                                dq, idx->mat.as<float>(), B, N, n_begin, ldp, keys, scores, 0, (uint32_t*)nullptr, (float*)nullptr, 0, (int64_t)0);

@@ -104,6 +104,15 @@ class Retriever(BiEncoder):
                                            C.c_void_p(out_scores.data_ptr()), ordinal, stream))
         return SearchResults(out_ids, out_scores)
 
+    def retireve_negatives(self, *args, **kwargs):
+        """Hard-negative mining for the reference's TRAINING loop (retriever.py:150-205, called from forward() at :51): out of this
+        build's scope (the retrieval hot path, no training).  Present so that a caller gets a clear message, not an
+        AttributeError."""
+        raise NotImplementedError("Retriever.retireve_negatives (hard-negative mining for training, reference retriever.py:150-205) is not part of "
+                                  "the MI355X retrieval path; use retrieve() and filter the hits")
+
+    retrieve_negatives = retireve_negatives
+
     # ---- index build (retriever.py:208-317) ----------------------------------------------------------
     def _tokenize_for_bot(self, texts: List[str], max_len: int):
         return self.encoder_p.tokenizer(texts, max_length=max_len, truncation=True)["input_ids"]
