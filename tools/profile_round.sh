@@ -1,7 +1,7 @@
 #!/bin/bash
 # One call on the GPU box: the round's evidence set at HEAD -> gpurun_out/<tag>_* (summaries are then copied to profiles/ by
 # tools/rocprof_summary.py / pmc_walk_summary.py on the build box).  Usage: bash tools/profile_round.sh r03
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
@@ -16,6 +16,7 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/${TAG}_write -o $TAG -- python
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_fetch_b32 -- python3 $ROOT/tools/probe_filter.py 21015324 32 100 fp32 filter > $OUT/${TAG}_fetch_b32.log 2>&1
 # 4. utilisation counters of the walk (4 M docs) and its phase clocks
 cd $ROOT && bash tools/pmc_walk.sh 4000000 ${TAG}_pmc sq1,sq2,sq3,tcp1,tcc1 > /dev/null 2>&1
+# (the summaries: tools/pmc_walk_summary.py gpurun_out/${TAG}_pmc ${TAG} bp_quad_topk)
 VS_BP_TIMING=1 python3 tools/probe_filter.py 21015324 1024 100 fp32 filter > $OUT/${TAG}_phase_clocks.txt 2>&1
 python3 tools/probe_latency.py 21015324 > $OUT/${TAG}_latency.txt 2>&1
 find $OUT/${TAG}_stats $OUT/${TAG}_fetch $OUT/${TAG}_write -name "*.db" | head

@@ -87,8 +87,9 @@ def main():
         # bench-sized launch (largest) of each scan kernel present -> profiles/pmc_summary.json, read by bench.py for roofline.traffic
         pmc_path = os.path.join(a.out, "pmc_summary.json")
         pmc = json.load(open(pmc_path)) if os.path.exists(pmc_path) else {}
-        pmc = {k: v for k, v in pmc.items() if k in ("bp_walk_topk", "csr_scan_topk_mq")}
-        for key in ("bp_walk_topk", "csr_scan_topk_mq"):
+        scan_kernels = ("bp_quad_topk", "bp_walk_topk", "bp_bin_topk", "csr_scan_topk_mq")
+        pmc = {k: v for k, v in pmc.items() if k in scan_kernels}
+        for key in scan_kernels:
             scan = lambda rows: max((r["KiB"] for r in rows if key in r["kernel"]), default=0.0)
             fetch, write = scan(summary["FETCH_SIZE"]), scan(summary["WRITE_SIZE"])
             if fetch <= 0:

@@ -174,6 +174,7 @@ struct vs_shard_group {
     std::vector<vs_index*> shards;
     std::vector<int64_t> row0;
     std::vector<hipStream_t> streams;
+    std::vector<bool> owns_stream;            // (shards on one device share the first one's stream)
     std::vector<hipEvent_t> done;
     std::vector<vs::DevBuf*> q, ids, sc;      // per shard, on the shard's device
     vs::DevBuf all_ids, all_sc, out_ids, out_sc;   // on shards[0]'s device
@@ -184,12 +185,14 @@ extern "C" void vs_shard_group_destroy(vs_shard_group* g) {
     if (!g) return;
     for (size_t i = 0; i < g->shards.size(); ++i) {
         (void)hipSetDevice(g->shards[i]->device);
-        if (i < g->streams.size() && g->streams[i]) { (void)hipStreamSynchronize(g->streams[i]); (void)hipStreamDestroy(g->streams[i]); }
+        if (i < g->streams.size() && g->streams[i]) (void)hipStreamSynchronize(g->streams[i]);
         if (i < g->done.size() && g->done[i]) (void)hipEventDestroy(g->done[i]);
         if (i < g->q.size()) delete g->q[i];
         if (i < g->ids.size()) delete g->ids[i];
         if (i < g->sc.size()) delete g->sc[i];
     }
+    for (size_t i = 0; i < g->streams.size(); ++i)
+        if (g->streams[i] && i < g->owns_stream.size() && g->owns_stream[i]) { (void)hipSetDevice(g->shards[i]->device); (void)hipStreamDestroy(g->streams[i]); }
     if (!g->shards.empty()) (void)hipSetDevice(g->shards[0]->device);
     delete g;
 }
@@ -208,9 +211,15 @@ extern "C" int vs_shard_group_create(vs_index* const* shards, int32_t n_shards, 
         g->row0.push_back(row);
         row += s->n_rows;
         VS_HIP(hipSetDevice(s->device));
+        // One stream per DEVICE: shards that share a GPU run one after the other.  Every walk is a persistent grid that wants the whole
+        // GPU (one 160 KB workgroup per CU, work items in lock step): two of them at once only take each other's CUs, and their
+        // lock-step windows wait for workgroups that are not resident (r3: 8 shards on one GPU cost 235 ms against 8 x 20).
         hipStream_t st = nullptr;
+        for (int j = 0; j < i && !st; ++j)
+            if (g->shards[j]->device == s->device) st = g->streams[j];
+        g->owns_stream.push_back(st == nullptr);
         hipEvent_t ev = nullptr;
-        VS_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        if (!st) VS_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
         g->streams.push_back(st);
         VS_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         g->done.push_back(ev);

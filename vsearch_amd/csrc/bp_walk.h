@@ -396,9 +396,9 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_kernel(const uint32_t* c
 // ---- walk ---------------------------------------------------------------------------------------------------------
 // Lock-step wait of the walks (BpArgs::pace): polls until *p >= need.  BOUNDED: lock step is a performance hint that assumes
 // every work item of the launch is resident; when another kernel shares the GPU -- several shards of a shard group on one device, two
-// processes, masked CUs -- the peers may never be scheduled, and an unbounded wait is a GPU hang.  After kPaceSpins polls (~ 20 ms) the
+// processes, masked CUs -- the peers may never be scheduled, and an unbounded wait is a GPU hang.  After kPaceSpins polls (~ 4 ms) the
 // caller gives up lock step for the rest of the launch (returns false).
-constexpr int kPaceSpins = 1 << 16;
+constexpr int kPaceSpins = 1 << 14;
 __device__ __forceinline__ bool pace_wait(const uint32_t* p, uint32_t need) {
     for (int spins = 0; spins < kPaceSpins; ++spins) {
         if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) return true;
