@@ -44,6 +44,12 @@ def _oracle_pin(seed, n, q, ids, sc, k, kind=0, val_law=0, nnz=768, windows=48, 
         else:
             assert np.allclose(want, sc[b], rtol=RTOL, atol=0), f"query {b}: returned scores differ from the oracle's by {np.abs(want - sc[b]).max()}"
     starts = np.linspace(0, n - window_rows, windows).astype(np.int64)
+    # ... plus windows that STRADDLE block boundaries of the column-grouped copy (1920- and 2048-document blocks: a window of 8192+ rows
+    # crosses four of them wherever it starts -- these are centred on a boundary in the middle and near the end) and the index's LAST rows
+    # (the last, partial block)
+    extra = [max(0, (n // 2 // 1920) * 1920 - window_rows // 2), max(0, (n // 2 // 2048) * 2048 - window_rows // 2),
+             max(0, ((n - 1) // 1920) * 1920 - window_rows // 2), max(0, n - window_rows)]
+    starts = np.unique(np.concatenate([starts, np.minimum(np.asarray(extra, dtype=np.int64), n - window_rows)]))
     for r0 in starts:
         ip, ix, d = oracle.synth_csr(seed, int(r0), window_rows, V, nnz, kind, val_law)
         _, _, allsc = oracle.csr_search(ip, ix, None if binary else d, V, q, 1, acc64=True, return_all=True)

@@ -334,6 +334,35 @@ def test_two_rank_bench_launch_on_one_gpu_equals_the_unsharded_search(tmp_path):
     assert (ids.cpu().numpy() == got["ids"]).all() and (sc.cpu().numpy() == got["scores"]).all()
 
 
+def test_eight_rank_bench_launch_on_one_gpu_equals_the_unsharded_search(tmp_path):
+    """eight rank processes sharing the one GPU (gloo exchange), 20 000-doc shards -- every rank's shard is big
+    enough for the postings filter, the path the measured run takes (bench.parity_sharded asserts it) -- rank 0's ids and scores equal
+    the unsharded index's bit for bit."""
+    import json, os, subprocess, sys
+    import bench
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dump = str(tmp_path / "ids8.npz")
+    docs, batch, k, world = 8 * 20_000, 32, 100, 8
+    cmd = [sys.executable, os.path.join(repo, "bench.py"), "--gpus", str(world), "--docs", str(docs), "--batch", str(batch), "--steps", "1", "--warmup", "1",
+           "--no-cpu-baseline", "--dump-ids", dump]
+    env = dict(os.environ, VS_BENCH_SHARE_GPU="1")
+    code = ("import sys, json; sys.path.insert(0, %r); from vsearch_amd import launch; "
+            "raise SystemExit(launch.spawn_ranks(%r, %d, timeout_s=900, extra_env={'VS_BENCH_SHARE_GPU': '1'}))" % (repo, cmd, world))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == world and line["exchange"]["world_size"] == world
+    par = line["parity"]
+    assert par["ranks"] == world and par["docs_per_rank"] == 20_000 and par["scan_path_rank0"] == 3
+    assert par["recall_at_100_vs_oracle"] == 1.0 and par["max_rel_score_err"] < 1e-4
+    got = np.load(dump)
+    idx = DeviceIndex.synthetic(bench.INDEX_SEED, 0, docs, V, bench.NNZ_DOC, 0, 0, nat.VS_F32)
+    import torch
+    qb = bench.make_query_batches(2, batch, torch.device("cuda", 0))
+    ids, sc = idx.search(qb[1], k)                                   # steps 1 + warmup 1: the last step searched batch 1
+    assert (ids.cpu().numpy() == got["ids"]).all() and (sc.cpu().numpy() == got["scores"]).all()
+
+
 def test_reserve_and_append_equals_single_shot():
     """Shard-by-shard construction (vs_index_create_reserved + vs_index_append_csr) == one-shot creation."""
     n = 1500
