@@ -1,21 +1,6 @@
 // csr_index.hip -- SparseIndex / BoTIndex device container and its search entry points.
 //   reference: src/ir/retriever/index.py:128-218 (containers), :88-94 (search)
-#include "common.h"
-#include "csr_scan.h"
-#include "csr_scan_mq.h"
-#include "bp_walk.h"
-#include "bp_refine.h"
-#include "bp_bin.h"
-// The three experimental walks of round 3 (flat worklists, streamed flat walk, two accumulator sets: all correct, all slower than the
-// list walk -- docs/EXPERIMENTS.md) are lab results, not components: compiled only with -DVS_EXPERIMENTAL_WALKS (make EXPERIMENTAL=1).
-// (bp_flat.h itself stays in: the bag-of-token walk, bp_bin.h, shares its candidate handling)
-#ifdef VS_EXPERIMENTAL_WALKS
-#include "bp_stream.h"
-#include "bp_duo.h"
-#else
-namespace vs { constexpr int kDuoMaxK = 0, kDuoEntCap = 0, kDuoQT = 4; }
-#endif
-#include "bp_quad.h"
+#include "csr_internal.h"
 #include "synth_device.h"
 
 #include <algorithm>
@@ -457,12 +442,6 @@ extern "C" int vs_index_create_synthetic(uint64_t seed, int64_t row0, int64_t n_
 // =================================================================================================
 // info / export / destroy
 // =================================================================================================
-constexpr int kQT = 8;   // queries per pass of the multi-query scan (csr_scan_mq.h)
-
-static int64_t csr_bytes_per_pass(const vs_index* idx) {
-    const int64_t per_packet = 16 + (idx->store_dtype == VS_F32 ? 32 : idx->store_dtype == VS_F16 ? 16 : 0);
-    return idx->n_packets * per_packet + (idx->n_rows + 1) * 4;
-}
 
 extern "C" int vs_index_info(const vs_index* idx, vs_index_info_t* o) {
     if (!idx || !o) return fail(VS_EINVAL, "NULL argument");
@@ -588,12 +567,6 @@ extern "C" int vs_index_export_csr(const vs_index* idx, int64_t* rowptr, int64_t
 // =================================================================================================
 namespace {
 
-struct ScanPlan {
-    int nchunk;
-    int64_t rows_per_chunk;
-    int grid;
-};
-
 ScanPlan plan_scan(const vs_index* idx, int B) {
     ScanPlan p;
     const int64_t min_rows = 512;
@@ -602,24 +575,6 @@ ScanPlan plan_scan(const vs_index* idx, int B) {
     p.nchunk = (int)std::max<int64_t>(1, ceil_div64(idx->n_rows, rpc));
     p.grid = (int)std::min<int64_t>((int64_t)B * p.nchunk, idx->cu_count);
     return p;
-}
-
-// Row chunks for `units` concurrent scans (query tiles, or single queries on the Qt = 1 path).  Work items = units x
-// chunks.  Every item pays a table / image build and top-k sorts, and -- more important -- workgroups that sweep the
-// SAME rows at the same time for different units share the stream through L2 / Infinity Cache, so chunks are as few
-// and as long as still fill the CUs: many units -> 1-2 chunks, one unit -> one chunk per CU.
-int choose_chunks(const vs_index* idx, int units, int max_nchunk) {
-    const int cus = idx->cu_count;
-    const int max_chunks = (int)std::max<int64_t>(1, std::min<int64_t>(max_nchunk, idx->n_rows / 512));
-    int best = std::min(max_chunks, std::max(1, (cus + units - 1) / units));
-    double best_eff = 0.0;
-    for (int c = best; c <= max_chunks; ++c) {
-        const int64_t it = (int64_t)units * c;
-        const double eff = (double)it / (double)(((it + cus - 1) / cus) * cus);          // fill of the last round
-        if (eff > best_eff + 1e-9) { best_eff = eff; best = c; }
-        if (eff >= 0.92) break;
-    }
-    return best;
 }
 
 template <int G, int VM>
@@ -693,843 +648,7 @@ int prep_queries(vs_index* idx, const void* q, int q_dtype, int64_t ldq, int B, 
 
 }  // namespace
 
-namespace {
-
-template <int G, int VM, int U, int DN>
-int launch_mq_gu(const MqArgs& a, int grid, size_t lds, hipStream_t s) {
-    VS_HIP(hipFuncSetAttribute((const void*)csr_scan_topk_mq<G, VM, kQT, U, DN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((csr_scan_topk_mq<G, VM, kQT, U, DN>), dim3(grid), dim3(kScanThreads), lds, s, a);
-    VS_HIP(hipGetLastError());
-    return VS_OK;
-}
-template <int G, int VM>
-int launch_mq_g(int u, bool shared_cols, const MqArgs& a, int grid, size_t lds, hipStream_t s) {
-    if (shared_cols)          // the shared-column variant keeps 16 more registers live: at most 2 packets in flight
-        return u <= 1 ? launch_mq_gu<G, VM, 1, 1>(a, grid, lds, s) : launch_mq_gu<G, VM, 2, 1>(a, grid, lds, s);
-    if (u <= 1) return launch_mq_gu<G, VM, 1, 0>(a, grid, lds, s);
-    if (u == 2) return launch_mq_gu<G, VM, 2, 0>(a, grid, lds, s);
-    return launch_mq_gu<G, VM, 3, 0>(a, grid, lds, s);
-}
-template <int VM>
-int launch_mq_vm(int g, int u, bool shared_cols, const MqArgs& a, int grid, size_t lds, hipStream_t s) {
-    switch (g) {
-        case 8: return launch_mq_g<8, VM>(u, shared_cols, a, grid, lds, s);
-        case 16: return launch_mq_g<16, VM>(u, shared_cols, a, grid, lds, s);
-        case 32: return launch_mq_g<32, VM>(u, shared_cols, a, grid, lds, s);
-        default: return launch_mq_g<64, VM>(u, shared_cols, a, grid, lds, s);
-    }
-}
-
-constexpr double kMqSharedOverlap = 40.0;   // columns shared by two queries above which the shared-column variant runs
-
-// LDS entries left for the tile's weights once the fixed tables are placed
-inline int mq_lanes(const vs_index* idx) { return std::max(idx->lanes_per_row, 8); }
-inline int mq_acc_rows(const vs_index* idx) {          // accumulator rows x copies (see S in csr_scan_topk_mq)
-    const int g = mq_lanes(idx);
-    return kScanWaves * (64 / g) * (g >= 32 ? 4 : (g >= 16 ? 2 : 1));
-}
-int mq_vals_cap(const vs_index* idx) {
-    const size_t fixed = mq_fixed_lds_bytes<kQT>(idx->n_cols, mq_acc_rows(idx));
-    const size_t total = 160 * 1024;
-    if (fixed + 1024 > total) return 0;
-    return (int)((total - fixed) / 4);
-}
-
-// ---- blocked postings (bp_walk.h): second, column-grouped copy of the index for sparse queries ---------------------
-constexpr int kBpExactQT = 4;     // queries per tile of the fp64 walk (its accumulators are twice as wide as the filter walk's)
-constexpr int kBpBinQT = 8;       // queries per tile of the binary index's filter walk
-
-bool bp_wanted(const vs_index* idx) {
-    if (idx->bp_pref == 0 || idx->n_rows <= 0 || idx->n_packets <= 0) return false;
-    if (((size_t)idx->n_cols + 1) * 4 + 4096 > 160 * 1024) return false;            // the builder keeps one counter per column in LDS
-    if (idx->bp_pref == 1) return true;
-    // pays off when the index is big enough for the per-block directory (4 (V + 1) bytes per block) to disappear
-    if (idx->store_dtype == VS_NONE) return idx->n_rows >= 65536;
-    return idx->n_rows >= 16384 && (double)idx->nnz / (double)idx->n_rows >= 256.0;
-}
-
-// value mode of the records: the index's own, or fp16 for the lossy filter copy of an fp32 index (bp_refine.h)
-inline int bp_record_vm(const vs_index* idx) {
-    if (idx->store_dtype == VS_NONE) return VM_BIN;
-    return (idx->store_dtype == VS_F16 || idx->bp_quant) ? VM_F16 : VM_F32;
-}
-
-void bp_release(vs_index* idx) {
-    idx->bp_dir.release(); idx->bp_base.release(); idx->bp_rec.release(); idx->bp_df.release(); idx->bp_vmax.release(); idx->bp_ovf.release();
-    idx->bp_hmap.release(); idx->bp_strip.release();
-    idx->bp_n_head = 0;
-    idx->bp_quad = false;
-    idx->bp_ready = false;
-}
-
-// valued index: QT queries per tile, blocks of <= 2048 documents (exact fp64 walk: QT = 4, filter walk: QT = 8);
-// binary index: filter walk only, one lane per (short) list
-constexpr int kFlRoundsF16 = 8, kFlRoundsF32 = 5;     // record loads in flight per lane (registers: 8 / 12 per record)
-// which walk serves the fixed-point filter of this index: 0 = a list per lane group (bp_walk.h), 1 = flat worklists (bp_flat.h),
-// 2 = the list walk on two accumulator sets, no block barrier (bp_duo.h), 3 = flat worklists, record loads software-pipelined (bp_stream.h)
-int bp_walk_kind(const vs_index* idx) {
-#ifdef VS_EXPERIMENTAL_WALKS
-    const bool can = !idx->bp_quad && idx->store_dtype != VS_NONE && idx->bp_n_head == 0 && idx->bp_max_block_recs < ((int64_t)1 << kFlRecBits) - 4096;
-    if (!can) return 0;
-    return idx->bp_walk_pref < 0 || idx->bp_walk_pref > 3 ? 0 : idx->bp_walk_pref;
-#else
-    (void)idx;
-    return 0;
-#endif
-}
-template <int AM>
-bool bp_flat_ok(const vs_index* idx, const BpArgs& a) { return AM == AM_FIX && !a.upper && bp_walk_kind(idx) >= 1; }
-// walk 2 (two accumulator sets, bp_duo.h) serves this call: 4 query slots per tile, K' within its candidate buffers
-bool bp_duo_ok(const vs_index* idx, int kp, const uint64_t* upper) { return bp_walk_kind(idx) == 2 && !upper && kp <= kDuoMaxK; }
-template <int QT, int AM>
-int launch_bp_walk(const vs_index* idx, const BpArgs& a, int grid, int ent_cap, hipStream_t s) {
-    const int vm = bp_record_vm(idx);
-    size_t lds = bp_lds_bytes<QT, AM, kBpRowsMax>(ent_cap, AM == AM_FIX ? a.n_head : 0);
-    void (*kern)(BpArgs) = nullptr;
-    if (idx->bp_quad) {
-        // quad chunks (bp_quad.h): the fixed-point filter walk only
-        if (AM != AM_FIX || a.upper || ent_cap > kBpEntCap) return fail(VS_EUNSUPPORTED, "quad postings serve the filter walk only");
-        kern = a.timing ? bp_quad_topk<1> : bp_quad_topk<0>;
-        lds = quad_lds_bytes();
-#ifdef VS_EXPERIMENTAL_WALKS
-    } else if (AM == AM_FIX && bp_duo_ok(idx, a.k, a.upper) && ent_cap <= kDuoEntCap) {
-        if (vm == VM_F32) kern = bp_duo_topk<VM_F32, kBpNB, kBpRowsMax>;
-        else kern = bp_duo_topk<VM_F16, kBpNBWide, kBpRowsMax>;
-        lds = bp_duo_lds_bytes<kBpRowsMax>(ent_cap);
-    } else if (bp_flat_ok<AM>(idx, a) && bp_walk_kind(idx) == 3) {
-        if (vm == VM_F32) kern = bp_stream_topk<VM_F32, 3, kBpRowsMax>;
-        else kern = bp_stream_topk<VM_F16, 4, kBpRowsMax>;
-        lds = bp_stream_lds_bytes<kBpRowsMax>(ent_cap);
-    } else if (bp_flat_ok<AM>(idx, a) && bp_walk_kind(idx) != 2) {
-        // valued records, no dense strips, fixed-point filter: the flat walk (bp_flat.h)
-        if (vm == VM_F32) { kern = bp_flat_topk<VM_F32, kFlRoundsF32, kBpRowsMax>; lds = bp_flat_lds_bytes<kFlRoundsF32, kBpRowsMax>(ent_cap); }
-        else { kern = bp_flat_topk<VM_F16, kFlRoundsF16, kBpRowsMax>; lds = bp_flat_lds_bytes<kFlRoundsF16, kBpRowsMax>(ent_cap); }
-#endif
-    } else if (vm == VM_BIN && AM == AM_FIX && idx->bp_walk_pref != 0 && !a.upper && ent_cap <= kBpEntCap) {
-        // bag-of-token index: the walk with the next block's records prefetched across the barrier (bp_bin.h); postings_walk = 0: the list walk
-        kern = bp_bin_topk<kBpRowsMaxBin>;
-        lds = bp_bin_lds_bytes<kBpRowsMaxBin>(ent_cap);
-    } else if (vm == VM_BIN) {
-        if (AM != AM_FIX) return fail(VS_EUNSUPPORTED, "binary postings serve the filter walk only");
-        // one lane per list; the option picks the records in flight per lane = the size of the chunks dealt to the waves (8: 512
-        // entries, 13 chunks a block on the Wiki21M shape, 16.4 k q/s; 4: 25 chunks for 16 waves, 13.0 k)
-        kern = idx->bp_lanes == 4 ? bp_walk_topk<VM_BIN, kBpBinQT, AM_FIX, 1, kBpRowsMaxBin, 4> : bp_walk_topk<VM_BIN, kBpBinQT, AM_FIX, 1, kBpRowsMaxBin, 8>;
-        lds = bp_lds_bytes<kBpBinQT, AM_FIX, kBpRowsMaxBin>(ent_cap);
-    } else if (AM == AM_FIX && a.n_head > 0) {
-        if constexpr (AM == AM_FIX) {
-            if (vm == VM_F32) kern = idx->bp_lanes != 4 ? bp_walk_topk<VM_F32, QT, AM_FIX, 8, kBpRowsMax, kBpNB, 1> : bp_walk_topk<VM_F32, QT, AM_FIX, 4, kBpRowsMax, kBpNB, 1>;
-            else kern = idx->bp_lanes != 4 ? bp_walk_topk<VM_F16, QT, AM_FIX, 8, kBpRowsMax, kBpNB, 1> : bp_walk_topk<VM_F16, QT, AM_FIX, 4, kBpRowsMax, kBpNB, 1>;
-        }
-    } else if (vm == VM_F32) {
-        kern = idx->bp_lanes != 4 ? bp_walk_topk<VM_F32, QT, AM, 8, kBpRowsMax> : bp_walk_topk<VM_F32, QT, AM, 4, kBpRowsMax>;
-    } else {
-        kern = idx->bp_lanes != 4 ? bp_walk_topk<VM_F16, QT, AM, 8, kBpRowsMax, (AM == AM_FIX ? kBpNBWide : kBpNB)> : bp_walk_topk<VM_F16, QT, AM, 4, kBpRowsMax>;
-    }
-    if (lds > 160 * 1024) return fail(VS_EUNSUPPORTED, "postings walk needs %zu B of LDS", lds);
-    VS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kScanThreads), lds, s, a);
-    VS_HIP(hipGetLastError());
-    return VS_OK;
-}
-
-int bp_build(vs_index* idx, hipStream_t s) {
-    idx->bp_tried = true;
-    bp_release(idx);
-    // Documents per block.  Valued index: as many as give an average list ~50 postings (768-nnz documents, V = 29 523: 1920) --
-    // a list is read by 8 lanes x 8 postings per round, and at 53 postings a list (2048 documents) 1 list in 15 needs a second
-    // record per lane, at 50 (1920) 1 in 40: 152.2 vs 158.7 ms at 21 M docs (1792: 156.1) -- capped by what the accumulators
-    // hold (2048) and kept a multiple of 128 (dense strips).  Binary index: 2048.
-    // Quad chunks (bp_quad.h) -- the default copy of a valued index searched by filter + refine: a list is cut into 64-cell chunks of
-    // one-dword postings (fp16 values).  Not for: a binary index; exact fp32 records ("postings_quant" = 0, signed / huge values);
-    // the fp64 walk ("postings_filter" = 0); a corpus with head columns (their dense strips belong to the list walk: bp_build starts
-    // over without quad when it finds any); the experimental walks 0 .. 3 ("postings_walk"), aligned or arranged records.
-    const bool quad_pref = idx->store_dtype != VS_NONE && idx->bp_filter != 0 && idx->n_cols <= 32768 && (idx->bp_walk_pref == -1 || idx->bp_walk_pref == 4) && !idx->bp_no_quad &&
-                           idx->bp_align_pref != 1 && idx->bp_arrange_pref != 1 && (idx->store_dtype == VS_F16 || idx->bp_quant_pref != 0);
-    idx->bp_no_quad = false;
-    auto auto_rows = [&]() -> int {
-        if (idx->store_dtype == VS_NONE) return kBpRowsMaxBin;
-        const double avg = idx->n_rows > 0 ? (double)idx->nnz / (double)idx->n_rows : 1.0;
-        // (quad chunks: at 50 postings a list 1 list in 40 goes on in an overflow chunk; 2048 documents per block measured the same)
-        const int r = (int)(50.0 * (double)idx->n_cols / std::max(avg, 1.0)) / 128 * 128;
-        return std::max(256, std::min(r, kBpRowsMax));
-    };
-    idx->bp_rows = idx->bp_rows_pref > 0 ? std::min(idx->bp_rows_pref, idx->store_dtype == VS_NONE ? kBpRowsMaxBin : kBpRowsMax)
-                   : idx->bp_rows_forced > 0 ? idx->bp_rows_forced : auto_rows();
-    idx->bp_rows_forced = 0;
-    const int64_t n_blocks = ceil_div64(idx->n_rows, idx->bp_rows);
-    const int V = idx->n_cols;
-    const int RS0 = bp_rec_bytes(idx->store_dtype == VS_F32 ? VM_F16 : idx->store_dtype == VS_F16 ? VM_F16 : VM_BIN);   // smallest record this index can get
-    const size_t b_dir = (size_t)n_blocks * ((size_t)V + 1) * 4;
-    size_t free_b = 0, total_b = 0;
-    VS_HIP(hipMemGetInfo(&free_b, &total_b));
-    const size_t margin = idx->bp_pref == 1 ? ((size_t)256 << 20) : ((size_t)4 << 30);  // leave room for scratch / other tensors
-    auto no_room = [&](size_t need) {
-        fprintf(stderr, "[vsearch_hip] blocked-postings copy not built: needs %.1f GB, %.1f GB of HBM free -- sparse queries use the CSR scan (3x slower)\n",
-                (double)need / 1e9, (double)free_b / 1e9);
-        bp_release(idx);
-        idx->bp_state = 2;
-        (void)hipGetLastError();
-        return VS_OK;
-    };
-    // lower bound of the records: one per 8 non-zeros
-    if (free_b < b_dir + (size_t)idx->n_packets * RS0 + margin) return no_room(b_dir + (size_t)idx->n_packets * RS0);
-    DevBuf block_recs;
-    if (idx->bp_dir.alloc(b_dir) != VS_OK || idx->bp_base.alloc((size_t)(n_blocks + 1) * 8) != VS_OK || idx->bp_df.alloc((size_t)V * 16) != VS_OK ||
-        block_recs.alloc((size_t)n_blocks * 4) != VS_OK)
-        return no_room(b_dir);
-    VS_HIP(hipMemsetAsync(idx->bp_df.p, 0, (size_t)V * 16, s));
-    unsigned long long* df_rec = idx->bp_df.as<unsigned long long>();
-    unsigned long long* df_nnz = df_rec + V;
-    const size_t lds = ((size_t)V + 1) * 4;
-    const int grid = (int)std::min<int64_t>(n_blocks, (int64_t)idx->cu_count * 8);
-    ProfScope prof("bp_build", s);
-    // max |value| (bounds the products of the fixed-point walk) and "any value negative"; a binary index has no values
-    uint32_t hv[2] = {0x3F800000u, 0u};
-    if (idx->store_dtype != VS_NONE) {
-        VS_TRY(idx->bp_vmax.alloc(8));
-        VS_HIP(hipMemsetAsync(idx->bp_vmax.p, 0, 8, s));
-        const int64_t nv = idx->n_packets * 8;
-        const unsigned g = (unsigned)std::min<int64_t>(ceil_div64(nv, 256 * 16), (int64_t)idx->cu_count * 16);
-        if (idx->store_dtype == VS_F32) hipLaunchKernelGGL(bp_vmax_kernel<VM_F32>, dim3(g), dim3(256), 0, s, (const void*)idx->vals.p, nv, idx->bp_vmax.as<uint32_t>());
-        else hipLaunchKernelGGL(bp_vmax_kernel<VM_F16>, dim3(g), dim3(256), 0, s, (const void*)idx->vals.p, nv, idx->bp_vmax.as<uint32_t>());
-        VS_HIP(hipGetLastError());
-        VS_HIP(hipMemcpyAsync(hv, idx->bp_vmax.p, 8, hipMemcpyDeviceToHost, s));
-    }
-    VS_HIP(hipStreamSynchronize(s));
-    float vmax_f;
-    memcpy(&vmax_f, &hv[0], 4);
-    const bool lossy_ok = hv[1] == 0u && vmax_f < 60000.f;       // fp16 copies of the values: non-negative, no overflow
-    const bool quad = quad_pref && lossy_ok;                        // (non-negative values: a set sign bit marks a link)
-    // Lossy filter copy of an fp32 index: values rounded to fp16 (4 instead of 6 bytes per posting); needs the filter-and-refine
-    // search, non-negative values and no fp16 overflow
-    idx->bp_quant = idx->store_dtype == VS_F32 && idx->bp_filter != 0 && idx->bp_quant_pref != 0 && lossy_ok;
-    // option "postings_align" = 1: lists start on whole 128-byte lines (+16 % bytes for -1.5 % walk time at 8 lanes per list: off by default)
-    idx->bp_al_shift = idx->bp_align_pref == 1 ? bp_align_shift(bp_record_vm(idx)) : 0;
-    DevBuf ovf;
-    VS_TRY(ovf.alloc(4));
-    VS_HIP(hipMemsetAsync(ovf.p, 0, 4, s));
-    if (quad) {
-        // quad chunks: main chunk of column c = chunk c of its block, overflow chunks behind (the directory is the builder's only)
-        const size_t b_main = (size_t)n_blocks * V * kQuadChunkBytes;
-        if (free_b < b_dir + b_main + margin) return no_room(b_dir + b_main);
-        VS_HIP(hipFuncSetAttribute((const void*)quad_count_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(quad_count_kernel<0>, dim3(grid), dim3(kScanThreads), lds, s, idx->pk_ptr.as<uint32_t>(), idx->cols.as<uint4>(), idx->n_rows, V, idx->bp_rows,
-                           idx->bp_dir.as<uint32_t>(), block_recs.as<uint32_t>(), df_rec, df_nnz, ovf.as<int32_t>());
-    } else {
-        VS_HIP(hipFuncSetAttribute((const void*)bp_count_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(bp_count_kernel<0>, dim3(grid), dim3(kScanThreads), lds, s, idx->pk_ptr.as<uint32_t>(), idx->cols.as<uint4>(), idx->n_rows, V, idx->bp_rows,
-                           idx->bp_dir.as<uint32_t>(), block_recs.as<uint32_t>(), df_rec, df_nnz, (const uint16_t*)nullptr, idx->bp_al_shift, ovf.as<int32_t>(), 3);
-    }
-    VS_STAGE("bp_count", s);
-    // Head columns (skewed vocabularies): present in >= 1/4 of the documents -> dense strips instead of posting lists.  Valued
-    // indexes with the filter search only (the strips hold fp16 values: the fp64 walk cannot use them).
-    idx->bp_vmax_f = vmax_f;
-    static const int head_env = getenv("VS_BP_HEAD") ? atoi(getenv("VS_BP_HEAD")) : -2;           // (developer override of "postings_head")
-    if (head_env > -2) idx->bp_head_pref = head_env;
-    if (idx->store_dtype != VS_NONE && idx->bp_filter != 0 && idx->bp_head_pref != 0 && idx->n_rows >= 4096 && lossy_ok && idx->bp_rows % 128 == 0 &&
-        vmax_f >= 1.f / 64.f) {
-        DevBuf nh;
-        VS_TRY(nh.alloc(4));
-        VS_TRY(idx->bp_hmap.alloc((size_t)V * 2));
-        hipLaunchKernelGGL(bp_head_select_kernel<0>, dim3(1), dim3(kScanThreads), 0, s, df_nnz, V, (unsigned long long)ceil_div64(idx->n_rows, idx->bp_head_pref > 0 ? idx->bp_head_pref : 4), kBpHeadCap,
-                           idx->bp_hmap.as<uint16_t>(), nh.as<int32_t>());
-        VS_HIP(hipGetLastError());
-        int32_t h_n = 0;
-        VS_HIP(hipMemcpyAsync(&h_n, nh.p, 4, hipMemcpyDeviceToHost, s));
-        VS_HIP(hipStreamSynchronize(s));
-        idx->bp_n_head = h_n;
-        if (h_n > 0 && quad) {                                  // head columns: records + dense strips (the list walk)
-            idx->bp_no_quad = true;
-            return bp_build(idx, s);
-        }
-        if (h_n > 0 && idx->bp_rows_pref <= 0 && idx->bp_rows < kBpRowsMax) {
-            // a skewed corpus: its lists are long whatever the block size, and the dense strips and the per-block costs want the
-            // largest blocks (zipf 21 M docs: 289 ms at 2048 documents per block, 301 at 1920) -- start over with those
-            idx->bp_rows_forced = kBpRowsMax;
-            idx->bp_no_quad = true;                               // (head columns: the restart must not try quad chunks again)
-            return bp_build(idx, s);
-        }
-        if (h_n > 0) {
-            // the directory again, without the head columns' lists
-            VS_HIP(hipMemsetAsync(idx->bp_df.p, 0, (size_t)V * 16, s));
-            hipLaunchKernelGGL(bp_count_kernel<0>, dim3(grid), dim3(kScanThreads), lds, s, idx->pk_ptr.as<uint32_t>(), idx->cols.as<uint4>(), idx->n_rows, V,
-                               idx->bp_rows, idx->bp_dir.as<uint32_t>(), block_recs.as<uint32_t>(), df_rec, df_nnz, (const uint16_t*)idx->bp_hmap.as<uint16_t>(),
-                               idx->bp_al_shift, ovf.as<int32_t>(), 3);
-            VS_HIP(hipGetLastError());
-            const size_t b_strip = (size_t)n_blocks * bp_head_pad(h_n) * idx->bp_rows * 2;
-            VS_HIP(hipMemGetInfo(&free_b, &total_b));
-            if (free_b < b_strip + margin || idx->bp_strip.alloc(b_strip) != VS_OK) return no_room(b_strip);
-            VS_HIP(hipMemsetAsync(idx->bp_strip.p, 0, b_strip, s));
-        } else {
-            idx->bp_hmap.release();
-        }
-    }
-    hipLaunchKernelGGL(bp_base_kernel<0>, dim3(1), dim3(kScanThreads), 0, s, block_recs.as<uint32_t>(), n_blocks, idx->bp_base.as<unsigned long long>());
-    VS_HIP(hipGetLastError());
-    VS_STAGE("bp_base", s);
-    unsigned long long n_rec = 0;
-    int32_t h_ovf = 0;
-    VS_HIP(hipMemcpyAsync(&n_rec, idx->bp_base.as<unsigned long long>() + n_blocks, 8, hipMemcpyDeviceToHost, s));
-    VS_HIP(hipMemcpyAsync(&h_ovf, ovf.p, 4, hipMemcpyDeviceToHost, s));
-    std::vector<uint32_t> h_brecs((size_t)n_blocks);
-    VS_HIP(hipMemcpyAsync(h_brecs.data(), block_recs.p, (size_t)n_blocks * 4, hipMemcpyDeviceToHost, s));
-    VS_HIP(hipStreamSynchronize(s));
-    idx->bp_max_block_recs = 0;
-    for (uint32_t r : h_brecs) idx->bp_max_block_recs = std::max<int64_t>(idx->bp_max_block_recs, (int64_t)r);
-    if (h_ovf) {                                                        // (2048 documents x 29 523 columns, all present, would do it)
-        fprintf(stderr, "[vsearch_hip] blocked-postings copy not built: a block holds more records than a directory word addresses -- sparse queries use the CSR scan\n");
-        bp_release(idx);
-        idx->bp_state = 3;
-        return VS_OK;
-    }
-    VS_STAGE("bp_vmax", s);
-    const int RS = quad ? kQuadChunkBytes : bp_rec_bytes(bp_record_vm(idx));
-    const size_t b_rec = ((size_t)n_rec + 2) * RS;                       // + one record: a lane past the last list's end re-reads "the record at the end"
-    VS_HIP(hipMemGetInfo(&free_b, &total_b));
-    if (free_b < b_rec + margin || idx->bp_rec.alloc(b_rec) != VS_OK) return no_room(b_rec);
-    idx->bp_records = (int64_t)n_rec;
-    VS_HIP(hipMemsetAsync(idx->bp_rec.p, 0, b_rec, s));                  // pad postings: document 0, value 0
-    if (quad) {
-        void (*fill)(const uint32_t*, const uint4*, const void*, int64_t, int32_t, int32_t, const uint32_t*, const unsigned long long*, uint32_t*) =
-            idx->store_dtype == VS_F32 ? quad_fill_kernel<VM_F32> : quad_fill_kernel<VM_F16>;
-        VS_HIP(hipFuncSetAttribute((const void*)fill, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(fill, dim3(grid), dim3(kScanThreads), lds, s, idx->pk_ptr.as<uint32_t>(), idx->cols.as<uint4>(), (const void*)idx->vals.p, idx->n_rows, V,
-                           idx->bp_rows, idx->bp_dir.as<uint32_t>(), idx->bp_base.as<unsigned long long>(), idx->bp_rec.as<uint32_t>());
-        VS_HIP(hipGetLastError());
-        VS_STAGE("quad_fill", s);
-        const size_t alds = (size_t)2 * 256 * (kQuadCells + 1) * 4;
-        VS_HIP(hipFuncSetAttribute((const void*)quad_arrange_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)alds));
-        hipLaunchKernelGGL(quad_arrange_kernel<0>, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div64((int64_t)n_rec, 256), (int64_t)idx->cu_count * 8))), dim3(256), alds, s,
-                           idx->bp_rec.as<uint32_t>(), n_rec);
-        VS_HIP(hipGetLastError());
-        VS_STAGE("quad_arrange", s);
-        idx->bp_quad = true;
-        VS_HIP(hipStreamSynchronize(s));
-        idx->bp_dir.release();                                           // (the chunks link to their overflow themselves)
-        idx->bp_quant = idx->store_dtype == VS_F32;                      // fp16-rounded values of an fp32 index: the refine step's bound accounts for them
-    } else {
-        void (*fill)(const uint32_t*, const uint4*, const void*, int64_t, int32_t, int32_t, const uint32_t*, const unsigned long long*, char*, const uint16_t*, __half*, int32_t, int32_t) =
-            idx->store_dtype == VS_F32 ? (idx->bp_quant ? bp_fill_kernel<VM_F32, VM_F16> : bp_fill_kernel<VM_F32, VM_F32>)
-            : idx->store_dtype == VS_F16 ? bp_fill_kernel<VM_F16, VM_F16> : bp_fill_kernel<VM_BIN, VM_BIN>;
-        VS_HIP(hipFuncSetAttribute((const void*)fill, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(fill, dim3(grid), dim3(kScanThreads), lds, s, idx->pk_ptr.as<uint32_t>(), idx->cols.as<uint4>(), (const void*)idx->vals.p, idx->n_rows, V,
-                           idx->bp_rows, idx->bp_dir.as<uint32_t>(), idx->bp_base.as<unsigned long long>(), idx->bp_rec.as<char>(),
-                           idx->bp_n_head > 0 ? (const uint16_t*)idx->bp_hmap.as<uint16_t>() : (const uint16_t*)nullptr, idx->bp_strip.as<__half>(), idx->bp_n_head,
-                           idx->bp_al_shift);
-    }
-    VS_HIP(hipGetLastError());
-    VS_STAGE("bp_fill", s);
-    // bank-aware order inside the lists (option "postings_arrange" = 1; off by default: 4 M docs, list walk 29.83 -> 29.58 ms for 55 ms more
-    // build time -- the scatter-add's bank conflicts are not what the walk waits for)
-    if (!quad && idx->store_dtype != VS_NONE && idx->bp_arrange_pref == 1) {
-        void (*arr)(const uint32_t*, const unsigned long long*, char*, int64_t, int32_t, int32_t) =
-            bp_record_vm(idx) == VM_F32 ? bp_arrange_kernel<VM_F32> : bp_arrange_kernel<VM_F16>;
-        const size_t alds = (size_t)256 * 64 * (2 + 4);
-        VS_HIP(hipFuncSetAttribute((const void*)arr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)alds));
-        hipLaunchKernelGGL(arr, dim3((unsigned)std::min<int64_t>(n_blocks, (int64_t)idx->cu_count * 8)), dim3(256), alds, s, idx->bp_dir.as<uint32_t>(),
-                           idx->bp_base.as<unsigned long long>(), idx->bp_rec.as<char>(), n_blocks, V, idx->bp_al_shift);
-        VS_HIP(hipGetLastError());
-        VS_STAGE("bp_arrange", s);
-    }
-    VS_HIP(hipStreamSynchronize(s));                                     // `block_recs` is freed on return
-    if (debug_sync_on()) {
-        std::vector<unsigned long long> hb((size_t)n_blocks + 1);
-        std::vector<uint32_t> hd((size_t)V + 1);
-        (void)hipMemcpy(hb.data(), idx->bp_base.p, hb.size() * 8, hipMemcpyDeviceToHost);
-        (void)hipMemcpy(hd.data(), idx->bp_dir.as<uint32_t>() + (size_t)(n_blocks - 1) * (V + 1), hd.size() * 4, hipMemcpyDeviceToHost);
-        bool mono = true;
-        for (size_t i = 0; i + 1 < hb.size(); ++i) mono = mono && hb[i] <= hb[i + 1];
-        bool dmono = true;
-        for (size_t i = 0; i + 2 < hd.size(); ++i) dmono = dmono && (hd[i] >> 12) <= (hd[i + 1] >> 12);
-        fprintf(stderr, "[vsearch_hip] bp: rows %d blocks %lld records %llu base[1] %llu base[last] %llu monotone %d; last block dir end %u (block holds %llu) monotone %d\n",
-                idx->bp_rows, (long long)n_blocks, n_rec, hb.size() > 1 ? hb[1] : 0ull, hb[n_blocks], (int)mono, (hd[V - 1] >> 12) << idx->bp_al_shift, hb[n_blocks] - hb[n_blocks - 1], (int)dmono);
-    }
-    idx->bp_ready = true;
-    idx->bp_state = 1;
-    return VS_OK;
-}
-
-// Builds the blocked-postings copy NOW when this index would get one at its first sparse search (vs_index_prepare: the 0.5 s of a
-// 21 M-doc build then belong to load / move_to_device, not to a user's first retrieve).  Idempotent.
-int csr_prepare_impl(vs_index* idx, hipStream_t s) {
-    if (idx->kind != VS_KIND_CSR || idx->qt_pref == 1) return VS_OK;
-    if (!bp_wanted(idx)) { if (!idx->bp_ready) idx->bp_state = 4; return VS_OK; }
-    if (!idx->bp_ready && !idx->bp_tried) VS_TRY(bp_build(idx, s));
-    return VS_OK;
-}
-
-// Error bound, in units of the fixed-point sums, of the dense (matrix-core) part of a filter score against the real sum of
-// weight * scale * fp16 strip value over the head columns (all terms >= 0, the sum < 2^30):
-//   weights split in two fp16 numbers: hi + lo misses <= 2^-22 of each weight                            -> 2^8
-//   lo below the fp16 normal range (taken as flushed to zero): <= 2^-14 of an operand unit, x 2^16       -> 4 per column
-//   strip values below the fp16 normal range (taken as flushed): value < 2^-14, weights sum < 2^30 / max -> 2^16 / max value
-//   fp32 accumulation: 33 additions per k-step of 32 columns, each off by <= one ulp of a sum < 2^30     -> 33 * 128 per k-step
-//   the lo column's own sums are 2^-11 of that; two truncations                                          -> 64 + 2
-int32_t bp_head_slack(const vs_index* idx) {
-    if (idx->bp_n_head <= 0) return 0;
-    const int hp = bp_head_pad(idx->bp_n_head);
-    return 256 + 4 * hp + (int32_t)ceilf(65536.f / idx->bp_vmax_f) + 33 * 128 * (hp / 32) + 66;
-}
-
-// chunks of the postings walk for `n_tiles` query tiles (see bp_filter_search)
-int bp_choose_chunks(const vs_index* idx, int n_tiles, int64_t n_blocks, int plan_nchunk) {
-    int nchunk = (int)std::min<int64_t>(choose_chunks(idx, n_tiles, plan_nchunk), n_blocks);
-    // Big index, enough tiles: as FEW chunks as give every CU ONE work item.  Every tile sweeps its chunk's blocks in the same
-    // order at the same pace, so with few chunks all tiles are within a few blocks of each other and each block is fetched from
-    // HBM once for all of them (Infinity Cache); and every item pays its start-up (entry sort, the candidate flood until its
-    // threshold rises) once.  21 M docs, 1024 queries, walk time: 2 chunks 159.0 ms (5 of 6 fresh processes; 167.3 in the sixth),
-    // 4 chunks 169.4, 3 chunks (384 items on 256 CUs) 328.  (Before the waves took their chunks of a block dynamically, one item
-    // per CU was unstable: 203 .. 233 ms against 207 at two per CU.)  Binary index: 2 chunks 63.5 ms, 4: 64.9, 8: 68.1.
-    if (idx->n_rows >= (2 << 20) && (int64_t)n_tiles * 4 >= idx->cu_count) {
-        int best = 1;
-        double best_eff = 0.0;
-        // (a skewed corpus -- one with head columns -- keeps two items per CU: its tiles differ in weight, and with one item
-        //  each the heaviest tile's CU finishes alone: zipf 21 M docs 441 ms against 289)
-        const int per_cu = idx->bp_n_head > 0 ? 2 : 1;
-        const int c0 = (int)std::max<int64_t>(1, ceil_div64(per_cu * (int64_t)idx->cu_count, n_tiles));
-        for (int c = c0; c <= c0 + 3; ++c) {
-            const int64_t it = (int64_t)n_tiles * c;
-            const double eff = (double)it / (double)(ceil_div64(it, idx->cu_count) * idx->cu_count);
-            if (eff > best_eff + 1e-9) { best_eff = eff; best = c; }
-            if (eff >= 0.95) break;
-        }
-        nchunk = (int)std::min<int64_t>(best, n_blocks);
-    }
-    if (idx->bp_chunks > 0) nchunk = (int)std::min<int64_t>(idx->bp_chunks, n_blocks);
-    static const int chunks_env = getenv("VS_BP_CHUNKS") ? atoi(getenv("VS_BP_CHUNKS")) : 0;      // (developer override)
-    if (chunks_env > 0) nchunk = (int)std::min<int64_t>(chunks_env, n_blocks);
-    return std::max(1, nchunk);
-}
-
-// the filter-and-refine search takes this call: one pass, k + margin within the candidate buffers
-bool bp_filter_ok(const vs_index* idx, int k, int col0, const uint64_t* upper) {
-    return idx->bp_ready && idx->bp_filter != 0 && col0 == 0 && !upper && k + std::max(28, k / 4) <= kBpMaxK &&
-           (idx->store_dtype == VS_NONE || idx->bp_vmax.p) && mq_vals_cap(idx) > 0;
-}
-
-// Filter and refine (bp_walk.h, bp_refine.h), WITHOUT a host synchronisation: the query tiles are planned on the device and the
-// kernels read the tile count there; scratch is sized from upper bounds (B queries x the entry capacity of a tile); queries too
-// dense for a tile, and queries whose top k the refine step cannot prove, are collected on the device and take the exact
-// one-query scan, launched unconditionally (it returns at once when the list is empty).
-int bp_filter_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64_t id_offset, int64_t* d_ids, float* d_scores, const ScanPlan& plan,
-                     hipStream_t s, bool* done, int32_t out_ld) {
-    const int V = idx->n_cols;
-    const int kp = k + std::max(28, k / 4);
-    const bool duo = bp_duo_ok(idx, kp, nullptr);
-    static const int qt_env = getenv("VS_BP_QT") ? atoi(getenv("VS_BP_QT")) : 0;                       // (developer: smaller tiles on the 8-slot walk)
-    const int qt = qt_env > 0 ? std::min(qt_env, kQT) : idx->store_dtype == VS_NONE ? kBpBinQT : (duo ? kDuoQT : kQT);
-    // (dense strips: their weight matrix takes 16 KB of the LDS the entries would use)
-    const int vals_cap = std::min(mq_vals_cap(idx), duo ? kDuoEntCap : (idx->bp_n_head > 0 ? kBpEntCap - 512 : kBpEntCap));
-    const int64_t qcap = (int64_t)B * vals_cap;                               // bound of the batch's (query, column) entries that enter a tile
-    const int64_t n_blocks = ceil_div64(idx->n_rows, idx->bp_rows);
-    if (idx->bp_rows > (idx->store_dtype == VS_NONE ? kBpRowsMaxBin : kBpRowsMax)) return fail(VS_EINVAL, "postings_rows beyond the walk's block capacity");
-    // scratch: per-query metadata (counts, qptr, plan, tiles, flags, scale, slack, weight sums), column frequencies, the sparse batch
-    const size_t off_counts = 0, off_qptr = off_counts + (size_t)B * 8, off_plan = off_qptr + (size_t)(B + 1) * 8, off_tiles = off_plan + 64,
-                 off_fb = off_tiles + (size_t)B * 8, off_scale = off_fb + (size_t)B * 8, off_slack = off_scale + (size_t)B * 4,
-                 off_wsum = off_slack + (size_t)B * 4, off_flags = off_wsum + (size_t)B * 4, off_nfb = off_flags + (size_t)B * 4,
-                 off_gtau = (off_nfb + 64 + 15) & ~(size_t)15, off_freq = (off_gtau + (size_t)B * 8 + 15) & ~(size_t)15;
-    VS_TRY(idx->ws_mq_meta.reserve(off_freq + (size_t)(V + 4) * 4 + 8));
-    char* meta = idx->ws_mq_meta.as<char>();
-    unsigned long long* gtau = (unsigned long long*)(meta + off_gtau);
-    int64_t* counts = (int64_t*)(meta + off_counts);
-    int64_t* qptr = (int64_t*)(meta + off_qptr);
-    int64_t* dplan = (int64_t*)(meta + off_plan);
-    int2* tiles = (int2*)(meta + off_tiles);
-    int2* fb_tiles = (int2*)(meta + off_fb);
-    float* qscale = (float*)(meta + off_scale);
-    int32_t* qslack = (int32_t*)(meta + off_slack);
-    float* qwsum = (float*)(meta + off_wsum);
-    uint32_t* flags = (uint32_t*)(meta + off_flags);
-    int32_t* fb_n = (int32_t*)(meta + off_nfb);
-    uint32_t* colfreq = (uint32_t*)(meta + off_freq);
-    VS_TRY(idx->ws_mq_q.reserve(std::max<size_t>((size_t)qcap * 8, 16)));
-    int32_t* qcols = idx->ws_mq_q.as<int32_t>();
-    float* qvals = reinterpret_cast<float*>(qcols + qcap);
-    // 1. sparsify the batch and plan the tiles, all on the device
-    VS_HIP(hipMemsetAsync(gtau, 0, (size_t)(off_freq - off_gtau) + (size_t)(V + 4) * 4 + 8, s));      // thresholds + column frequencies (adjacent)
-    hipLaunchKernelGGL(bp_count_colfreq_kernel<0>, dim3(std::min(B, 2048)), dim3(256), 0, s, dq, (int64_t)V, B, V, counts, colfreq);
-    if (B <= kPlanFast) hipLaunchKernelGGL(bp_plan_fast_kernel<0>, dim3(1), dim3(256), 0, s, counts, B, qt, vals_cap, qptr, tiles, dplan, flags);
-    else hipLaunchKernelGGL(bp_plan_kernel<0>, dim3(1), dim3(64), 0, s, counts, B, qt, vals_cap, qptr, tiles, dplan, flags);
-    hipLaunchKernelGGL(fill_csr_kernel<0>, dim3(std::min(B, 2048)), dim3(kSpThreads), 0, s, dq, (int64_t)V, B, V, qptr, qcols, qvals, qcap);
-    if (idx->bp_df.p)
-        hipLaunchKernelGGL(bp_walk_kernel<0>, dim3(1), dim3(kScanThreads), 0, s, colfreq, idx->bp_df.as<unsigned long long>(),
-                           idx->bp_df.as<unsigned long long>() + V, V, dplan + 4);
-    hipLaunchKernelGGL(bp_qscale_kernel<0>, dim3((unsigned)ceil_div(B, 4)), dim3(256), 0, s, qptr, qvals, B, idx->bp_vmax.as<uint32_t>(),
-                       idx->store_dtype == VS_NONE ? 1 : 0, (idx->bp_quant || idx->bp_n_head > 0) ? 1 : 0, qscale, qslack, qwsum, (const int32_t*)qcols,
-                       idx->bp_n_head > 0 ? (const uint16_t*)idx->bp_hmap.as<uint16_t>() : (const uint16_t*)nullptr, bp_head_slack(idx));
-    VS_HIP(hipGetLastError());
-    VS_STAGE("sparsify", s);
-    // 2. the walk.  Work items = (tile, chunk); the tile count lives on the device, the chunks follow its lower bound ceil(B / qt)
-    const int n_tiles_est = ceil_div(B, qt);
-    const int nchunk = bp_choose_chunks(idx, n_tiles_est, n_blocks, plan.nchunk);
-    const int nchunk_fb = (int)std::min<int64_t>(n_blocks, 64);
-    const int grid = (int)std::min<int64_t>((int64_t)B * nchunk, idx->cu_count);
-    VS_TRY(idx->ws_mq_cand.reserve((size_t)idx->cu_count * kQT * std::max(kBpCap, kFlCap) * 8));
-    VS_TRY(idx->ws_cand.reserve(std::max((size_t)B * nchunk * kp, (size_t)B * nchunk_fb * k) * 8));
-    BpArgs a{};
-    a.rows = idx->bp_rows;
-    a.dir = idx->bp_dir.as<uint32_t>();
-    a.al_shift = idx->bp_al_shift;
-    a.base = idx->bp_base.as<unsigned long long>();
-    a.rec = idx->bp_rec.as<char>();
-    a.n_rows = idx->n_rows;
-    a.n_cols = V;
-    a.k = kp;
-    a.nchunk = nchunk;
-    a.blocks_per_chunk = ceil_div64(n_blocks, nchunk);
-    a.qptr = qptr;
-    a.qcols = qcols;
-    a.qvals = qvals;
-    a.tiles = tiles;
-    a.n_tiles = 0;
-    a.n_tiles_dev = reinterpret_cast<const int32_t*>(dplan);                  // plan[0] (little endian: the low word of the int64)
-    a.ent_cap = vals_cap;
-    a.cand = idx->ws_cand.as<uint64_t>();
-    a.gcand = idx->ws_mq_cand.as<uint64_t>();
-    a.qscale = qscale;
-    a.gtau = gtau;
-    a.df = idx->bp_df.p ? idx->bp_df.as<unsigned long long>() + V : nullptr;          // (second half of bp_df: non-zeros per column)
-    a.hmap = idx->bp_n_head > 0 ? idx->bp_hmap.as<uint16_t>() : nullptr;
-    a.strip = idx->bp_strip.as<__half>();
-    a.n_head = idx->bp_n_head;
-    if (a.n_head > 0) {
-        int ve;
-        (void)frexpf(idx->bp_vmax_f, &ve);                          // max value < 2^ve
-        a.head_pre = ldexpf(1.f, ve - 16);                          // weight * scale < 2^30 / max value  ->  * 2^ve / 2^16 < 2^15: an fp16 number
-        a.head_mul = ldexpf(1.f, 16 - ve);
-    }
-    idx->last_path = 3;
-    idx->last_plan_dev = dplan;
-    idx->last_plan_rs = idx->bp_quad ? kQuadChunkBytes : bp_rec_bytes(bp_record_vm(idx));
-    idx->last_plan_blocks = n_blocks;
-    // lock-step window of the walk's work items (all walks; kernels ignore it when not every item is resident)
-    static const int pace_env = getenv("VS_BP_PACE") ? atoi(getenv("VS_BP_PACE")) : -1;
-    // (off by default for the list walk: it costs it 10 %; the bag-of-token walk of bp_bin.h runs ahead of its memory and
-    //  NEEDS it: free running 81 ms, window 16: 66.7, 32: 56.5, 48: 57.2, 64: 58.7, 128: 73 -- the list walk: 61.3)
-    const bool bin_walk = idx->store_dtype == VS_NONE && idx->bp_walk_pref != 0;
-    // (the two-set walk has no block barrier to keep its workgroups at one pace: 4 M docs 56.9 ms free running, window 1: 39.8, 2: 37.9, 4: 42.2)
-    const int pace_w = pace_env >= 0 ? pace_env : (idx->bp_pace >= 0 ? idx->bp_pace : (bin_walk ? 32 : (duo ? 2 : (idx->bp_quad ? kQuadPaceDefault : 0))));
-    if (pace_w > 0) {
-        VS_TRY(idx->ws_pace.reserve((size_t)nchunk * a.blocks_per_chunk * 4));
-        VS_HIP(hipMemsetAsync(idx->ws_pace.p, 0, (size_t)nchunk * a.blocks_per_chunk * 4, s));
-        a.pace = idx->ws_pace.as<uint32_t>();
-        a.pace_window = pace_w;
-    }
-    static const int knob_env = getenv("VS_BP_KNOB") ? atoi(getenv("VS_BP_KNOB")) : 0;
-    a.knob = knob_env;
-    static const bool debug_on = getenv("VS_BP_DEBUG") != nullptr;
-    DevBuf dbg;
-    if (debug_on) {
-        VS_TRY(dbg.alloc(64));
-        VS_HIP(hipMemsetAsync(dbg.p, 0, 64, s));
-        a.debug = dbg.as<unsigned long long>();
-    }
-    static const bool timing_on = getenv("VS_BP_TIMING") != nullptr;            // developer aid: where the walk's wave-cycles go
-    DevBuf timing;
-    if (timing_on) {
-        VS_TRY(timing.alloc(128 + (size_t)grid * 32));
-        VS_HIP(hipMemsetAsync(timing.p, 0, 128 + (size_t)grid * 32, s));
-        a.timing = timing.as<unsigned long long>();
-    }
-    {
-        ProfScope prof("csr_scan_topk", s);
-        VS_TRY((launch_bp_walk<kQT, AM_FIX>(idx, a, grid, vals_cap, s)));
-    }
-    if (debug_on) {
-        unsigned long long d[8] = {0};
-        VS_HIP(hipMemcpyAsync(d, dbg.p, 64, hipMemcpyDeviceToHost, s));
-        VS_HIP(hipStreamSynchronize(s));
-        fprintf(stderr, "[vsearch_hip] stream walk debug: %llu bad items (e.g. item %08llx, block of %llu records, block %llu, batch of %llu)\n", d[0], d[1] >> 32, d[1] & 0xFFFFFFFFull,
-                d[2] >> 32, d[2] & 0xFFFFFFFFull);
-    }
-    if (timing_on) {
-        unsigned long long h[16] = {0};
-        VS_HIP(hipMemcpyAsync(h, timing.p, 128, hipMemcpyDeviceToHost, s));
-        VS_HIP(hipStreamSynchronize(s));
-        {
-            std::vector<unsigned long long> wg((size_t)grid * 4);
-            VS_HIP(hipMemcpy(wg.data(), timing.as<unsigned long long>() + 16, wg.size() * 8, hipMemcpyDeviceToHost));
-            double tmin = 1e30, tmax = 0, tsum = 0;
-            double xs[8] = {0}, xc[8] = {0}, xn[8] = {0};
-            unsigned long long s_min = ~0ull, s_max = 0, e_max = 0;
-            for (int i = 0; i < grid; ++i) {
-                const double t = (double)wg[4 * i] * 1e-5, cyc = (double)wg[4 * i + 1];       // ms
-                tmin = std::min(tmin, t); tmax = std::max(tmax, t); tsum += t;
-                const int x = (int)(wg[4 * i + 2] & 7);
-                xs[x] += t; xc[x] += cyc; xn[x] += 1;
-                s_min = std::min(s_min, wg[4 * i + 1]); s_max = std::max(s_max, wg[4 * i + 1]); e_max = std::max(e_max, wg[4 * i + 1] + wg[4 * i]);
-            }
-            fprintf(stderr, "[vsearch_hip] walk: workgroup time min %.2f mean %.2f max %.2f ms; starts spread over %.2f ms, first start -> last end %.2f ms;", tmin, tsum / grid, tmax,
-                    (double)(s_max - s_min) * 1e-5, (double)(e_max - s_min) * 1e-5);
-            fprintf(stderr, "\n");
-            if (getenv("VS_BP_TIMING_WG")) {
-                std::vector<int> ord(grid);
-                for (int i = 0; i < grid; ++i) ord[i] = i;
-                std::sort(ord.begin(), ord.end(), [&](int x, int y) { return wg[4 * x] > wg[4 * y]; });
-                for (int j = 0; j < std::min(grid, 12); ++j) {
-                    const int i = ord[j];
-                    const unsigned hw = (unsigned)wg[4 * i + 3];
-                    fprintf(stderr, "   wg %3d: %.2f ms, %.1f Mcycles, xcc %d se %d sh %d cu %d simd %d\n", i, (double)wg[4 * i] * 1e-5, (double)wg[4 * i + 1] * 1e-6, (int)(wg[4 * i + 2] & 7),
-                            (hw >> 13) & 7, (hw >> 12) & 1, (hw >> 8) & 15, (hw >> 4) & 3);
-                }
-            }
-        }
-        if (idx->bp_quad) {
-            const double bw = (double)std::max<unsigned long long>(1, h[5]);
-            fprintf(stderr, "[vsearch_hip] quad walk, cycles per block and wave: gathers back %.0f, scan %.0f, barrier %.0f, emit %.0f, barrier (+ rest of the plan) %.0f\n", (double)h[6] / bw, (double)h[7] / bw,
-                    (double)h[8] / bw, (double)h[9] / bw, (double)h[3] / bw);
-            h[12] = h[14] = 0;
-        }
-        if (h[12] | h[14]) {
-            const double bw = (double)std::max<unsigned long long>(1, h[5]) / 16.0;
-            fprintf(stderr, "[vsearch_hip] binary walk, cycles per block: wave 0 walk %.0f wait %.0f; wave 8 walk %.0f wait %.0f\n", (double)h[12] / bw, (double)h[13] / bw,
-                    (double)h[14] / bw, (double)h[15] / bw);
-        }
-        if (bp_flat_ok<AM_FIX>(idx, a)) {        // the flat walk has no dense part: slot 3 carries 100 MHz ticks
-            fprintf(stderr, "[vsearch_hip] flat walk: shader clock %.0f MHz\n", 100.0 * (double)(h[0] + h[1] + h[2] + h[4]) / (double)std::max<unsigned long long>(1, h[3]));
-            h[3] = 0;
-        }
-        const double tot = (double)(h[0] + h[1] + h[2] + h[3] + h[4]);
-        fprintf(stderr, "[vsearch_hip] walk wave-cycles: prologue %.1f %%, list walk %.1f %%, barrier wait %.1f %%, dense %.1f %%, epilogue %.1f %%; per block and wave: "
-                        "walk %.0f wait %.0f dense %.0f epilogue %.0f cycles\n", 100.0 * h[0] / tot, 100.0 * h[1] / tot, 100.0 * h[2] / tot, 100.0 * h[3] / tot, 100.0 * h[4] / tot,
-                (double)h[1] / (double)std::max<unsigned long long>(1, h[5]), (double)h[2] / (double)std::max<unsigned long long>(1, h[5]),
-                (double)h[3] / (double)std::max<unsigned long long>(1, h[5]), (double)h[4] / (double)std::max<unsigned long long>(1, h[5]));
-    }
-    VS_STAGE("filter walk", s);
-    // 3. refine: exact scores of the K' candidates, the proof, the flags
-    RefineArgs r{};
-    r.cand = a.cand;
-    r.n_cand = (int64_t)nchunk * kp;
-    r.run_len = kp;
-    r.B = B; r.k = k; r.kp = kp;
-    r.pk_ptr = idx->pk_ptr.as<uint32_t>();
-    r.cols = idx->cols.as<uint4>();
-    r.vals = idx->vals.p;
-    r.n_cols = V;
-    r.n_rows = idx->n_rows;
-    r.q = dq;
-    r.qscale = qscale;
-    r.qslack = qslack;
-    r.qwsum = qwsum;
-    r.quant = (idx->bp_quant || idx->bp_n_head > 0) ? 1 : 0;       // fp16-rounded values in the records and / or the dense strips
-    r.force_flag = idx->bp_force_fb ? 1 : 0;
-    r.id_offset = id_offset;
-    r.out_ids = d_ids;
-    r.out_scores = d_scores;
-    r.out_ld = out_ld;
-    r.flags = flags;
-    {
-        ProfScope prof("refine_topk", s);
-        // the query's dense row in LDS when it fits beside the candidate buffers (V <= ~30 k): one workgroup per CU then
-        const bool img = refine_lds_bytes(V, 1) <= (size_t)160 * 1024;
-        const size_t rlds = refine_lds_bytes(V, img ? 1 : 0);
-        const int rgrid = std::min(B, idx->cu_count * (img ? 1 : 2));
-        void (*rk)(RefineArgs) = idx->store_dtype == VS_F32 ? (img ? refine_topk_kernel<VM_F32, 1> : refine_topk_kernel<VM_F32, 0>)
-                               : idx->store_dtype == VS_F16 ? (img ? refine_topk_kernel<VM_F16, 1> : refine_topk_kernel<VM_F16, 0>)
-                                                            : (img ? refine_topk_kernel<VM_BIN, 1> : refine_topk_kernel<VM_BIN, 0>);
-        VS_HIP(hipFuncSetAttribute((const void*)rk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));
-        hipLaunchKernelGGL(rk, dim3(rgrid), dim3(kScanThreads), rlds, s, r);
-        VS_HIP(hipGetLastError());
-    }
-    VS_STAGE("refine", s);
-    // 4. flagged queries (too dense for a tile, or unproven; normally none): exact one-query scan of the CSR packets + merge
-    {
-        ProfScope prof("exact_fallback", s);
-        hipLaunchKernelGGL(fb_plan_kernel<0>, dim3(1), dim3(kScanThreads), 0, s, flags, B, fb_tiles, fb_n);
-        ScanArgs sa{};
-        sa.pk_ptr = idx->pk_ptr.as<uint32_t>();
-        sa.cols = idx->cols.as<uint4>();
-        sa.vals = idx->vals.p;
-        sa.q = dq;
-        sa.n_rows = idx->n_rows;
-        sa.n_cols = V;
-        sa.B = B;
-        sa.k = k;
-        sa.nchunk = nchunk_fb;
-        sa.rows_per_chunk = ceil_div64(idx->n_rows, nchunk_fb);
-        sa.cand = a.cand;
-        const size_t slds = scan_lds_bytes(V);
-        void (*ek)(ScanArgs, const int2*, const int32_t*) = idx->store_dtype == VS_NONE  ? exact_scan_topk_kernel<VM_BIN>
-                                                            : idx->store_dtype == VS_F16 ? exact_scan_topk_kernel<VM_F16> : exact_scan_topk_kernel<VM_F32>;
-        VS_HIP(hipFuncSetAttribute((const void*)ek, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds));
-        hipLaunchKernelGGL(ek, dim3(idx->cu_count), dim3(kScanThreads), slds, s, sa, (const int2*)fb_tiles, (const int32_t*)fb_n);
-        MergeArgs m{};
-        m.cand = a.cand;
-        m.n_cand = (int64_t)nchunk_fb * k;
-        m.B = B;
-        m.k = k;
-        m.id_offset = id_offset;
-        m.out_ids = d_ids;
-        m.out_scores = d_scores;
-        m.out_ld = out_ld;
-        m.col0 = 0;
-        m.run_len = k;
-        m.sel = fb_tiles;
-        m.sel_n = fb_n;
-        hipLaunchKernelGGL(merge_topk_kernel<0>, dim3(std::min(B, idx->cu_count)), dim3(kScanThreads), 0, s, m);
-        VS_HIP(hipGetLastError());
-    }
-    VS_STAGE("fallback", s);
-    idx->last_flags = flags;
-    idx->last_flags_n = B;
-    *done = true;
-    return VS_OK;
-}
-
-// Multi-query pass (Qt = kQT).  Returns VS_OK and sets *done = false when the batch does not qualify
-// (a query denser than the LDS weight capacity): the caller then takes the dense-image path.
-// One pass delivers ranks [col0, col0 + k) of every query into columns col0.. of the [B, out_ld] outputs; `upper`
-// ([B], nullable) holds the exclusive upper-bound keys on entry and the k-th keys of this pass on return.
-int mq_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64_t id_offset, int64_t* d_ids, float* d_scores,
-              const ScanPlan& plan, hipStream_t s, bool* done, int32_t out_ld, int32_t col0, uint64_t* upper) {
-    *done = false;
-    // Filter and refine (bp_refine.h): the walk runs on int32 fixed-point sums and returns K' > k documents per query, the refine
-    // kernel re-scores them exactly and proves the top k; unproven queries go through the fp64 walk.  Without it (option
-    // "postings_filter" = 0, "search after" passes, k beyond the candidate buffers) every tile takes the fp64 walk.
-    if (bp_filter_ok(idx, k, col0, upper)) return bp_filter_search(idx, dq, B, k, id_offset, d_ids, d_scores, plan, s, done, out_ld);
-    const bool filter_only = idx->bp_quant || idx->bp_quad || idx->store_dtype == VS_NONE || idx->bp_n_head > 0;    // lossy / binary records, quad chunks, dense strips: the filter only
-    const bool use_bp = idx->bp_ready && !filter_only;                         // the fp64 walk over exact records
-    const int qt_plan = use_bp ? kBpExactQT : kQT;
-    const int bp_cap = kBpEntCap / 2;
-    const int vals_cap = use_bp ? std::min(mq_vals_cap(idx), bp_cap) : mq_vals_cap(idx);     // entries (non-zeros) one tile may hold
-    if (vals_cap <= 0 || k > (use_bp ? kBpMaxK : kMaxKMq)) return VS_OK;     // (callers split larger k into passes)
-    const int V = idx->n_cols;
-    // 1. sparsify the batch: counts -> (qptr, tiles, plan) -> (qcols, qvals)
-    const size_t off_counts = 0, off_qptr = off_counts + (size_t)B * 8, off_plan = off_qptr + (size_t)(B + 1) * 8,
-                 off_tiles = off_plan + 64, off_freq = off_tiles + (((size_t)B * sizeof(int2) + 15) & ~(size_t)15);
-    VS_TRY(idx->ws_mq_meta.reserve(off_freq + (size_t)(V + 4) * 4 + 8));
-    char* meta = idx->ws_mq_meta.as<char>();
-    int64_t* counts = (int64_t*)(meta + off_counts);
-    int64_t* qptr = (int64_t*)(meta + off_qptr);
-    int64_t* dplan = (int64_t*)(meta + off_plan);
-    int2* tiles = (int2*)(meta + off_tiles);
-    uint32_t* colfreq = (uint32_t*)(meta + off_freq);
-    VS_HIP(hipMemsetAsync(colfreq, 0, (size_t)(V + 4) * 4 + 8, s));          // counts + the 64-bit overlap sum behind them
-    hipLaunchKernelGGL(count_nz_kernel<0>, dim3(std::min(B, 2048)), dim3(kSpThreads), 0, s, dq, (int64_t)V, B, V, counts);
-    hipLaunchKernelGGL(mq_colfreq_kernel<0>, dim3(std::min(B, 2048)), dim3(kSpThreads), 0, s, dq, (int64_t)V, B, V, colfreq);
-    hipLaunchKernelGGL(mq_plan_kernel<0>, dim3(1), dim3(64), 0, s, counts, B, qt_plan, vals_cap, qptr, tiles, dplan, colfreq, V);
-    VS_HIP(hipGetLastError());
-    if (use_bp && idx->bp_df.p)
-        hipLaunchKernelGGL(bp_walk_kernel<0>, dim3(1), dim3(kScanThreads), 0, s, colfreq, idx->bp_df.as<unsigned long long>(),
-                           idx->bp_df.as<unsigned long long>() + V, V, dplan + 4);
-    int64_t hplan[6] = {0, 0, 0, 0, 0, 0};
-    VS_HIP(hipMemcpyAsync(hplan, dplan, sizeof(hplan), hipMemcpyDeviceToHost, s));
-    VS_HIP(hipStreamSynchronize(s));
-    if (hplan[1] > vals_cap) return VS_OK;                       // some query is too dense for the tile tables
-    const int n_tiles = (int)hplan[0];
-    const int64_t qnnz = hplan[2];
-    VS_TRY(idx->ws_mq_q.reserve(std::max<size_t>((size_t)qnnz * 8, 16)));
-    int32_t* qcols = idx->ws_mq_q.as<int32_t>();
-    float* qvals = reinterpret_cast<float*>(qcols + qnnz);
-    hipLaunchKernelGGL(fill_csr_kernel<0>, dim3(std::min(B, 2048)), dim3(kSpThreads), 0, s, dq, (int64_t)V, B, V, qptr, qcols, qvals, qnnz);
-    VS_HIP(hipGetLastError());
-    VS_STAGE("sparsify", s);
-    if (debug_sync_on()) fprintf(stderr, "[vsearch_hip] plan: tiles %d qnnz %lld max %lld cap %d\n", n_tiles, (long long)qnnz, (long long)hplan[1], vals_cap);
-    // 2. scan.  Work items = (tile, row chunk)
-    int nchunk = choose_chunks(idx, n_tiles, plan.nchunk);
-    if (use_bp) {
-        // blocked postings: chunks are runs of blocks
-        const int64_t n_blocks = ceil_div64(idx->n_rows, idx->bp_rows);
-        nchunk = (int)std::min<int64_t>(nchunk, n_blocks);
-        nchunk = bp_choose_chunks(idx, n_tiles, n_blocks, plan.nchunk);
-        const int64_t blocks_per_chunk = ceil_div64(n_blocks, nchunk);
-        const int64_t items = (int64_t)n_tiles * nchunk;
-        const int grid = (int)std::min<int64_t>(items, idx->cu_count);
-        VS_TRY(idx->ws_mq_cand.reserve((size_t)idx->cu_count * kQT * kBpCap * 8));
-        VS_TRY(idx->ws_cand.reserve((size_t)B * nchunk * k * 8));
-        const int RS = bp_rec_bytes(bp_record_vm(idx));
-        BpArgs a{};
-        a.rows = idx->bp_rows;
-        a.dir = idx->bp_dir.as<uint32_t>();
-        a.al_shift = idx->bp_al_shift;
-    a.al_shift = idx->bp_al_shift;
-        a.base = idx->bp_base.as<unsigned long long>();
-        a.rec = idx->bp_rec.as<char>();
-        a.n_rows = idx->n_rows;
-        a.n_cols = V;
-        a.k = k;
-        a.nchunk = nchunk;
-        a.blocks_per_chunk = blocks_per_chunk;
-        a.qptr = qptr;
-        a.qcols = qcols;
-        a.qvals = qvals;
-        a.tiles = tiles;
-        a.n_tiles = n_tiles;
-        a.ent_cap = vals_cap;
-        a.cand = idx->ws_cand.as<uint64_t>();
-        a.gcand = idx->ws_mq_cand.as<uint64_t>();
-        a.upper = col0 > 0 ? upper : nullptr;
-        // what this launch has to read: the records of the batch's (query, column) entries + one directory pair per entry and block
-        idx->last_scan_bytes += hplan[4] * RS + qnnz * n_blocks * 4;
-        idx->last_walk_postings += hplan[5];
-        idx->last_path = 2;
-        ProfScope prof("csr_scan_topk", s);
-        VS_TRY((launch_bp_walk<kBpExactQT, AM_F64>(idx, a, grid, vals_cap, s)));
-        VS_STAGE("fp64 walk", s);
-    } else {
-    const int64_t rows_per_chunk = ceil_div64(idx->n_rows, nchunk);
-    const int64_t items = (int64_t)n_tiles * nchunk;
-    const int grid = (int)std::min<int64_t>(items, idx->cu_count);
-    VS_TRY(idx->ws_mq_cand.reserve((size_t)grid * kQT * kMqCap * 8));
-    VS_TRY(idx->ws_cand.reserve((size_t)B * nchunk * k * 8));
-    MqArgs a{};
-    a.pk_ptr = idx->pk_ptr.as<uint32_t>();
-    a.cols = idx->cols.as<uint4>();
-    a.vals = idx->vals.p;
-    a.n_rows = idx->n_rows;
-    a.n_cols = V;
-    a.k = k;
-    a.nchunk = nchunk;
-    a.rows_per_chunk = rows_per_chunk;
-    a.qptr = qptr;
-    a.qcols = qcols;
-    a.qvals = qvals;
-    a.tiles = tiles;
-    a.n_tiles = n_tiles;
-    a.vals_cap = vals_cap;
-    a.cand = idx->ws_cand.as<uint64_t>();
-    a.gcand = idx->ws_mq_cand.as<uint64_t>();
-    a.upper = col0 > 0 ? upper : nullptr;
-    const size_t lds = mq_fixed_lds_bytes<kQT>(V, mq_acc_rows(idx)) + (size_t)vals_cap * 4;
-    idx->last_scan_bytes += (int64_t)n_tiles * csr_bytes_per_pass(idx);
-    idx->last_path = 1;
-    {
-        ProfScope prof("csr_scan_topk", s);
-        // packets per lane per trip: enough to cover an average row in one trip, at most 3
-        const double ppr = idx->n_rows > 0 ? (double)idx->n_packets / (double)idx->n_rows : 1.0;
-        const int u = std::max(1, std::min(3, (int)((ppr + mq_lanes(idx) - 1) / mq_lanes(idx))));
-        // expected number of columns two queries of the batch share; uniform 776-nnz queries: ~20
-        const double overlap = B > 1 ? (double)hplan[3] / ((double)B * (double)(B - 1)) : 0.0;
-        const bool shared_cols = idx->mq_variant >= 0 ? idx->mq_variant == 1 : overlap > kMqSharedOverlap;
-        int rc = idx->store_dtype == VS_F32 ? launch_mq_vm<VM_F32>(mq_lanes(idx), u, shared_cols, a, grid, lds, s)
-               : idx->store_dtype == VS_F16 ? launch_mq_vm<VM_F16>(mq_lanes(idx), u, shared_cols, a, grid, lds, s)
-                                            : launch_mq_vm<VM_BIN>(mq_lanes(idx), u, shared_cols, a, grid, lds, s);
-        VS_TRY(rc);
-    }
-    }
-    // 3. merge chunks
-    MergeArgs m{};
-    m.cand = idx->ws_cand.as<uint64_t>();
-    m.n_cand = (int64_t)nchunk * k;
-    m.B = B;
-    m.k = k;
-    m.id_offset = id_offset;
-    m.out_ids = d_ids;
-    m.out_scores = d_scores;
-    m.out_ld = out_ld;
-    m.col0 = col0;
-    m.upper_out = upper;
-    m.run_len = k;                                 // every chunk's list is sorted
-    {
-        ProfScope prof("merge_topk", s);
-        hipLaunchKernelGGL(merge_topk_kernel<0>, dim3(std::min(B, idx->cu_count * 2)), dim3(kScanThreads), 0, s, m);
-    }
-    VS_HIP(hipGetLastError());
-    *done = true;
-    return VS_OK;
-}
-
-}  // namespace
+// (the multi-query scan and its launches: mq_search.hip)
 
 int vs_csr_prepare(vs_index* idx, hipStream_t s) { return csr_prepare_impl(idx, s); }
 
