@@ -198,6 +198,8 @@ __global__ __launch_bounds__(kSpThreads) void mask_rows_kernel(MaskArgs a) {
     }
 }
 
+#include "mask_rows_fast.h"
+
 int check_device(int device) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
@@ -221,8 +223,11 @@ int run_mask(MaskArgs a, const float* x_in, float* emb_io, const int64_t* ids, u
     if (lds > 160 * 1024) return fail(VS_EUNSUPPORTED, "V = %d needs %zu B of LDS (> 160 KiB)", a.V, lds);
     DevBuf st_x, st_ids, st_mask;
     DevBuf& flags = device_scratch(device, 0);
-    VS_TRY(flags.reserve(4));
+    VS_TRY(flags.reserve(128));
     if (ids) VS_HIP(hipMemsetAsync(flags.p, 0, 4, s));
+#ifdef MR_TIMING
+    VS_HIP(hipMemsetAsync(flags.p, 0, 128, s));
+#endif
     a.flags = flags.as<int>();
     const size_t row_span = a.B > 0 ? ((size_t)(a.B - 1) * a.ld + a.V) * 4 : 0;
     const float* src = emb_io ? emb_io : x_in;
@@ -243,9 +248,32 @@ int run_mask(MaskArgs a, const float* x_in, float* emb_io, const int64_t* ids, u
         if (m_host) { VS_TRY(st_mask.alloc((size_t)a.B * a.V)); a.mask = st_mask.as<uint8_t>(); }
         else a.mask = mask_out;
     }
-    VS_HIP(hipFuncSetAttribute((const void*)mask_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(mask_rows_kernel, dim3(std::min(a.B, 1024)), dim3(kSpThreads), lds, s, a);
+    ProfScope prof("mask_rows", s);
+    if (!a.bow && a.topk > 0 && a.x && a.V <= kMrCols) {
+        // the encoder's case (mask_rows_fast.h): persistent workgroups, the next row's loads in flight through a row's select
+        void (*kern)(MaskArgs) = a.V <= 4 * kMrStep ? mask_rows_fast_kernel<4> : a.V <= 8 * kMrStep ? mask_rows_fast_kernel<8> : mask_rows_fast_kernel<16>;
+        int cus = 0;
+        VS_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+        VS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mask_fast_lds_bytes()));
+        hipLaunchKernelGGL(kern, dim3(std::max(1, std::min(a.B, cus))), dim3(kMrThreads), mask_fast_lds_bytes(), s, a);
+    } else {
+        VS_HIP(hipFuncSetAttribute((const void*)mask_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(mask_rows_kernel, dim3(std::min(a.B, 1024)), dim3(kSpThreads), lds, s, a);
+    }
     VS_HIP(hipGetLastError());
+#ifdef MR_TIMING
+    {
+        unsigned long long h[16];
+        VS_HIP(hipMemcpyAsync(h, flags.p, 128, hipMemcpyDeviceToHost, s));
+        VS_HIP(hipStreamSynchronize(s));
+        static int calls = 0;
+        if (++calls == 5) {
+            const double rows = (double)a.B;
+            fprintf(stderr, "[vsearch_hip] mask stage, cycles per row (wave 0): barrier+wait %.0f, pack %.0f, issue+clear+lex %.0f, pass A %.0f, pick A %.0f, pass B + pick B %.0f, candidates %.0f, write %.0f\n",
+                    h[1] / rows, h[2] / rows, h[3] / rows, h[4] / rows, h[5] / rows, h[6] / rows, h[7] / rows, h[8] / rows);
+        }
+    }
+#endif
     if (emb_io && x_host) VS_HIP(hipMemcpyAsync(emb_io, st_x.p, row_span, hipMemcpyDeviceToHost, s));
     if (m_host) VS_HIP(hipMemcpyAsync(mask_out, st_mask.p, (size_t)a.B * a.V, hipMemcpyDeviceToHost, s));
     if (ids) {                     // a bad token id must surface as an error (the reference's scatter_ asserts on it)
@@ -328,6 +356,7 @@ extern "C" int vs_rerank_scores(const void* p_emb, int p_dtype, int64_t ldp, int
     VS_TRY(check_device(device));
     hipStream_t s = (hipStream_t)stream;
     if (n_rows > 0) {
+        ProfScope prof("rerank", s);
         const unsigned grid = (unsigned)std::min<int64_t>(ceil_div64(n_rows, 4), 8192);
         if (p_dtype == VS_F32)
             hipLaunchKernelGGL(rerank_scores_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)p_emb, ldp, n_rows, row0, q, ldq, k, n_cols, scores);
@@ -346,6 +375,7 @@ extern "C" int vs_rerank_topk(const float* scores, const int64_t* hit_ids, int32
         return fail(VS_EINVAL, "vs_rerank_topk takes device pointers");
     VS_TRY(check_device(device));
     hipStream_t s = (hipStream_t)stream;
+    ProfScope prof("rerank", s);
     hipLaunchKernelGGL(rerank_topk_kernel, dim3((unsigned)std::min(B, 4096)), dim3(kSpThreads), 0, s, scores, hit_ids, B, k, out_ids, out_scores);
     VS_HIP(hipGetLastError());
     if (!stream) VS_HIP(hipStreamSynchronize(s));
@@ -430,6 +460,7 @@ extern "C" int vs_dense_to_csr(const float* x, int32_t B, int32_t V, int64_t ld,
     const bool rp_dev = is_device_ptr(rowptr);
     if (!cols) {
         // sizing call: rowptr out
+        ProfScope prof("dense_to_csr", s);
         hipLaunchKernelGGL(count_nz_kernel<0>, dim3(std::min(B, 2048)), dim3(kSpThreads), 0, s, (const float*)dx, ld, B, V, counts.as<int64_t>());
         int64_t* rp_out = rp_dev ? rowptr : d_rp.as<int64_t>();
         hipLaunchKernelGGL(scan_counts_kernel<0>, dim3(1), dim3(kSpThreads), 0, s, counts.as<int64_t>(), B, rp_out);
@@ -457,7 +488,10 @@ extern "C" int vs_dense_to_csr(const float* x, int32_t B, int32_t V, int64_t ld,
         dc = st_c.as<int32_t>();
         dv = st_v.as<float>();
     }
-    hipLaunchKernelGGL(fill_csr_kernel<0>, dim3(std::min(B, 2048)), dim3(kSpThreads), 0, s, (const float*)dx, ld, B, V, rp_in, dc, dv, cap);
+    {
+        ProfScope prof("dense_to_csr", s);
+        hipLaunchKernelGGL(fill_csr_kernel<0>, dim3(std::min(B, 2048)), dim3(kSpThreads), 0, s, (const float*)dx, ld, B, V, rp_in, dc, dv, cap);
+    }
     VS_HIP(hipGetLastError());
     if (o_host && cap > 0) {
         VS_HIP(hipMemcpyAsync(cols, dc, (size_t)cap * 4, hipMemcpyDeviceToHost, s));
