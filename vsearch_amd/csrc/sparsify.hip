@@ -291,6 +291,9 @@ int run_mask(MaskArgs a, const float* x_in, float* emb_io, const int64_t* ids, u
 // One wave per re-embedded passage; fp32 products summed in fp64 (the library's exact numerics); the passage rows are ~97 %
 // zeros, the query row comes from L2.  `row0` = index (b * k + j) of the chunk's first row: the re-embedding can be streamed in
 // batches, the dense [B * k, V] tensor of the reference never has to exist.
+// A lane takes 4 consecutive columns per step (16-byte loads of the fp32 passage row and of the query row; a row's first element only
+// has to be 4-byte aligned) and the steps are unrolled 4 deep: 4 KB of the row in flight per wave, where the one-dword-a-lane loop
+// this replaces kept 256 B and moved 2.4 TB/s.  A zero passage element contributes nothing whatever the query holds (0 * inf).
 template <class T>
 __global__ __launch_bounds__(256) void rerank_scores_kernel(const T* p, int64_t ldp, int64_t n_rows, int64_t row0, const float* q, int64_t ldq, int32_t k,
                                                             int32_t V, float* scores) {
@@ -300,11 +303,32 @@ __global__ __launch_bounds__(256) void rerank_scores_kernel(const T* p, int64_t 
         const T* pr = p + (size_t)r * ldp;
         const float* qr = q + (size_t)(g / k) * ldq;
         double sum = 0.0;
-        for (int c = lane; c < V; c += 64) {
-            float v;
-            if constexpr (sizeof(T) == 2) v = __half2float(pr[c]);
-            else v = pr[c];
-            if (v != 0.f) sum += (double)(v * qr[c]);
+        auto add = [&](float v, float w) { sum += (double)(v != 0.f ? v * w : 0.f); };
+        int c = lane * 4;
+        if constexpr (sizeof(T) == 4) {
+            constexpr int U = 4;
+            for (; c + (U - 1) * 256 + 4 <= V; c += U * 256) {
+                float4 pv[U], qv[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    __builtin_memcpy(&pv[u], pr + c + u * 256, 16);            // (dword-aligned 16-byte loads)
+                    __builtin_memcpy(&qv[u], qr + c + u * 256, 16);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) { add(pv[u].x, qv[u].x); add(pv[u].y, qv[u].y); add(pv[u].z, qv[u].z); add(pv[u].w, qv[u].w); }
+            }
+            for (; c + 4 <= V; c += 256) {
+                float4 pv, qv;
+                __builtin_memcpy(&pv, pr + c, 16);
+                __builtin_memcpy(&qv, qr + c, 16);
+                add(pv.x, qv.x); add(pv.y, qv.y); add(pv.z, qv.z); add(pv.w, qv.w);
+            }
+        }
+        // fp16 rows, and the last V % 4 columns: element by element
+        if constexpr (sizeof(T) == 2) {
+            for (int e = lane; e < V; e += 64) add(__half2float(pr[e]), qr[e]);
+        } else {
+            for (int e = c; e < V && e < c + 4; ++e) add(pr[e], qr[e]);       // (only the lane whose 4 columns straddle V gets here with e < V)
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
