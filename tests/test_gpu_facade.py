@@ -399,6 +399,35 @@ def test_fused_head_project_pool(golden, B, L, H, vocab):
         np.testing.assert_allclose(got.cpu().numpy(), want_golden, rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("Vv", [29523, 8000, 33000], ids=["vdr-vocabulary", "two-load-rows", "beyond-the-register-kernel"])
+def test_embed_mask_signed_and_special_values(Vv):
+    """The mask stage on rows of continuous values with negatives, both zeros and infinities (vdr.py:152-169: emb *= mask, so an
+    unselected -3.5 becomes -0.0 and an unselected inf a NaN): mask_rows_fast_kernel (V <= 32 Ki: key halves in registers / LDS,
+    elements rebuilt from them) and mask_rows_kernel (beyond) against the oracle, bit patterns included; 4 rows per workgroup and more
+    rows than workgroups exercise the prefetch of the next row."""
+    rng = np.random.default_rng(Vv)
+    B, L, shift = 1030, 24, 999
+    vocab = Vv + shift
+    emb = (rng.standard_normal((B, Vv)) * 3).astype(np.float32)
+    emb[:, ::7] = np.abs(emb[:, ::7])
+    emb[3, :50] = 0.0
+    emb[3, 50:90] = -0.0
+    emb[5, 10] = np.inf
+    emb[5, 11] = -np.inf
+    emb[6, :] = -np.abs(emb[6, :])                                       # a row of negatives only
+    emb[7, :] = 0.25                                                     # one value: every tie goes to the lowest columns
+    ids = rng.integers(0, vocab, size=(B, L)).astype(np.int64)
+    for topk, lex in ((768, True), (1, False), (Vv, False), (Vv // 2, True)):
+        want = oracle.embed_mask(emb, ids, vocab, shift, topk=topk, activate_lexical=lex)
+        got = torch.from_numpy(emb).cuda()
+        sp.apply_embed_mask_(got, torch.from_numpy(ids), vocab, shift, topk, lex)
+        got = got.cpu().numpy()
+        same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+        assert same.all(), (Vv, topk, lex, np.argwhere(~same)[:5])
+    k = 777
+    assert (sp.build_topk_mask(torch.from_numpy(emb), k).numpy() == oracle.topk_mask(emb, k)).all()
+
+
 @pytest.mark.parametrize("seed", range(5))
 def test_random_embed_mask_against_oracle(seed):
     """Randomised mask stage (vdr.py:152-169): heavy ties (few distinct values), odd vocab sizes, every flag combination."""
