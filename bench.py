@@ -35,7 +35,11 @@ BATCH = 1024
 K = 100
 INDEX_SEED, QUERY_SEED = 0, 1
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-LDS_ADD_U32_PEAK = 5.0e12    # ds_add_u32 at random addresses, all 256 CUs (profiles/r02_lds_scatter.txt)
+LDS_ADD_U32_PEAK = 7.8e12    # ds_add_u32, <= 2 lanes per bank (what the arranged quad chunks are built for): 12.83 adds / clk / CU x 256 CUs x 2.38 GHz
+                             # (profiles/r04_conflicts.txt, tools/microbench/lds_conflicts.hip)
+LDS_ADD_U32_RANDOM = 5.0e12  # the same at random addresses (profiles/r02_lds_scatter.txt): what the list walks of records see
+L2_PEAK_GBS = 34500.0        # aggregate L2 -> L1 bandwidth, 256 CUs x 64 B / clk (MI355X_MICROARCH.md): the bound of a walk whose bytes are L2-served
+SHADER_CLOCK_HZ = 2.4e9      # (cycles-per-chunk figures are quoted at this clock)
 MFMA_F32_PEAK_TF = 157.3     # fp32-input MFMA = the fp32 vector peak (MI355X_MICROARCH.md)
 WALK_KERNEL = {-1: "csr_scan_topk_mq", 0: "bp_walk_topk", 4: "bp_quad_topk", 5: "bp_bin_topk"}     # vs_index_info_t.postings_walk -> the filter's kernel
 
@@ -196,6 +200,40 @@ def cpu_baseline(sample_docs, device, kind=0):
             "sample_qps": qps_sample, "host_cpus": os.cpu_count()}
 
 
+# (VS_BENCH_LEGS name, key in `secondary`, (docs, nnz per doc, synth kind, store dtype, query value law, steps, keyword arguments))
+SECONDARY_LEGS = (
+    ("C3", "C3_1m_sparse", (1_000_000, NNZ_DOC, 0, 0, 0, 10, {})),
+    ("C5", "C5_bot_21m", (N_DOCS, 86, 1, -1, 1, 5, {"exact": True})),                        # SVDR bag-of-token index, dyadic query weights: bit-exact
+    ("zipf", "zipf_21m", (N_DOCS, NNZ_DOC, 2, 0, 0, 3, {"columns": "zipf"})),
+    ("fp16", "fp16_21m", (N_DOCS, NNZ_DOC, 0, 1, 0, 3, {})),                                 # the reference's load default (index.py:135 fp16=True)
+)
+
+
+def summarise(line):
+    """{leg: [ms per step, queries/sec (or null), roofline frac, parity ok]} of the headline and every secondary leg, <= 1 500 characters,
+    the LAST key of the JSON line (the driver keeps known keys + the line's tail)."""
+    def ok(p):
+        if not p:
+            return None
+        if "ok" in p:
+            return bool(p["ok"])
+        if p.get("ids_bit_exact") is not None:
+            return bool(p["ids_bit_exact"])
+        return bool(p.get("recall_at_100_vs_oracle", 0) >= 0.999 and p.get("max_rel_score_err", 1) <= 1e-4)
+    r3 = lambda x: None if x is None else float(f"{x:.4g}")
+    out = {"_": "leg: [ms, q/s, roofline.frac, parity ok]", "headline": [r3(line["ms_per_step"]), r3(line["value"]), r3(line["roofline"]["frac"]), ok(line.get("parity"))]}
+    short = {"C2_dense_100k": "C2", "C3_1m_sparse": "C3", "C5_bot_21m": "C5", "zipf_21m": "zipf", "fp16_21m": "fp16", "facade": "facade", "shard_group_8_on_one_gpu": "shards8",
+             "embed_mask_B1024": "mask", "dense_to_csr_B1024": "to_csr", "embed_to_csr_B1024": "mask_csr", "head_project_pool_64x256": "head", "rerank_1024x100": "rerank"}
+    for key, rec in (line.get("secondary") or {}).items():
+        if key not in short or not isinstance(rec, dict) or "error" in rec:
+            continue
+        ms = rec.get("ms_per_step", rec.get("kernel_ms", rec.get("ms")))
+        out[short[key]] = [r3(ms), r3(rec.get("queries_per_sec")), r3((rec.get("roofline") or {}).get("frac")), ok(rec.get("parity"))]
+    if (line.get("secondary") or {}).get("errors"):
+        out["errors"] = len(line["secondary"]["errors"])
+    return out
+
+
 def _timed(fn, steps, warmup=1):
     for _ in range(warmup):
         fn()
@@ -205,6 +243,87 @@ def _timed(fn, steps, warmup=1):
         fn()
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / steps
+
+
+def pmc_leg(name, batch):
+    """HBM bytes per launch of a secondary leg's scan kernel from the committed rocprofv3 --pmc passes (profiles/pmc_summary.json ->
+    "legs"), only when taken on this kernel build and batch size; else None."""
+    try:
+        rec = json.load(open(os.path.join(REPO, "profiles", "pmc_summary.json"))).get("legs", {}).get(name)
+        if rec and rec.get("source_hash") == kernel_source_hash() and rec.get("queries_per_launch") == batch and rec.get("hbm_bytes_per_launch"):
+            return rec
+    except Exception:
+        pass
+    return None
+
+
+def run_leg(name, docs, nnz, kind, store, val_law, steps, B, k, local_rank, device, exact=False, columns="uniform", parity=True):
+    """One secondary configuration: builds the synthetic index, times `steps` searches of 1024-query batches, returns the record
+    (ms, q/s, scan kernel time, `roofline`, oracle parity of a prefix).  The `roofline` is traffic-based when profiles/pmc_summary.json
+    holds FETCH_SIZE / WRITE_SIZE passes of this leg on this kernel build; otherwise the kernel's algorithmic bytes are priced
+    against the L2 -> L1 aggregate (they are L2 / Infinity-Cache served: never against the HBM peak)."""
+    from vsearch_amd import _native as nat
+    from vsearch_amd import synth
+    from vsearch_amd.device_index import DeviceIndex, Profile
+    t0 = time.perf_counter()
+    idx = DeviceIndex.synthetic(INDEX_SEED, 0, docs, V, nnz, kind, 0, store, local_rank)
+    qkind = 0 if kind == synth.KIND_BOT else kind
+    qs = []
+    for i in range(2):
+        gen = DeviceIndex.synthetic(QUERY_SEED, i * B, B, V, NNZ_Q, qkind, val_law, 0, local_rank)
+        ip, ix, d = gen.export_csr()
+        gen.close()
+        q = torch.zeros((B, V), dtype=torch.float32, device=device)
+        q[torch.from_numpy(np.repeat(np.arange(B), np.diff(ip))).to(device), torch.from_numpy(ix).to(device)] = torch.from_numpy(d).to(device)
+        qs.append(q)
+    idx.search(qs[0][:8], k)
+    torch.cuda.synchronize()
+    build_s = time.perf_counter() - t0
+    it = [0]
+
+    def step():
+        idx.search(qs[it[0] % 2], k)
+        it[0] += 1
+    Profile.enable(True)
+    Profile.reset()
+    dt = _timed(step, steps)
+    Profile.enable(False)
+    scan_ms, launches = Profile.read("csr_scan_topk")
+    pre_ms, _ = Profile.read("head_gemm")
+    info = idx.info()
+    launch_s = scan_ms / 1e3 / max(1, launches)                      # the scan launches of one search (a head-column corpus: one per half batch)
+    per_search_s = scan_ms / 1e3 / max(1, steps + 1)
+    algo = info.last_scan_bytes / per_search_s / 1e9 if per_search_s > 0 else 0.0
+    kernel = WALK_KERNEL.get(info.postings_walk, "?")
+    pmc = pmc_leg(name, B)
+    one_pass = info.bytes_per_pass / (HBM_PEAK_GBS * 1e9)
+    extra = dict(one_pass_lower_bound_ms=one_pass * 1e3, frac_of_one_pass_lower_bound=one_pass / per_search_s if per_search_s > 0 else None,
+                 algorithmic_GBps=algo, kernel=kernel)
+    if info.last_path >= 2 and info.head_columns == 0 and per_search_s > 0:
+        # (with head columns the strips' multiply-adds run on the matrix cores: not LDS adds)
+        peak = LDS_ADD_U32_PEAK if info.postings_walk == 4 else LDS_ADD_U32_RANDOM
+        extra["frac_of_lds_add_peak"] = info.last_walk_postings / per_search_s / peak
+        extra["lds_add_peak_per_s"] = peak
+    if pmc:
+        hbm = pmc["hbm_bytes_per_launch"] / per_search_s / 1e9
+        rl = roof("hbm", hbm, HBM_PEAK_GBS, "GB/s", traffic=pmc["hbm_bytes_per_launch"],
+                  achieved_is="HBM traffic (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this leg, profiles/pmc_summary.json) / scan kernel time",
+                  traffic_source=pmc.get("source"), **extra)
+    else:
+        rl = roof("hbm", algo, L2_PEAK_GBS, "GB/s", traffic=None, bound_note="L2: the walk's bytes are L2 / Infinity-Cache served; no PMC pass of this leg on this kernel "
+                  "build, so the algorithmic bytes are priced against the L2 -> L1 aggregate, not the HBM peak",
+                  achieved_is="algorithmic bytes of the scan kernel / its time", **extra)
+    rec = {"docs": docs, "nnz_per_doc": nnz, "columns": columns, "store": {0: "fp32", 1: "fp16", -1: "binary"}.get(store, str(store)), "batch": B, "k": k, "steps": steps,
+           "ms_per_step": dt * 1e3, "queries_per_sec": B / dt,
+           "scan_path": info.last_path, "kernel": kernel, "scan_kernel_ms": per_search_s * 1e3, "scan_launches_per_search": launches / max(1, steps + 1),
+           "head_gemm_ms": pre_ms / max(1, steps + 1) if pre_ms else None,
+           "fallback_queries": info.last_fallbacks, "head_columns": info.head_columns, "postings_copy_bytes": info.aux_bytes,
+           "walk_adds_per_s": (info.last_walk_postings / per_search_s) if per_search_s > 0 and info.last_path >= 2 else None,
+           "roofline": rl, "index_build_s": round(build_s, 2)}
+    idx.close()
+    if parity:
+        rec["parity"] = parity_check(local_rank, kind, nnz, store, val_law, expect_path=info.last_path, n=80_000 if kind == synth.KIND_BOT else 20_000, exact=exact)
+    return rec
 
 
 def secondary(index, batches, args, local_rank, device, headline_s):
@@ -237,50 +356,6 @@ def secondary(index, batches, args, local_rank, device, headline_s):
             lat[f"B={b}_ms"] = _timed(lambda: index.search(batches[0][:b], args.k), 20, 3) * 1e3
         out["latency_21m"] = lat
     index.close()
-
-    def run(name, docs, nnz, kind, store, val_law, steps, exact=False, columns="uniform"):
-        t0 = time.perf_counter()
-        idx = DeviceIndex.synthetic(INDEX_SEED, 0, docs, V, nnz, kind, 0, store, local_rank)
-        qkind = 0 if kind == synth.KIND_BOT else kind
-        qs = []
-        for i in range(2):
-            gen = DeviceIndex.synthetic(QUERY_SEED, i * B, B, V, NNZ_Q, qkind, val_law, 0, local_rank)
-            ip, ix, d = gen.export_csr()
-            gen.close()
-            q = torch.zeros((B, V), dtype=torch.float32, device=device)
-            q[torch.from_numpy(np.repeat(np.arange(B), np.diff(ip))).to(device), torch.from_numpy(ix).to(device)] = torch.from_numpy(d).to(device)
-            qs.append(q)
-        idx.search(qs[0][:8], args.k)
-        torch.cuda.synchronize()
-        build_s = time.perf_counter() - t0
-        it = [0]
-
-        def step():
-            idx.search(qs[it[0] % 2], args.k)
-            it[0] += 1
-        Profile.enable(True)
-        Profile.reset()
-        dt = _timed(step, steps)
-        Profile.enable(False)
-        scan_ms, launches = Profile.read("csr_scan_topk")
-        info = idx.info()
-        launch_s = scan_ms / 1e3 / max(1, launches)                      # one scan launch per search
-        algo = info.last_scan_bytes / launch_s / 1e9 if launch_s > 0 else 0.0
-        rec = {"docs": docs, "nnz_per_doc": nnz, "columns": columns, "batch": B, "k": args.k, "steps": steps, "ms_per_step": dt * 1e3, "queries_per_sec": B / dt,
-               "scan_path": info.last_path, "kernel": WALK_KERNEL.get(info.postings_walk, "?"), "scan_kernel_ms": launch_s * 1e3,
-               "fallback_queries": info.last_fallbacks, "head_columns": info.head_columns,
-               "walk_adds_per_s": (info.last_walk_postings / launch_s) if launch_s > 0 and info.last_path >= 2 else None,
-               # HBM roofline on the kernel's ALGORITHMIC bytes (chunks / records of the batch's posting lists): on the postings paths
-               # most of them are served by L2 / Infinity Cache, so the fraction can exceed 1 and is not HBM utilisation; the second figure
-               # is the one-pass bound of SURVEY 8(d) (Qt = B: the index streamed once per batch at the HBM peak)
-               "roofline": roof("hbm", algo, HBM_PEAK_GBS, "GB/s", achieved_is="algorithmic bytes of the scan kernel / its time (L2 / Infinity-Cache served: not HBM utilisation)",
-                                one_pass_lower_bound_ms=info.bytes_per_pass / (HBM_PEAK_GBS * 1e9) * 1e3,
-                                frac_of_one_pass_lower_bound=info.bytes_per_pass / (HBM_PEAK_GBS * 1e9) / launch_s if launch_s > 0 else None,
-                                frac_of_lds_add_peak=(info.last_walk_postings / launch_s / LDS_ADD_U32_PEAK) if launch_s > 0 and info.last_path >= 2 else None),
-               "index_build_s": round(build_s, 2)}
-        idx.close()
-        rec["parity"] = parity_check(local_rank, kind, nnz, store, val_law, expect_path=info.last_path, n=80_000 if kind == synth.KIND_BOT else 20_000, exact=exact)
-        out[name] = rec
 
     # one process, 8 row shards of the same index on this one device (vs_shard_group_*: per-shard searches on their own streams, the
     # B * k pairs gathered and merged on the first shard's device): what the in-process sharding adds to 8 x the single-shard step
@@ -315,15 +390,13 @@ def secondary(index, batches, args, local_rank, device, headline_s):
         fs._drop_device()                                            # closes the group and the shards
     except Exception as e:                                       # (never lose the headline line to a secondary leg)
         out["shard_group_8_on_one_gpu"] = {"error": str(e)[:200]}
-    for name, leg in (("C3", lambda: run("C3_1m_sparse", 1_000_000, NNZ_DOC, 0, nat.VS_F32, 0, 10)),
-                      ("C5", lambda: run("C5_bot_21m", N_DOCS, 86, synth.KIND_BOT, nat.VS_NONE, synth.VAL_DYADIC, 5, exact=True)),
-                      ("zipf", lambda: run("zipf_21m", N_DOCS, NNZ_DOC, synth.KIND_SKEW, nat.VS_F32, 0, 3, columns="zipf"))):
+    for name, key, leg_args in SECONDARY_LEGS:
         if not want(name):
             continue
         try:
-            leg()
+            out[key] = run_leg(key, *leg_args[:6], B, args.k, local_rank, device, **leg_args[6])
         except Exception as e:
-            out.setdefault("errors", []).append(str(e)[:300])
+            out.setdefault("errors", []).append(f"{name}: {str(e)[:300]}")
     # ---- the rest of the path under the same clock: dense index (C2), sparsify kernels, fused encoder head, rerank
     def c2_dense():
         n, b = 100_000, 256
@@ -343,13 +416,29 @@ def secondary(index, batches, args, local_rank, device, headline_s):
         Profile.enable(False)
         gemm_ms, launches = Profile.read("dense_scores")
         flops = 2.0 * b * V * n
-        ref = (q @ mat.t()).topk(args.k)
-        rel = float(((ref.values - sc).abs() / ref.values).max().item())
-        same = float((ref.indices == ids).float().mean().item())
+        # parity against the CPU oracle, on a row sample: for 8 queries, every RETURNED row and 1 500 random rows are
+        # scored by oracle.dense_search (fp64 sums): the returned scores must be the oracle's (1e-4) and no sampled row may beat a query's
+        # k-th returned score unless it was returned
+        import oracle
+        nq_chk = 8
+        g_ids = ids[:nq_chk].cpu().numpy()
+        g_sc = sc[:nq_chk].cpu().numpy()
+        rows = np.unique(np.concatenate([g_ids.reshape(-1), np.random.default_rng(0).choice(n, 1500, replace=False)]))
+        sub = mat[torch.from_numpy(rows).to(device)].cpu().numpy()
+        o_ids, o_sc = oracle.dense_search(sub, q[:nq_chk].cpu().numpy(), sub.shape[0], acc64=True)
+        rel, beaten = 0.0, 0
+        for i in range(nq_chk):
+            score_of = dict(zip(rows[o_ids[i]].tolist(), o_sc[i].tolist()))
+            want = np.array([score_of[int(r)] for r in g_ids[i]], dtype=np.float64)
+            rel = max(rel, float(np.max(np.abs(want - g_sc[i]) / np.abs(want))))
+            kth = float(g_sc[i, -1])
+            better = rows[o_ids[i][o_sc[i] > kth * (1 + 1e-4)]]
+            beaten += int(np.setdiff1d(better, g_ids[i]).size)
         idx.close()
         out["C2_dense_100k"] = {"docs": n, "batch": b, "k": args.k, "ms_per_step": dt * 1e3, "queries_per_sec": b / dt, "kernel": "dense_scores_kernel (v_mfma_f32_32x32x2_f32)",
                                 "roofline": roof("mfma", flops / (dt * 1e12), MFMA_F32_PEAK_TF, "TFLOP/s", achieved_is="2 B V N flop / step time (dense kernels + select; fp32 in, fp32 accumulate)"),
-                                "parity": {"vs": "torch.matmul(q, P.t()).topk(k) on this GPU (index.py:91-92)", "max_rel_score_err": rel, "ids_equal_frac": same}}
+                                "parity": {"vs": "oracle.dense_search (CPU, fp64 sums) on the returned rows + 1 500 random rows, 8 queries", "max_rel_score_err": rel,
+                                           "sampled_rows_beating_kth_not_returned": beaten, "ok": bool(rel <= 1e-4 and beaten == 0)}}
 
     def kernel_ms(scope, fn, reps, warmup=2):
         """(per-call GPU time incl. the host gaps between calls, kernel time of the library's `scope` per call: hipEvents around the launches on their stream)"""
@@ -576,8 +665,8 @@ def main():
             "hbm_frac": hbm_frac, "hbm_GBps": (traffic / avg_launch_s / 1e9) if traffic else None, "traffic_source": traffic_src,
             "one_pass_lower_bound_ms": index_pass_bytes / (HBM_PEAK_GBS * 1e9) * 1e3,
             "frac_of_one_pass_lower_bound": index_pass_bytes / (HBM_PEAK_GBS * 1e9) / avg_launch_s,
-            "walk_adds_per_s": adds_per_s, "lds_add_u32_peak_per_s": LDS_ADD_U32_PEAK,
-            "frac_of_lds_add_peak": (adds_per_s / LDS_ADD_U32_PEAK) if adds_per_s else None,
+            "walk_adds_per_s": adds_per_s, "lds_add_u32_peak_per_s": LDS_ADD_U32_PEAK if info.postings_walk == 4 else LDS_ADD_U32_RANDOM,
+            "frac_of_lds_add_peak": (adds_per_s / (LDS_ADD_U32_PEAK if info.postings_walk == 4 else LDS_ADD_U32_RANDOM)) if adds_per_s else None,
             "csr_scan_equivalent_GBps": csr_equiv, "bytes_per_csr_pass": info.bytes_per_pass, "merge_ms_total": merge_ms,
             "refine_ms_total": refine_ms, "exact_fallback_ms_total": fb_ms, "fallback_queries_last_step": info.last_fallbacks,
             "note": "algorithmic_GBps: bytes the dominant kernel has to read (the records of the batch's (query, column) posting lists + "
@@ -612,6 +701,8 @@ def main():
                 line["secondary"] = secondary(index, batches, args, local_rank, device, elapsed / args.steps)
             if not args.no_cpu_baseline:
                 line["cpu_baseline"] = cpu_baseline(args.cpu_sample_docs, local_rank, kind)
+        line["roofline"]["cycles_per_chunk_and_cu"] = (avg_launch_s * SHADER_CLOCK_HZ * 256 / (algo_bytes_per_launch / 256.0)) if info.postings_walk == 4 and algo_bytes_per_launch > 0 else None
+        line["summary"] = summarise(line)                     # LAST key: the driver keeps the line's tail
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -124,6 +124,12 @@ VS_API int vs_index_create_reserved(int64_t rows_cap, int64_t packets_cap, int32
 VS_API int vs_index_append_csr(vs_index* index, const void* rowptr, int rowptr_dtype, const void* colidx, int col_dtype,
                                const void* values, int val_dtype, int64_t n_rows);
 
+/* Row-range sharding ("per-shard npz or row ranges"): rows [row0, row0 + n_rows) of a CSR index as a NEW
+ * index on GPU `device` -- the packets are copied device to device (a peer copy across GPUs).  The reference joins its shard files
+ * with vstack (index.py:172-175) and keeps ONE matrix on one device; SparseIndex(index_file=<one file>, devices=N) and
+ * Retriever.build_index(..., devices=N) deal that one matrix out in contiguous row ranges with this call.                      */
+VS_API int vs_index_slice_rows(const vs_index* index, int64_t row0, int64_t n_rows, int device, vs_index** out);
+
 /* Native shard files (".vsx"): the device format written / read verbatim.  SparseIndex.init_index re-parses,
  * slices and vstacks scipy .npz shards on every load (index.py:172-176); a .vsx file is a header + the three
  * device arrays, so a 97 GB index loads at storage speed.                                                */

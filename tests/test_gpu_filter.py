@@ -482,3 +482,25 @@ def test_head_strips_edge_cases_empty_queries_and_append():
         if stage == "9000 rows":
             idx.append_csr(ip[9000:] - ip[9000], ix[cut:], d[cut:])
             assert idx.info().head_columns == 0                       # the copy (lists and strips) is gone until the next search
+
+
+def test_sparse_rows_take_the_record_copy_not_quad_chunks():
+    """VERDICT r4 item 5 / ADVICE r4: a valued index of 128-nnz documents.  Quad chunks would cost n_blocks x V x 256 bytes (5 x the CSR)
+    for 86 %-empty chunks; the auto policy must pick the record copy (postings_walk 0), stay under 3 x the CSR bytes, take the filter
+    path and match the oracle; forcing quad chunks (postings_walk = 4) must still be bit-identical."""
+    n, nnz = 40_000, 128
+    ip, ix, d = oracle.synth_csr(0, 0, n, V, nnz)
+    idx = DeviceIndex.from_csr(ip, ix, d, V, store_dtype=nat.VS_F32)
+    q = oracle.synth_queries(1, 16)
+    ids, sc, info = _search(idx, q, 100, blocked_postings=1)
+    assert info.last_path == 3 and info.postings_walk == 0, (info.last_path, info.postings_walk)
+    csr_bytes = info.device_bytes
+    assert 0 < info.aux_bytes < 3 * csr_bytes, (info.aux_bytes, csr_bytes)
+    o_ids, o_sc, allsc = oracle.csr_search(ip, ix, d, V, q, 100, acc64=True, return_all=True)
+    compare.check_topk_valid(allsc, ids, sc, rtol=RTOL)
+    compare.compare_topk(o_ids, o_sc, ids, sc, rtol=RTOL)
+    ids4, sc4, info4 = _search(idx, q, 100, postings_walk=4)
+    assert info4.last_path == 3 and info4.postings_walk == 4
+    assert (ids4 == ids).all() and (sc4 == sc).all()
+    assert info4.aux_bytes > info.aux_bytes                    # (what the gate avoids)
+    idx.close()

@@ -1,4 +1,4 @@
-// The inner loop of the row walk (vsearch_amd/csrc/bp_row_asm.h) on its own: every CU walks `n_desc` posting lists (~50 postings
+// The inner loop of the row walk (tools/microbench/bp_row_asm.h) on its own: every CU walks `n_desc` posting lists (~50 postings
 // each, sorted offsets with gaps -- a tile's 21 % of the columns) of NBLK blocks of 5.9 MB and scatter-adds them into LDS.
 // Prints cycles per list and CU, checks workgroup 0's sums against the host.  Mode 1: the workgroup first COPIES its descriptor
 // table with vector stores (alternating between two sources), then reads the copy with scalar loads -- the coherence the real

@@ -51,6 +51,9 @@ def main():
     ap.add_argument("--store", default="fp32", help="bench.py --store of the profiled command")
     ap.add_argument("--scan", default="auto", help="bench.py --scan of the profiled command")
     ap.add_argument("--columns", default="uniform", help="bench.py --columns of the profiled command")
+    ap.add_argument("--leg", default="", help="a secondary leg of bench.py (tools/leg_pmc.py under rocprofv3): key in bench.SECONDARY_LEGS, e.g. C3_1m_sparse; "
+                    "with --fetch and --write, updates profiles/pmc_summary.json -> legs[key]")
+    ap.add_argument("--searches", type=int, default=2, help="--leg: full-batch searches in the profiled command (tools/leg_pmc.py: 1 warm-up + N)")
     ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles"))
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
@@ -83,12 +86,33 @@ def main():
                 f.write(f"# rocprofv3 --pmc {counter}   ({a.note})\n# value = sum over XCDs/instances, KiB; per dispatch in launch order\n")
                 for name, grid, val, n in rows:
                     f.write(f"{name[:100]:100s} grid={grid:<10d} {val:18.1f}\n")
-    if a.queries > 0 and "FETCH_SIZE" in summary and "WRITE_SIZE" in summary:
+    if a.leg and "FETCH_SIZE" in summary and "WRITE_SIZE" in summary:
+        # a secondary leg: HBM bytes of ONE full-batch search = sum over the bench-sized dispatches (>= 1/5 of the largest: the 8-query
+        # warm-up search is excluded) of the leg's scan kernel (+ its head pre-pass), divided by the full-batch searches profiled
+        pmc_path = os.path.join(a.out, "pmc_summary.json")
+        pmc = json.load(open(pmc_path)) if os.path.exists(pmc_path) else {}
+        scan_kernels = ("bp_quad_topk", "bp_walk_topk", "bp_bin_topk", "csr_scan_topk_mq", "head_gemm")
+        def total(rows):
+            vals = [r["KiB"] for r in rows if any(k in r["kernel"] for k in scan_kernels)]
+            big = [v for v in vals if v >= 0.2 * max(vals)] if vals else []
+            return sum(big) / max(1, a.searches), len(big)
+        fetch, nf = total(summary["FETCH_SIZE"])
+        write, _ = total(summary["WRITE_SIZE"])
+        names = sorted({r["kernel"].split("<")[0].split("(")[0].replace("void vs::", "") for r in summary["FETCH_SIZE"] if any(k in r["kernel"] for k in scan_kernels)})
+        if fetch > 0:
+            pmc.setdefault("legs", {})[a.leg] = {
+                "hbm_bytes_per_launch": (2 * fetch + write) * 1024, "fetch_KiB": fetch, "write_KiB": write, "queries_per_launch": a.queries or 1024,
+                "kernels": names, "bench_sized_dispatches": nf, "searches": a.searches, "tag": a.tag, "source_hash": source_hash(),
+                "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 summed over the scan dispatches of one full-batch search",
+                "source": f"profiles/{a.tag}_fetch_size.txt, profiles/{a.tag}_write_size.txt (rocprofv3 --pmc, separate passes, {a.note})"}
+            with open(pmc_path, "w") as f:
+                json.dump(pmc, f, indent=1)
+    elif a.queries > 0 and "FETCH_SIZE" in summary and "WRITE_SIZE" in summary:
         # bench-sized launch (largest) of each scan kernel present -> profiles/pmc_summary.json, read by bench.py for roofline.traffic
         pmc_path = os.path.join(a.out, "pmc_summary.json")
         pmc = json.load(open(pmc_path)) if os.path.exists(pmc_path) else {}
         scan_kernels = ("bp_quad_topk", "bp_walk_topk", "bp_bin_topk", "csr_scan_topk_mq")
-        pmc = {k: v for k, v in pmc.items() if k in scan_kernels}
+        pmc = {k: v for k, v in pmc.items() if k in scan_kernels or k == "legs"}
         for key in scan_kernels:
             scan = lambda rows: max((r["KiB"] for r in rows if key in r["kernel"]), default=0.0)
             fetch, write = scan(summary["FETCH_SIZE"]), scan(summary["WRITE_SIZE"])

@@ -40,6 +40,7 @@ _SIGNATURES = {
     "vs_index_create_csr": ([_vp, _int, _vp, _int, _vp, _int, _int, _i64, _i32, _int, C.POINTER(_vp)], _int),
     "vs_index_create_reserved": ([_i64, _i64, _i32, _int, _int, C.POINTER(_vp)], _int),
     "vs_index_append_csr": ([_vp, _vp, _int, _vp, _int, _vp, _int, _i64], _int),
+    "vs_index_slice_rows": ([_vp, _i64, _i64, _int, C.POINTER(_vp)], _int),
     "vs_npz_inspect": ([C.c_char_p, _i32, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)], _int),
     "vs_index_append_npz": ([_vp, C.c_char_p, _i32], _int),
     "vs_index_save_npz": ([_vp, C.c_char_p, _int], _int),

@@ -238,7 +238,8 @@ __global__ __launch_bounds__(kScanThreads) void bp_bin_topk(BpArgs a) {
             if (a.pace && items <= (int64_t)gridDim.x && tid == 0 && have_b && !pace_off) {
                 uint32_t* pc = a.pace + (size_t)c * a.blocks_per_chunk;
                 const int rel = b - b0;
-                __hip_atomic_fetch_add(pc + rel, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!((a.knob & 64) && blockIdx.x == 0))              // (VS_BP_KNOB=64, tests: workgroup 0 never reports -- every peer's wait must time out, not hang)
+                    __hip_atomic_fetch_add(pc + rel, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (rel >= a.pace_window) {
                     const uint32_t need = (uint32_t)(items / a.nchunk);
                     if (!pace_wait(pc + rel - a.pace_window, need)) pace_off = true;

@@ -38,11 +38,13 @@ static_assert(kQuadAccBytes >= kBpSortBytes, "the accumulator area holds the 819
 __host__ __device__ constexpr size_t quad_fixed_lds() { return kQuadAccBytes + (size_t)kBpCap * 8 + (size_t)kQuadQT * 16 + 64 * 4; }
 __host__ __device__ constexpr size_t quad_lds_bytes() { return quad_fixed_lds() + (size_t)(kBpEntCap + 64 + 64 * kQuadOverRead) * 8; }
 static_assert(quad_lds_bytes() <= (size_t)160 * 1024, "the quad walk's LDS");
-// a wave's two link lists live in its 1 KB of the sort buffer: 48 descriptors + the 16 null ones a walk over-reads, twice
-constexpr int kQuadListCap = 48, kQuadListBytes = (kQuadListCap + 4 * kQuadOverRead) * 8;
+// a wave's two link lists live in its 1 KB of the sort buffer: 64 descriptors each, of which 4 * kQuadOverRead are the null ones a walk over-reads
+constexpr int kQuadListCap = 64 - 4 * kQuadOverRead, kQuadListBytes = (kQuadListCap + 4 * kQuadOverRead) * 8;
+static_assert(kQuadListCap >= 16, "room for links in a wave's list");
 static_assert(2 * kQuadListBytes * kScanWaves <= kBpCap * 8, "the link lists fit the sort buffer");
 // postings a chunk holds when its list goes on in another chunk (the last two cells are the link), overflow chunks of a list of n postings
 constexpr int kQuadLinked = kQuadCells - 2;
+constexpr double kQuadMaxRatio = 3.0;                              // auto policy: quad chunks while their main area is within this multiple of the CSR bytes (bp_build)
 constexpr int kQuadPaceDefault = 8;                                // lock-step window in blocks (see the walk)
 __host__ __device__ constexpr uint32_t quad_overflow_chunks(uint32_t n) { return n > (uint32_t)kQuadCells ? (n - (uint32_t)kQuadCells + (uint32_t)kQuadLinked - 1u) / (uint32_t)kQuadLinked : 0u; }
 
@@ -91,10 +93,8 @@ __global__ __launch_bounds__(kScanThreads) void quad_count_kernel(const uint32_t
             d[i] = bp_dir_pack((uint32_t)off, r);
             if (r > kBpDirRecMask || (uint32_t)off > kBpDirUnitMax) overflow[0] = 1;
             off += (int)r;
-            if (c) {
-                atomicAdd(&df_rec[i], (unsigned long long)(1u + r));
-                atomicAdd(&df_nnz[i], (unsigned long long)c);
-            }
+            atomicAdd(&df_rec[i], (unsigned long long)(1u + r));        // chunks an entry on this column reads in this block (the main chunk even when empty)
+            if (c) atomicAdd(&df_nnz[i], (unsigned long long)c);
         }
         if (tid == 0) { d[n_cols] = bp_dir_pack((uint32_t)tot, 0u); block_recs[b] = (uint32_t)n_cols + (uint32_t)tot; }
     }
@@ -356,7 +356,8 @@ __global__ __launch_bounds__(kScanThreads) void bp_quad_topk(BpArgs a) {
             if (a.pace && items <= (int64_t)gridDim.x && tid == 0 && have && !pace_off) {
                 uint32_t* pc = a.pace + (size_t)c * a.blocks_per_chunk;
                 const int64_t rel = b - b0;
-                __hip_atomic_fetch_add(pc + rel, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!((a.knob & 64) && blockIdx.x == 0))              // (VS_BP_KNOB=64, tests: workgroup 0 never reports -- every peer's wait must time out, not hang)
+                    __hip_atomic_fetch_add(pc + rel, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (rel >= a.pace_window) {
                     const uint32_t need = (uint32_t)(items / a.nchunk);
                     if (!pace_wait(pc + rel - a.pace_window, need)) pace_off = true;

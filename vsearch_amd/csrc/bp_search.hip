@@ -32,7 +32,7 @@ bool bp_wanted(const vs_index* idx) {
 }
 
 void bp_release(vs_index* idx) {
-    idx->bp_dir.release(); idx->bp_base.release(); idx->bp_rec.release(); idx->bp_df.release(); idx->bp_vmax.release(); idx->bp_ovf.release();
+    idx->bp_dir.release(); idx->bp_base.release(); idx->bp_rec.release(); idx->bp_df.release(); idx->bp_vmax.release();
     idx->bp_hmap.release(); idx->bp_strip.release();
     idx->bp_n_head = 0;
     idx->bp_quad = false;
@@ -41,7 +41,9 @@ void bp_release(vs_index* idx) {
 
 // valued index: QT queries per tile, blocks of <= 2048 documents (exact fp64 walk: QT = 4, filter walk: QT = 8);
 // binary index: filter walk only, one lane per (short) list
+#ifdef VS_EXPERIMENTAL_WALKS
 constexpr int kFlRoundsF16 = 8, kFlRoundsF32 = 5;     // record loads in flight per lane (registers: 8 / 12 per record)
+#endif
 // which walk serves the fixed-point filter of this index: 0 = a list per lane group (bp_walk.h), 1 = flat worklists (bp_flat.h),
 // 2 = the list walk on two accumulator sets, no block barrier (bp_duo.h), 3 = flat worklists, record loads software-pipelined (bp_stream.h)
 int bp_walk_kind(const vs_index* idx) {
@@ -120,8 +122,17 @@ int bp_build(vs_index* idx, hipStream_t s) {
     // one-dword postings (fp16 values).  Not for: a binary index; exact fp32 records ("postings_quant" = 0, signed / huge values);
     // the fp64 walk ("postings_filter" = 0); a corpus with head columns (their dense strips belong to the list walk: bp_build starts
     // over without quad when it finds any); the experimental walks 0 .. 3 ("postings_walk"), aligned or arranged records.
+    // Size gate (profiles/r05_quad_policy.txt): a block's main chunks cost n_cols x 256 bytes whatever the lists hold.
+    // Measured at 4 M docs, 64 .. 768 nnz per document: the quad walk is FASTER than the record walk at every density (31.6 vs 39.7 ms at
+    // 64 nnz: a chunk step per list against the list walk's per-list bookkeeping), so speed never argues against it -- memory does: at
+    // 128 nnz the chunks are 4.8 x the CSR packets, 86 % of their cells empty.  With "postings_walk" = -1 (auto) quad chunks are chosen
+    // when their main area stays within kQuadMaxRatio x the CSR bytes (>= ~205 nnz per document at V = 29 523); 4 forces them.
+    const int64_t quad_blocks = ceil_div64(std::max<int64_t>(idx->n_rows, 1), kQuadRows);
+    const double quad_main = (double)quad_blocks * (double)idx->n_cols * (double)kQuadChunkBytes;
+    const double csr_bytes = (double)idx->n_packets * (16.0 + (idx->store_dtype == VS_F32 ? 32.0 : idx->store_dtype == VS_F16 ? 16.0 : 0.0)) + (double)(idx->n_rows + 1) * 4.0;
+    const bool quad_dense_enough = idx->bp_walk_pref == 4 || quad_main <= kQuadMaxRatio * csr_bytes;
     const bool quad_pref = idx->store_dtype != VS_NONE && idx->bp_filter != 0 && idx->n_cols <= 32768 && (idx->bp_walk_pref == -1 || idx->bp_walk_pref == 4) && !idx->bp_no_quad &&
-                           idx->bp_align_pref != 1 && idx->bp_arrange_pref != 1 && (idx->store_dtype == VS_F16 || idx->bp_quant_pref != 0);
+                           idx->bp_align_pref != 1 && idx->bp_arrange_pref != 1 && (idx->store_dtype == VS_F16 || idx->bp_quant_pref != 0) && quad_dense_enough;
     idx->bp_no_quad = false;
     auto auto_rows = [&]() -> int {
         if (idx->store_dtype == VS_NONE) return kBpRowsMaxBin;
@@ -188,14 +199,20 @@ int bp_build(vs_index* idx, hipStream_t s) {
     if (quad) {
         // quad chunks: main chunk of column c = chunk c of its block, overflow chunks behind (the directory is the builder's only)
         const size_t b_main = (size_t)n_blocks * V * kQuadChunkBytes;
-        if (free_b < b_dir + b_main + margin) return no_room(b_dir + b_main);
+        if (free_b < b_dir + b_main + margin) {
+            // no room for the chunks: the record copy is smaller (4 bytes a posting against 256 a list) -- try that before giving
+            // up to the CSR scan
+            fprintf(stderr, "[vsearch_hip] quad chunks need %.1f GB, %.1f GB of HBM free: building the record copy instead\n", (double)(b_dir + b_main) / 1e9, (double)free_b / 1e9);
+            idx->bp_no_quad = true;
+            return bp_build(idx, s);
+        }
         VS_HIP(hipFuncSetAttribute((const void*)quad_count_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(quad_count_kernel<0>, dim3(grid), dim3(kScanThreads), lds, s, idx->pk_ptr.as<uint32_t>(), idx->cols.as<uint4>(), idx->n_rows, V, idx->bp_rows,
                            idx->bp_dir.as<uint32_t>(), block_recs.as<uint32_t>(), df_rec, df_nnz, ovf.as<int32_t>());
     } else {
         VS_HIP(hipFuncSetAttribute((const void*)bp_count_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(bp_count_kernel<0>, dim3(grid), dim3(kScanThreads), lds, s, idx->pk_ptr.as<uint32_t>(), idx->cols.as<uint4>(), idx->n_rows, V, idx->bp_rows,
-                           idx->bp_dir.as<uint32_t>(), block_recs.as<uint32_t>(), df_rec, df_nnz, (const uint16_t*)nullptr, idx->bp_al_shift, ovf.as<int32_t>(), 3);
+                           idx->bp_dir.as<uint32_t>(), block_recs.as<uint32_t>(), df_rec, df_nnz, (const uint16_t*)nullptr, idx->bp_al_shift, ovf.as<int32_t>());
     }
     VS_STAGE("bp_count", s);
     // Head columns (skewed vocabularies): present in >= 1/4 of the documents -> dense strips instead of posting lists.  Valued
@@ -231,7 +248,7 @@ int bp_build(vs_index* idx, hipStream_t s) {
             VS_HIP(hipMemsetAsync(idx->bp_df.p, 0, (size_t)V * 16, s));
             hipLaunchKernelGGL(bp_count_kernel<0>, dim3(grid), dim3(kScanThreads), lds, s, idx->pk_ptr.as<uint32_t>(), idx->cols.as<uint4>(), idx->n_rows, V,
                                idx->bp_rows, idx->bp_dir.as<uint32_t>(), block_recs.as<uint32_t>(), df_rec, df_nnz, (const uint16_t*)idx->bp_hmap.as<uint16_t>(),
-                               idx->bp_al_shift, ovf.as<int32_t>(), 3);
+                               idx->bp_al_shift, ovf.as<int32_t>());
             VS_HIP(hipGetLastError());
             const size_t b_strip = (size_t)n_blocks * bp_head_pad(h_n) * idx->bp_rows * 2;
             VS_HIP(hipMemGetInfo(&free_b, &total_b));
@@ -263,7 +280,14 @@ int bp_build(vs_index* idx, hipStream_t s) {
     const int RS = quad ? kQuadChunkBytes : bp_rec_bytes(bp_record_vm(idx));
     const size_t b_rec = ((size_t)n_rec + 2) * RS;                       // + one record: a lane past the last list's end re-reads "the record at the end"
     VS_HIP(hipMemGetInfo(&free_b, &total_b));
-    if (free_b < b_rec + margin || idx->bp_rec.alloc(b_rec) != VS_OK) return no_room(b_rec);
+    if (free_b < b_rec + margin || idx->bp_rec.alloc(b_rec) != VS_OK) {
+        if (quad) {                                                       // (overflow chunks took it past what is free: the record copy next)
+            (void)hipGetLastError();
+            idx->bp_no_quad = true;
+            return bp_build(idx, s);
+        }
+        return no_room(b_rec);
+    }
     idx->bp_records = (int64_t)n_rec;
     VS_HIP(hipMemsetAsync(idx->bp_rec.p, 0, b_rec, s));                  // pad postings: document 0, value 0
     if (quad) {
@@ -313,7 +337,7 @@ int bp_build(vs_index* idx, hipStream_t s) {
         std::vector<unsigned long long> hb((size_t)n_blocks + 1);
         std::vector<uint32_t> hd((size_t)V + 1);
         (void)hipMemcpy(hb.data(), idx->bp_base.p, hb.size() * 8, hipMemcpyDeviceToHost);
-        (void)hipMemcpy(hd.data(), idx->bp_dir.as<uint32_t>() + (size_t)(n_blocks - 1) * (V + 1), hd.size() * 4, hipMemcpyDeviceToHost);
+        if (!idx->bp_quad) (void)hipMemcpy(hd.data(), idx->bp_dir.as<uint32_t>() + (size_t)(n_blocks - 1) * (V + 1), hd.size() * 4, hipMemcpyDeviceToHost);   // (quad chunks: the directory is gone)
         bool mono = true;
         for (size_t i = 0; i + 1 < hb.size(); ++i) mono = mono && hb[i] <= hb[i + 1];
         bool dmono = true;

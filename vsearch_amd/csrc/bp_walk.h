@@ -73,8 +73,7 @@ __host__ __device__ inline uint32_t bp_dir_pack(uint32_t unit, uint32_t recs) { 
 template <int UNUSED>
 __global__ __launch_bounds__(kScanThreads) void bp_count_kernel(const uint32_t* pk_ptr, const uint4* cols, int64_t n_rows, int32_t n_cols, int32_t rows,
                                                                 uint32_t* dir, uint32_t* block_recs, unsigned long long* df_rec,
-                                                                unsigned long long* df_nnz, const uint16_t* hmap, int32_t al_shift, int32_t* overflow,
-                                                                int32_t cell_shift) {          // postings per record: 2^cell_shift (8; quad chunks, bp_quad.h: 64)
+                                                                unsigned long long* df_nnz, const uint16_t* hmap, int32_t al_shift, int32_t* overflow) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint32_t* cnt = reinterpret_cast<uint32_t*>(smem);                  // [n_cols + 1]
     __shared__ int scratch[32];
@@ -101,8 +100,7 @@ __global__ __launch_bounds__(kScanThreads) void bp_count_kernel(const uint32_t* 
         __syncthreads();
         const int i0 = tid * seg, i1 = min(n_cols + 1, i0 + seg);
         // (head columns -- hmap[c] != 0xFFFF -- live in the dense strips: no records, empty lists)
-        const uint32_t cell_mask = (1u << cell_shift) - 1u;
-        auto recs_of = [&](int i) -> uint32_t { return (hmap && i < n_cols && hmap[i] != 0xFFFFu) ? 0u : (cnt[i] + cell_mask) >> cell_shift; };
+        auto recs_of = [&](int i) -> uint32_t { return (hmap && i < n_cols && hmap[i] != 0xFFFFu) ? 0u : (cnt[i] + 7u) >> 3; };       // 8 postings a record
         // a list starts on a multiple of 2^al_shift records: the scan runs in those units
         const uint32_t al_mask = (1u << al_shift) - 1u;
         int mine = 0;
@@ -928,7 +926,8 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
             if (a.pace && items <= (int64_t)gridDim.x && tid == 0 && have && !pace_off) {
                 uint32_t* pc = a.pace + (size_t)c * a.blocks_per_chunk;
                 const int64_t rel = b - b0;
-                __hip_atomic_fetch_add(pc + rel, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!((a.knob & 64) && blockIdx.x == 0))              // (VS_BP_KNOB=64, tests: workgroup 0 never reports -- every peer's wait must time out, not hang)
+                    __hip_atomic_fetch_add(pc + rel, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (rel >= a.pace_window) {
                     const uint32_t need = (uint32_t)(items / a.nchunk);
                     if (!pace_wait(pc + rel - a.pace_window, need)) pace_off = true;

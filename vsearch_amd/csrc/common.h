@@ -207,7 +207,6 @@ struct vs_index {
     vs::DevBuf bp_dir;   // uint32 [n_blocks, n_cols + 1]: first record of a column inside its block
     vs::DevBuf bp_base;  // uint64 [n_blocks + 1]: first record of a block
     vs::DevBuf bp_rec;   // records: 8 x uint16 document-in-block + 8 values (fp32 | fp16 | none)
-    vs::DevBuf bp_ovf;   // quad chunks (bp_quad.h): uint32 [n_blocks][bitmap words]: columns of a block whose list overflows its main chunk
     vs::DevBuf bp_df;    // uint64 [2][n_cols]: records / non-zeros per column over all blocks -- what a query entry walks
     int64_t bp_records = 0;
     vs::DevBuf bp_hmap;  // uint16 [n_cols]: strip index of a head column (dense strip), 0xFFFF otherwise; valid when bp_n_head > 0

@@ -357,6 +357,77 @@ extern "C" int vs_index_create_reserved(int64_t rows_cap, int64_t packets_cap, i
     return VS_OK;
 }
 
+namespace {
+// a row slice's pk_ptr (still the source's offsets, first packet p0): out[0] = non-pad column slots of the slice (its nnz) ...
+template <int UNUSED>
+__global__ __launch_bounds__(256) void slice_count_kernel(const uint32_t* pk_ptr, int64_t n_rows, uint32_t p0, const uint16_t* cols, int32_t n_cols, unsigned long long* nnz_out) {
+    unsigned long long nnz = 0;
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n_rows; r += (int64_t)gridDim.x * 256) {
+        const uint32_t a = pk_ptr[r] - p0, b = pk_ptr[r + 1] - p0;
+        if (b > a) {                                           // pads sit at the tail of a row's last packet only
+            nnz += (unsigned long long)(b - a - 1) * 8ull;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) nnz += cols[(size_t)(b - 1) * 8 + i] != (uint16_t)n_cols ? 1ull : 0ull;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) nnz += __shfl_xor(nnz, o, 64);
+    if ((threadIdx.x & 63) == 0 && nnz) atomicAdd(nnz_out, nnz);
+}
+// ... then rebased to the slice's first packet (a second launch: every element on its own)
+template <int UNUSED>
+__global__ __launch_bounds__(256) void slice_rebase_kernel(uint32_t* pk_ptr, int64_t n_rows, uint32_t p0) {
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r <= n_rows; r += (int64_t)gridDim.x * 256) pk_ptr[r] -= p0;
+}
+}  // namespace
+
+// Rows [row0, row0 + n_rows) of a CSR index as a NEW index on `device` (any GPU): the packets are copied device to device (a peer
+// copy across GPUs), the host never sees them.  This is what row-range sharding is made of ("per-shard npz or
+// row ranges"): one .npz / .vsx file, or an index built in memory, dealt over several GPUs.
+extern "C" int vs_index_slice_rows(const vs_index* src, int64_t row0, int64_t n_rows, int device, vs_index** out) {
+    if (!out) return fail(VS_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (!src || src->kind != VS_KIND_CSR) return fail(VS_EINVAL, "not a CSR index");
+    if (row0 < 0 || n_rows < 0 || row0 + n_rows > src->n_rows) return fail(VS_ERANGE, "rows [%lld, %lld) outside the index's %lld rows", (long long)row0, (long long)(row0 + n_rows), (long long)src->n_rows);
+    VS_HIP(hipSetDevice(src->device));
+    uint32_t pr[2] = {0u, 0u};
+    VS_HIP(hipMemcpy(&pr[0], src->pk_ptr.as<uint32_t>() + row0, 4, hipMemcpyDeviceToHost));
+    VS_HIP(hipMemcpy(&pr[1], src->pk_ptr.as<uint32_t>() + row0 + n_rows, 4, hipMemcpyDeviceToHost));
+    const int64_t packets = (int64_t)pr[1] - (int64_t)pr[0];
+    if (packets < 0) return fail(VS_EINVAL, "row pointers decrease");
+    vs_index* idx = nullptr;
+    VS_TRY(vs_index_create_reserved(n_rows, packets, src->n_cols, src->store_dtype, device, &idx));
+    struct Guard { vs_index* p; ~Guard() { if (p) vs_index_destroy(p); } } guard{idx};
+    const size_t vb = src->store_dtype == VS_F32 ? 32 : (src->store_dtype == VS_F16 ? 16 : 0);
+    auto copy = [&](void* dst, const void* from, size_t bytes) -> int {
+        if (bytes == 0) return VS_OK;
+        if (device == src->device) VS_HIP(hipMemcpy(dst, from, bytes, hipMemcpyDeviceToDevice));
+        else VS_HIP(hipMemcpyPeer(dst, device, from, src->device, bytes));
+        return VS_OK;
+    };
+    VS_TRY(copy(idx->pk_ptr.p, src->pk_ptr.as<uint32_t>() + row0, (size_t)(n_rows + 1) * 4));
+    VS_TRY(copy(idx->cols.p, src->cols.as<char>() + (size_t)pr[0] * 16, (size_t)packets * 16));
+    if (vb) VS_TRY(copy(idx->vals.p, src->vals.as<char>() + (size_t)pr[0] * vb, (size_t)packets * vb));
+    VS_HIP(hipSetDevice(device));
+    DevBuf cnt;
+    VS_TRY(cnt.alloc(8));
+    VS_HIP(hipMemset(cnt.p, 0, 8));
+    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div64(n_rows + 1, 256), 4096));
+    hipLaunchKernelGGL(slice_count_kernel<0>, dim3(grid), dim3(256), 0, 0, idx->pk_ptr.as<uint32_t>(), n_rows, pr[0], idx->cols.as<uint16_t>(), src->n_cols,
+                       cnt.as<unsigned long long>());
+    hipLaunchKernelGGL(slice_rebase_kernel<0>, dim3(grid), dim3(256), 0, 0, idx->pk_ptr.as<uint32_t>(), n_rows, pr[0]);
+    VS_HIP(hipGetLastError());
+    unsigned long long nnz = 0;
+    VS_HIP(hipMemcpy(&nnz, cnt.p, 8, hipMemcpyDeviceToHost));
+    idx->n_rows = n_rows;
+    idx->n_packets = packets;
+    idx->nnz = (int64_t)nnz;
+    idx->logical_dense = src->logical_dense;
+    idx->lanes_per_row = pick_lanes_per_row(idx->n_packets, idx->n_rows);
+    guard.p = nullptr;
+    *out = idx;
+    return VS_OK;
+}
+
 extern "C" int vs_index_append_csr(vs_index* idx, const void* rowptr, int rowptr_dtype, const void* colidx, int col_dtype,
                                    const void* values, int val_dtype, int64_t n_rows) {
     if (!idx || idx->kind != VS_KIND_CSR) return fail(VS_EINVAL, "not a CSR index");
@@ -465,7 +536,9 @@ extern "C" int vs_index_info(const vs_index* idx, vs_index_info_t* o) {
         VS_HIP(hipSetDevice(idx->device));
         VS_HIP(hipDeviceSynchronize());
         VS_HIP(hipMemcpy(hp, idx->last_plan_dev, sizeof(hp), hipMemcpyDeviceToHost));
-        o->last_scan_bytes = hp[4] * idx->last_plan_rs + hp[2] * idx->last_plan_blocks * 4;      // records + one directory word per (entry, block)
+        // records + one directory word per (entry, block); quad chunks: every chunk the walk reads (main chunks, empty ones included, and
+        // overflow chunks -- quad_count_kernel counts them all), no directory
+        o->last_scan_bytes = idx->bp_quad ? hp[4] * idx->last_plan_rs : hp[4] * idx->last_plan_rs + hp[2] * idx->last_plan_blocks * 4;
         o->last_walk_postings = hp[5];
     }
     if (idx->last_path == 3 && idx->last_flags && idx->last_flags_n > 0) {
@@ -475,7 +548,7 @@ extern "C" int vs_index_info(const vs_index* idx, vs_index_info_t* o) {
         VS_HIP(hipMemcpy(h.data(), idx->last_flags, h.size() * 4, hipMemcpyDeviceToHost));
         for (uint32_t f : h) o->last_fallbacks += f ? 1 : 0;
     }
-    o->aux_bytes = idx->bp_ready ? (int64_t)(idx->bp_dir.bytes + idx->bp_base.bytes + idx->bp_rec.bytes + idx->bp_strip.bytes + idx->bp_ovf.bytes) : 0;
+    o->aux_bytes = idx->bp_ready ? (int64_t)(idx->bp_dir.bytes + idx->bp_base.bytes + idx->bp_rec.bytes + idx->bp_strip.bytes) : 0;
     if (idx->kind == VS_KIND_CSR) {
         o->bytes_per_pass = csr_bytes_per_pass(idx);
         o->device_bytes = (int64_t)(idx->pk_ptr.bytes + idx->cols.bytes + idx->vals.bytes);

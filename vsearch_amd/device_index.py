@@ -112,6 +112,13 @@ class DeviceIndex:
         nat.check(nat.lib().vs_index_append_csr(self._h, p_rp, dt_rp, p_ci, dt_ci, p_v, dt_v if data is not None else nat.VS_F32,
                                                 int(indptr.shape[0]) - 1))
 
+    def slice_rows(self, row0: int, n_rows: int, device: int = None) -> "DeviceIndex":
+        """Rows [row0, row0 + n_rows) as a new CSR index on GPU `device` (default: this index's): a device-to-device (peer) copy of
+        the packets -- what row-range sharding deals out (vs_index_slice_rows)."""
+        h = C.c_void_p()
+        nat.check(nat.lib().vs_index_slice_rows(self._h, int(row0), int(n_rows), int(self.device if device is None else device), C.byref(h)))
+        return DeviceIndex(h)
+
     def append_npz(self, path: str, shift: int = 0):
         """Append a scipy.sparse.save_npz CSR shard read natively (zip + npy parsed in the library): columns below `shift` dropped,
         ids moved down by `shift`, sorted within a row.  NotImplementedError for non-CSR files; NotBinaryError when a binary

@@ -289,6 +289,38 @@ class SparseIndex(Index):
                 sh.prepare()
         self.device = f"cuda:{shards[0].device}"
 
+    def shard_rows(self, devices):
+        """Deal this (unsharded, device-resident) index over `devices` in contiguous, equal row ranges ("per-shard npz
+        or row ranges"): one .npz / .vsx file -- what SparseIndex.save writes, index.py:181-202 -- or an index built in memory
+        (Retriever.build_index, retriever.py:284-317) then uses more than one GPU.  Device-to-device copies of the packets
+        (vs_index_slice_rows); results stay bit-identical to the unsharded index."""
+        gpus = _resolve_devices(devices)
+        if not gpus:
+            return self
+        if self._shards:
+            raise NotImplementedError("the index is row-sharded already")
+        from vsearch_amd.distributed import shard_rows as _range
+        whole = self._device_index()
+        info = whole.info()
+        if info.kind != nat.VS_KIND_CSR:
+            raise NotImplementedError("row sharding serves the sparse and bag-of-token indexes")
+        self._shape = (int(info.n_rows), int(info.n_cols))
+        built = []
+        try:
+            for r, gpu in enumerate(gpus):
+                row0, n = _range(int(info.n_rows), len(gpus), r)
+                built.append(whole.slice_rows(row0, n, gpu))
+        except Exception:
+            for dev in built:
+                dev.close()
+            raise
+        self._dev = None
+        self._vector = None
+        whole.close()
+        self._devices = gpus
+        self._adopt_shards(built)
+        return self
+
     @property
     def shards(self):
         """the DeviceIndex of every row shard, in row order (None: the index is not sharded)"""
@@ -387,6 +419,42 @@ class SparseIndex(Index):
         if not files:
             raise FileNotFoundError(f"no index file matches {index_file!r}")
         logger.info("***** Loading %s Index from %d files *****", self.index_type.value, len(files))
+        if all(f.endswith(".vsx") for f in files) and self._devices and len(files) < len(self._devices):
+            # fewer native files than GPUs: row ranges.  The files are joined on the first GPU (device-to-device), then dealt out
+            if self.shift:
+                raise ValueError(f"a native .vsx shard stores the columns after the shift was applied: load it with shift=0 (got shift={self.shift})")
+            self._drop_device()
+            self._vector = None
+            gpus, self._devices = self._devices, None
+            try:
+                if len(files) == 1:
+                    self.init_index(files[0], fp16)
+                    self.shard_rows(gpus)
+                else:
+                    # every file's rows, sliced at the GPUs' range boundaries; a GPU whose range spans two files holds two shards
+                    # (a shard group takes any number of shards per device, in row order)
+                    from vsearch_amd.distributed import shard_rows as _range
+                    loaded = [DeviceIndex.load_native(f, device=gpus[0]) for f in files]
+                    rows = [int(d.info().n_rows) for d in loaded]
+                    total, built, start = sum(rows), [], 0
+                    bounds = [_range(total, len(gpus), r) for r in range(len(gpus))]
+                    try:
+                        for dev, n in zip(loaded, rows):
+                            for gpu, (b0, bn) in zip(gpus, bounds):
+                                lo, hi = max(start, b0), min(start + n, b0 + bn)
+                                if hi > lo:
+                                    built.append(dev.slice_rows(lo - start, hi - lo, gpu))
+                            start += n
+                    finally:
+                        for dev in loaded:
+                            dev.close()
+                    info = built[0].info()
+                    self._dtype = torch.float32 if info.store_dtype == nat.VS_F32 else torch.float16
+                    self._shape = (total, int(info.n_cols))
+                    self._adopt_shards(built)
+            finally:
+                self._devices = gpus
+            return
         if all(f.endswith(".vsx") for f in files) and (len(files) == 1 or self._devices):
             # native shard files: the device format verbatim.  One file -> this device; several (with `devices`) -> one row shard each,
             # dealt to the GPUs in order
@@ -455,6 +523,10 @@ class SparseIndex(Index):
         # pass 2: one shard at a time -- the reference's vstack(shards) (index.py:175) never exists on the host.  With `devices` the
         # files are dealt to the GPUs in row order, whole files, as evenly in rows as their boundaries allow.
         gpus = self._devices or [_gpu_ordinal(self.device)]
+        split_rows = bool(self._devices) and len(files) < len(gpus)      # fewer files than GPUs (one .npz: what `save` writes): row ranges
+        all_gpus = gpus
+        if split_rows:
+            gpus = gpus[:1]
         groups, start = [[] for _ in gpus], 0
         for f in files:
             groups[min(len(gpus) - 1, start * len(gpus) // max(rows_total, 1))].append(f)
@@ -497,7 +569,10 @@ class SparseIndex(Index):
                 built = convert(valued)
         else:
             built = convert(valued)
-        if len(built) == 1:
+        if len(built) == 1 and split_rows:
+            self._dev = built[0]
+            self.shard_rows(all_gpus)                                # joined on the first GPU, dealt out in row ranges (device to device)
+        elif len(built) == 1:
             self._dev = built[0]
             self._prepare()
         else:

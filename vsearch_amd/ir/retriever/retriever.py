@@ -192,7 +192,9 @@ class Retriever(BiEncoder):
             vals.append(va.cpu())
         return torch.sparse_csr_tensor(torch.cat(ptrs), torch.cat(cols).to(torch.int64), torch.cat(vals), size=(len(texts), V))
 
-    def build_index(self, texts: List[str], batch_size=32, index_type=IndexType.DENSE, bag_of_token=False):
+    def build_index(self, texts: List[str], batch_size=32, index_type=IndexType.DENSE, bag_of_token=False, devices=None):
+        """retriever.py:284-317.  `devices` (not in the reference): deal the built sparse / bag-of-token index over several GPUs of this
+        process in contiguous row ranges (SparseIndex.shard_rows) -- None, "all", a count, or a list of GPU ordinals."""
         if isinstance(index_type, str):
             index_type = IndexType(index_type.lower())
         elif not isinstance(index_type, IndexType):
@@ -217,6 +219,10 @@ class Retriever(BiEncoder):
         else:
             raise NotImplementedError
         self.index.move_to_device(self.device)
+        if devices is not None:
+            if index_type == IndexType.DENSE:
+                raise NotImplementedError("devices=: row sharding serves the sparse and bag-of-token indexes")
+            self.index.shard_rows(devices)
 
     def save_index(self, path):
         self.index.save(path)
