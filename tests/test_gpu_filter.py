@@ -331,13 +331,17 @@ def test_skewed_columns_device_generator_and_search():
     compare.check_topk_valid(allsc, ids, sc, rtol=RTOL)
 
 
+@pytest.mark.parametrize("gemm", [0, 1], ids=["in-walk", "pre-pass"])
 @pytest.mark.parametrize("store", [nat.VS_F32, nat.VS_F16], ids=["fp32", "fp16"])
-def test_dense_head_strips_keep_the_results(store):
-    """Option postings_head: the columns present in >= 1/N of the documents move from posting lists to dense fp16 strips that the
-    tile scores with multiply-adds in registers.  Whatever N, the results are the CSR scan's, bit for bit; more than 512
-    qualifying columns keep the 512 most frequent."""
+def test_dense_head_strips_keep_the_results(store, gemm):
+    """Option postings_head: the columns present in >= 1/N of the documents move from posting lists to dense fp16 strips scored on
+    the matrix cores -- inside the walk, tile by tile (postings_head_gemm = 0: auto N = 4, at most 512 columns), or by the head
+    pre-pass (bp_head.h, the default: auto N = 8, at most 1024).  Whatever N, the results are the CSR scan's, bit for bit; more
+    qualifying columns than the cap keep the most frequent."""
     n = 9000
+    cap, auto_n = (1024, 8) if gemm else (512, 4)
     idx = DeviceIndex.synthetic(0, 100, n, V, 768, synth.KIND_SKEW, 0, store)
+    idx.set_option("postings_head_gemm", gemm)
     ip, ix, d = idx.export_csr()
     df = np.bincount(ix, minlength=V)
     q = oracle.synth_queries(1, 19, kind=synth.KIND_SKEW)
@@ -358,8 +362,14 @@ def test_dense_head_strips_keep_the_results(store):
         assert (ids == ref_ids).all() and (sc == ref_sc).all(), f"postings_head={head}: differs from the CSR scan"
         seen[head] = info.head_columns
     assert seen[0] == 0
-    assert seen[2] == int((df >= -(-n // 2)).sum()) and seen[-1] == int((df >= -(-n // 4)).sum())
-    assert seen[2] < seen[-1] <= seen[8] <= seen[64] == 512
+    assert seen[2] == int((df >= -(-n // 2)).sum()) and seen[-1] == min(cap, int((df >= -(-n // auto_n)).sum()))
+    assert seen[2] < seen[-1] <= seen[8] <= seen[64] <= cap and seen[64] > cap - 32       # (ties at the raised threshold can leave a few below the cap)
+    if gemm:
+        # the pre-pass in several passes over the batch's 3 tiles (2 + 1), and one tile at a time
+        for tiles in (2, 1):
+            ids, sc, info = _search(idx, q, 100, blocked_postings=1, postings_head=-1, postings_head_tiles=tiles)
+            assert info.last_path == 3 and (ids == ref_ids).all() and (sc == ref_sc).all(), f"{tiles} tiles per pass"
+        idx.set_option("postings_head_tiles", 0)
     _, _, allsc = oracle.csr_search(ip, ix, d.astype(np.float32), V, q, 100, acc64=True, return_all=True)
     compare.check_topk_valid(allsc, ref_ids, ref_sc, rtol=RTOL)
     # forced exact pass and the fp64 walk on the same index (the latter rebuilds the copy without strips)

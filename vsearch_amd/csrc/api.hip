@@ -131,6 +131,20 @@ extern "C" int vs_index_set_option(vs_index* idx, const char* name, int value) {
         idx->bp_head_pref = value;
         return VS_OK;
     }
+    if (n == "postings_head_gemm") {
+        if (value < -1 || value > 1) return fail(VS_EINVAL, "postings_head_gemm: -1 = auto (on), 1 = head columns by the head pre-pass, 0 = inside the walk");
+        if (value != idx->bp_head_gemm_pref) {
+            idx->bp_dir.release(); idx->bp_base.release(); idx->bp_rec.release(); idx->bp_strip.release(); idx->bp_hmap.release();
+            idx->bp_n_head = 0; idx->bp_ready = false; idx->bp_tried = false;
+        }
+        idx->bp_head_gemm_pref = value;
+        return VS_OK;
+    }
+    if (n == "postings_head_tiles") {
+        if (value < 0 || value > 4096) return fail(VS_EINVAL, "postings_head_tiles: 0 = auto, else tiles per pass of the head pre-pass");
+        idx->bp_head_tiles = value;
+        return VS_OK;
+    }
     if (n == "postings_lanes") {
         if (value != 0 && value != 4 && value != 8) return fail(VS_EINVAL, "postings_lanes: 0 = auto | 4 | 8");
         idx->bp_lanes = value;
@@ -142,8 +156,8 @@ extern "C" int vs_index_set_option(vs_index* idx, const char* name, int value) {
 #ifndef VS_EXPERIMENTAL_WALKS
         if (value >= 1 && value <= 3) return fail(VS_EUNSUPPORTED, "postings_walk %d: the experimental walks are not part of this build (make EXPERIMENTAL=1)", value);
 #endif
-        // quad chunks and records are different copies: a change between them rebuilds
-        if ((value == -1 || value == 4) != (idx->bp_walk_pref == -1 || idx->bp_walk_pref == 4)) {
+        // quad chunks and records are different copies, and auto (-1) picks between them by size: any change rebuilds at the next search
+        if (value != idx->bp_walk_pref) {
             idx->bp_dir.release(); idx->bp_base.release(); idx->bp_rec.release(); idx->bp_quad = false; idx->bp_ready = false; idx->bp_tried = false;
         }
         idx->bp_walk_pref = value;

@@ -25,6 +25,10 @@
 #include "bp_quad_loop.h"
 #include "bp_quad_asm.h"
 
+#ifndef VS_QUAD_EPI
+#define VS_QUAD_EPI 2          // how the epilogue reads and zeroes a document's sums: 0 = 8 reads + 8 writes, 1 = 8 ds_wrxchg_rtn_b32, 2 = 4 ds_wrxchg2_rtn_b32
+#endif
+
 namespace vs {
 
 constexpr int kQuadRows = 2048;                                   // documents per block
@@ -38,6 +42,7 @@ static_assert(kQuadAccBytes >= kBpSortBytes, "the accumulator area holds the 819
 __host__ __device__ constexpr size_t quad_fixed_lds() { return kQuadAccBytes + (size_t)kBpCap * 8 + (size_t)kQuadQT * 16 + 64 * 4; }
 __host__ __device__ constexpr size_t quad_lds_bytes() { return quad_fixed_lds() + (size_t)(kBpEntCap + 64 + 64 * kQuadOverRead) * 8; }
 static_assert(quad_lds_bytes() <= (size_t)160 * 1024, "the quad walk's LDS");
+static_assert(kQuadQT == 8 && (kQuadAccBytes + (size_t)kBpCap * 8) % 16 == 0, "the epilogue reads thresholds and counters 16 bytes at a time");
 // a wave's two link lists live in its 1 KB of the sort buffer: 64 descriptors each, of which 4 * kQuadOverRead are the null ones a walk over-reads
 constexpr int kQuadListCap = 64 - 4 * kQuadOverRead, kQuadListBytes = (kQuadListCap + 4 * kQuadOverRead) * 8;
 static_assert(kQuadListCap >= 16, "room for links in a wave's list");
@@ -370,17 +375,43 @@ __global__ __launch_bounds__(kScanThreads) void bp_quad_topk(BpArgs a) {
             // epilogue: 1024 documents at a time, one per thread: its QT sums -> order keys -> candidates; prune when a buffer could overflow
             for (int d0 = 0; d0 < rows_b || d0 == 0; d0 += kScanThreads) {
                 const int d = d0 + tid;
+                // (LDS instructions are what the epilogue costs -- 16 waves x 2 rounds a block: the 8 threshold halves in four 16-byte reads,
+                //  a document's 8 sums read AND zeroed by four ds_wrxchg2_rtn_b32, the 8 counters below in two 16-byte reads: 10 instead of 32)
                 uint32_t thi[QT];
+                {
+                    const uint4* t4 = reinterpret_cast<const uint4*>(tau);
 #pragma unroll
-                for (int q = 0; q < QT; ++q) thi[q] = (uint32_t)(tau[q] >> 32);
+                    for (int i = 0; i < QT / 2; ++i) { const uint4 t = t4[i]; thi[2 * i] = t.y; thi[2 * i + 1] = t.w; }
+                }
                 if (d < rows_b) {
                     const int64_t row = b * a.rows + d;
-                    int32_t* pa = acc + quad_acc_index((uint32_t)d);
                     int32_t sums[QT];
+#if VS_QUAD_EPI == 0
+                    int32_t* pa = acc + quad_acc_index((uint32_t)d);
 #pragma unroll
                     for (int q = 0; q < QT; ++q) sums[q] = pa[q * 16];
 #pragma unroll
                     for (int q = 0; q < QT; ++q) pa[q * 16] = 0;
+#elif VS_QUAD_EPI == 1
+                    {
+                        const uint32_t pa = quad_acc_index((uint32_t)d) * 4u, zero = 0u;      // LDS byte address (the accumulators start at 0)
+                        asm volatile("ds_wrxchg_rtn_b32 %0, %8, %9\n\tds_wrxchg_rtn_b32 %1, %8, %9 offset:64\n\tds_wrxchg_rtn_b32 %2, %8, %9 offset:128\n\t"
+                                     "ds_wrxchg_rtn_b32 %3, %8, %9 offset:192\n\tds_wrxchg_rtn_b32 %4, %8, %9 offset:256\n\tds_wrxchg_rtn_b32 %5, %8, %9 offset:320\n\t"
+                                     "ds_wrxchg_rtn_b32 %6, %8, %9 offset:384\n\tds_wrxchg_rtn_b32 %7, %8, %9 offset:448\n\ts_waitcnt lgkmcnt(0)"
+                                     : "=&v"(sums[0]), "=&v"(sums[1]), "=&v"(sums[2]), "=&v"(sums[3]), "=&v"(sums[4]), "=&v"(sums[5]), "=&v"(sums[6]), "=&v"(sums[7])
+                                     : "v"(pa), "v"(zero) : "memory");
+                    }
+#else
+                    {
+                        const uint32_t pa = quad_acc_index((uint32_t)d) * 4u, zero = 0u;
+                        unsigned long long s01, s23, s45, s67;
+                        asm volatile("ds_wrxchg2_rtn_b32 %0, %4, %5, %5 offset0:0 offset1:16\n\tds_wrxchg2_rtn_b32 %1, %4, %5, %5 offset0:32 offset1:48\n\t"
+                                     "ds_wrxchg2_rtn_b32 %2, %4, %5, %5 offset0:64 offset1:80\n\tds_wrxchg2_rtn_b32 %3, %4, %5, %5 offset0:96 offset1:112\n\ts_waitcnt lgkmcnt(0)"
+                                     : "=&v"(s01), "=&v"(s23), "=&v"(s45), "=&v"(s67) : "v"(pa), "v"(zero) : "memory");
+                        sums[0] = (int32_t)(uint32_t)s01; sums[1] = (int32_t)(uint32_t)(s01 >> 32); sums[2] = (int32_t)(uint32_t)s23; sums[3] = (int32_t)(uint32_t)(s23 >> 32);
+                        sums[4] = (int32_t)(uint32_t)s45; sums[5] = (int32_t)(uint32_t)(s45 >> 32); sums[6] = (int32_t)(uint32_t)s67; sums[7] = (int32_t)(uint32_t)(s67 >> 32);
+                    }
+#endif
 #pragma unroll
                     for (int q = 0; q < QT; ++q) {
                         const uint32_t hi = (uint32_t)sums[q] ^ 0x80000000u;
@@ -396,8 +427,11 @@ __global__ __launch_bounds__(kScanThreads) void bp_quad_topk(BpArgs a) {
                 lds_barrier();                                          // (the counters and sums are LDS; candidates other threads stored are read only when a prune follows)
                 const bool last = b + 1 >= b1 && d0 + kScanThreads >= rows_b;
                 uint32_t cnts[QT];
-#pragma unroll
-                for (int q = 0; q < QT; ++q) cnts[q] = ccnt[q];
+                {
+                    const uint4* c4 = reinterpret_cast<const uint4*>(ccnt);
+                    const uint4 c0 = c4[0], c1 = c4[1];
+                    cnts[0] = c0.x; cnts[1] = c0.y; cnts[2] = c0.z; cnts[3] = c0.w; cnts[4] = c1.x; cnts[5] = c1.y; cnts[6] = c1.z; cnts[7] = c1.w;
+                }
                 bool any = last;
 #pragma unroll
                 for (int q = 0; q < QT; ++q) any = any || cnts[q] > (uint32_t)(kBpCap - kScanThreads);

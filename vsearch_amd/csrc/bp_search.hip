@@ -14,6 +14,7 @@
 namespace vs { constexpr int kDuoMaxK = 0, kDuoEntCap = 0, kDuoQT = 4; }
 #endif
 #include "bp_quad.h"
+#include "bp_head.h"
 
 #include <chrono>
 #include <vector>
@@ -35,6 +36,8 @@ void bp_release(vs_index* idx) {
     idx->bp_dir.release(); idx->bp_base.release(); idx->bp_rec.release(); idx->bp_df.release(); idx->bp_vmax.release();
     idx->bp_hmap.release(); idx->bp_strip.release();
     idx->bp_n_head = 0;
+    idx->bp_head_gemm = false;
+    idx->ws_head_w.release(); idx->ws_head_out.release();
     idx->bp_quad = false;
     idx->bp_ready = false;
 }
@@ -94,6 +97,13 @@ int launch_bp_walk(const vs_index* idx, const BpArgs& a, int grid, int ent_cap, 
         // entries, 13 chunks a block on the Wiki21M shape, 16.4 k q/s; 4: 25 chunks for 16 waves, 13.0 k)
         kern = idx->bp_lanes == 4 ? bp_walk_topk<VM_BIN, kBpBinQT, AM_FIX, 1, kBpRowsMaxBin, 4> : bp_walk_topk<VM_BIN, kBpBinQT, AM_FIX, 1, kBpRowsMaxBin, 8>;
         lds = bp_lds_bytes<kBpBinQT, AM_FIX, kBpRowsMaxBin>(ent_cap);
+    } else if (AM == AM_FIX && a.n_head > 0 && a.head_out) {
+        // head columns served by the head pre-pass (bp_head.h): the list walk adds its sums in the epilogue; no strip weights in LDS
+        if constexpr (AM == AM_FIX) {
+            if (vm == VM_F32) kern = idx->bp_lanes != 4 ? bp_walk_topk<VM_F32, QT, AM_FIX, 8, kBpRowsMax, kBpNB, 2> : bp_walk_topk<VM_F32, QT, AM_FIX, 4, kBpRowsMax, kBpNB, 2>;
+            else kern = idx->bp_lanes != 4 ? bp_walk_topk<VM_F16, QT, AM_FIX, 8, kBpRowsMax, kBpNBWide, 2> : bp_walk_topk<VM_F16, QT, AM_FIX, 4, kBpRowsMax, kBpNB, 2>;
+        }
+        lds = bp_lds_bytes<QT, AM, kBpRowsMax>(ent_cap, 0);
     } else if (AM == AM_FIX && a.n_head > 0) {
         if constexpr (AM == AM_FIX) {
             if (vm == VM_F32) kern = idx->bp_lanes != 4 ? bp_walk_topk<VM_F32, QT, AM_FIX, 8, kBpRowsMax, kBpNB, 1> : bp_walk_topk<VM_F32, QT, AM_FIX, 4, kBpRowsMax, kBpNB, 1>;
@@ -225,13 +235,19 @@ int bp_build(vs_index* idx, hipStream_t s) {
         DevBuf nh;
         VS_TRY(nh.alloc(4));
         VS_TRY(idx->bp_hmap.alloc((size_t)V * 2));
-        hipLaunchKernelGGL(bp_head_select_kernel<0>, dim3(1), dim3(kScanThreads), 0, s, df_nnz, V, (unsigned long long)ceil_div64(idx->n_rows, idx->bp_head_pref > 0 ? idx->bp_head_pref : 4), kBpHeadCap,
+        // head pre-pass (bp_head.h, default): columns in >= 1/8 of the documents, up to 1024; multiplied inside the walk: >= 1/4, up to 512
+        static const int gemm_env = getenv("VS_BP_HEAD_GEMM") ? atoi(getenv("VS_BP_HEAD_GEMM")) : -2;   // (developer override of "postings_head_gemm")
+        if (gemm_env > -2) idx->bp_head_gemm_pref = gemm_env;
+        const bool gemm = idx->bp_head_gemm_pref != 0 && kQT == 8;
+        hipLaunchKernelGGL(bp_head_select_kernel<0>, dim3(1), dim3(kScanThreads), 0, s, df_nnz, V,
+                           (unsigned long long)ceil_div64(idx->n_rows, idx->bp_head_pref > 0 ? idx->bp_head_pref : (gemm ? 8 : 4)), gemm ? kBpHeadCapGemm : kBpHeadCap,
                            idx->bp_hmap.as<uint16_t>(), nh.as<int32_t>());
         VS_HIP(hipGetLastError());
         int32_t h_n = 0;
         VS_HIP(hipMemcpyAsync(&h_n, nh.p, 4, hipMemcpyDeviceToHost, s));
         VS_HIP(hipStreamSynchronize(s));
         idx->bp_n_head = h_n;
+        idx->bp_head_gemm = gemm && h_n > 0;
         if (h_n > 0 && quad) {                                  // head columns: records + dense strips (the list walk)
             idx->bp_no_quad = true;
             return bp_build(idx, s);
@@ -461,7 +477,29 @@ int bp_filter_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64
     VS_HIP(hipGetLastError());
     VS_STAGE("sparsify", s);
     // 2. the walk.  Work items = (tile, chunk); the tile count lives on the device, the chunks follow its lower bound ceil(B / qt)
-    const int n_tiles_est = ceil_div(B, qt);
+    // Head pre-pass (bp_head.h): the walk runs in PASSES over ranges of tiles, each behind the matrix product that writes the dense part
+    // of its tiles' sums (64 KB per tile and block) to a scratch array -- as many tiles per pass as the scratch HBM has room for.
+    const bool head_gemm = idx->bp_n_head > 0 && idx->bp_head_gemm;
+    int tiles_per_pass = 0, n_pass = 1;
+    const int head_ks = bp_head_pad(idx->bp_n_head) / 32;
+    if (head_gemm) {
+        const size_t per_tile = (size_t)n_blocks * (size_t)idx->bp_rows * 8 * 4;
+        size_t free_b = 0, total_b = 0;
+        VS_HIP(hipMemGetInfo(&free_b, &total_b));
+        const size_t have = idx->ws_head_out.bytes, margin = (size_t)6 << 30;
+        const size_t room = free_b + have > margin ? free_b + have - margin : 0;
+        static const int tpp_env = getenv("VS_HEAD_TILES") ? atoi(getenv("VS_HEAD_TILES")) : 0;      // (developer: tiles per pass)
+        int tpp = (int)std::min<size_t>(std::max<size_t>(have, std::min<size_t>(room, (size_t)48 << 30)) / std::max<size_t>(per_tile, 1), (size_t)ceil_div(B, qt));
+        if (tpp_env > 0) tpp = std::min(tpp, tpp_env);
+        if (idx->bp_head_tiles > 0) tpp = std::min(tpp, idx->bp_head_tiles);
+        if (tpp >= 32) tpp = tpp / 32 * 32;                                   // whole groups of the product's workgroups (4 waves x 8 tiles)
+        if (tpp < 1) return fail(VS_ENOMEM, "head pre-pass: no HBM for the dense sums of one tile (%.2f GB)", (double)per_tile / 1e9);
+        tiles_per_pass = tpp;
+        VS_TRY(idx->ws_head_out.reserve((size_t)tpp * per_tile));
+        VS_TRY(idx->ws_head_w.reserve((size_t)tpp * head_ks * 1024));
+        n_pass = ceil_div(B, tpp);                                           // (a tile holds >= 1 query: passes beyond the batch's tiles return at once)
+    }
+    const int n_tiles_est = head_gemm ? std::min(tiles_per_pass, ceil_div(B, qt)) : ceil_div(B, qt);
     const int nchunk = bp_choose_chunks(idx, n_tiles_est, n_blocks, plan.nchunk);
     const int nchunk_fb = (int)std::min<int64_t>(n_blocks, 64);
     const int grid = (int)std::min<int64_t>((int64_t)B * nchunk, idx->cu_count);
@@ -532,7 +570,45 @@ int bp_filter_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64
         VS_HIP(hipMemsetAsync(timing.p, 0, 128 + (size_t)grid * 32, s));
         a.timing = timing.as<unsigned long long>();
     }
-    {
+    for (int pass = 0; pass < n_pass; ++pass) {
+        if (head_gemm) {
+            HeadArgs h{};
+            h.strip = a.strip;
+            h.wt = idx->ws_head_w.as<uint4>();
+            h.out = idx->ws_head_out.as<int32_t>();
+            h.tiles = tiles;
+            h.n_tiles_dev = a.n_tiles_dev;
+            h.tile0 = pass * tiles_per_pass;
+            h.tile_cnt = tiles_per_pass;
+            h.qptr = qptr; h.qcols = qcols; h.qvals = qvals; h.qscale = qscale;
+            h.hmap = a.hmap;
+            h.n_head = a.n_head;
+            h.rows = idx->bp_rows;
+            h.n_rows = idx->n_rows;
+            h.n_blocks = n_blocks;
+            h.head_pre = a.head_pre; h.head_mul = a.head_mul;
+            a.head_out = h.out;
+            a.tile0 = h.tile0;
+            a.tile_cnt = tiles_per_pass;
+            if (a.pace && pass > 0) VS_HIP(hipMemsetAsync(idx->ws_pace.p, 0, (size_t)nchunk * a.blocks_per_chunk * 4, s));
+            ProfScope prof("head_gemm", s);
+            hipLaunchKernelGGL(head_weights_kernel<0>, dim3(tiles_per_pass), dim3(256), 0, s, h);
+            static const int shape_env = getenv("VS_HEAD_SHAPE") ? atoi(getenv("VS_HEAD_SHAPE")) : 24;     // (developer: waves of a workgroup, documents x tiles)
+            const int hgrid = idx->cu_count * (shape_env == 14 || shape_env == 22 ? 2 : 1);
+            if (shape_env == 18) hipLaunchKernelGGL((head_gemm_kernel<1, 8>), dim3(hgrid), dim3(512), 0, s, h);
+            else if (shape_env == 42) hipLaunchKernelGGL((head_gemm_kernel<4, 2>), dim3(hgrid), dim3(512), 0, s, h);
+            else if (shape_env == 14) hipLaunchKernelGGL((head_gemm_kernel<1, 4>), dim3(hgrid), dim3(256), 0, s, h);
+            else if (shape_env == 22) hipLaunchKernelGGL((head_gemm_kernel<2, 2>), dim3(hgrid), dim3(256), 0, s, h);
+            else if (shape_env == 240) hipLaunchKernelGGL((head_gemm_kernel<2, 4>), dim3(hgrid), dim3(512), 0, s, h);
+            else {
+                // (default) operands through LDS by LDS-DMA: 2 x 4 waves, 3 images of 40 KB
+                constexpr size_t hl = head_gemm_lds_bytes<2, 4, 3>();
+                void (*hk)(HeadArgs) = head_gemm_lds_kernel<2, 4, 3>;
+                VS_HIP(hipFuncSetAttribute((const void*)hk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hl));
+                hipLaunchKernelGGL(hk, dim3(hgrid), dim3(512), hl, s, h);
+            }
+            VS_HIP(hipGetLastError());
+        }
         ProfScope prof("csr_scan_topk", s);
         VS_TRY((launch_bp_walk<kQT, AM_FIX>(idx, a, grid, vals_cap, s)));
     }

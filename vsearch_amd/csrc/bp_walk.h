@@ -128,7 +128,8 @@ __global__ __launch_bounds__(kScanThreads) void bp_count_kernel(const uint32_t* 
 // cores -- than as a 2048-posting list of scatter-adds (an LDS atomic costs ~20 lane-cycles).  Measured per block and tile:
 // ~95 clocks per head column (the strip streams from L2 at ~26 TB/s chip-wide) against 4 800 p^2 for a list of density p, so
 // the lists win below p ~ 1/7; the default threshold is 1/4.  hmap[c] = strip index of column c, 0xFFFF = ordinary column.
-constexpr int kBpHeadCap = 512;
+constexpr int kBpHeadCap = 512;          // multiplied inside the walk (their weights live in its LDS)
+constexpr int kBpHeadCapGemm = 1024;     // served by the head pre-pass (bp_head.h)
 // One workgroup.  Deterministic: when more than `cap` columns reach `thresh`, the threshold rises to the smallest document
 // count that leaves at most `cap` of them; strip indexes follow column order.
 template <int UNUSED>
@@ -200,6 +201,10 @@ __global__ __launch_bounds__(kScanThreads) void bp_base_kernel(const uint32_t* b
 // so a wave reads one operand with ONE coalesced 1 KB load and the 8 operands of its 128 documents from 8 KB contiguous.
 // n_head rounds up to 32 columns (the pad columns are zero).
 __host__ __device__ inline int bp_head_pad(int n_head) { return (n_head + 31) & ~31; }
+// head pre-pass output (bp_head.h): [tile of the pass][block][document / 16][slot 8][16 documents] int32 -> offset of (document d, slot 0)
+__host__ __device__ inline size_t head_out_offset(int64_t tile_rel, int64_t n_blocks, int64_t b, int rows, int d) {
+    return (((size_t)tile_rel * (size_t)n_blocks + (size_t)b) * (size_t)(rows / 16) + (size_t)(d >> 4)) * 128 + (size_t)(d & 15);
+}
 __host__ __device__ inline size_t bp_strip_index(int64_t b, int h, int dl, int n_head, int rows) {
     const size_t ks = (size_t)bp_head_pad(n_head) / 32, mb = (size_t)rows / 16;
     const size_t unit = (((size_t)b * ks + (size_t)(h >> 5)) * mb + (size_t)(dl >> 4)) * 64 + (size_t)(((h & 31) >> 3) * 16 + (dl & 15));
@@ -434,6 +439,8 @@ struct BpArgs {
     const __half* strip;      // fp16 values of the head columns, MFMA operand order (bp_strip_index)
     int32_t n_head;
     float head_pre, head_mul; // powers of two: weights enter the fp16 operand as w * scale * head_pre (< 2^15), the sums leave as C * head_mul
+    const int32_t* head_out;  // HD = 2 (head pre-pass, bp_head.h): the dense part of the sums, [tile - tile0][block][document / 16][slot][16] int32
+    int32_t tile0, tile_cnt;  // tile_cnt > 0: this launch walks tiles [tile0, tile0 + tile_cnt) only (the passes of the head pre-pass)
     uint32_t* pace;           // optional [nchunk][blocks_per_chunk], zeroed per search: work items that have finished a block (flat walk: lock-step window)
     int32_t pace_window;      // blocks an item may run ahead of the slowest item of its chunk
     int32_t knob;             // developer switches (VS_BP_KNOB)
@@ -536,10 +543,11 @@ __device__ __forceinline__ uint32_t quad_bcast(uint32_t x) {          // lane U 
 
 // LG = lanes per posting list (8 for the long lists of a valued index, 1 for the short lists of the bag-of-token index),
 // RMAX = block capacity in documents
-// HD = 1: the index has head columns (dense strips); 0 compiles that path out.
+// HD = 1: the index has head columns (dense strips) multiplied in this kernel, one tile at a time; HD = 2: their part of the sums was
+// computed by the head pre-pass (bp_head.h) and is added in the epilogue; 0 compiles both out.
 template <int VM, int QT, int AM, int LG, int RMAX, int NB = kBpNB, int HD = 0>
 __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
-    static_assert(!HD || (AM == AM_FIX && VM != VM_BIN), "dense strips: valued filter walk only");
+    static_assert(!HD || (AM == AM_FIX && VM != VM_BIN && QT == 8), "dense strips: valued filter walk only");
     static_assert(bp_acc_bytes<QT, AM, RMAX>() >= kBpSortBytes, "the accumulator area holds the 8192-slot entry sort");
     static_assert(VM != VM_BIN || RMAX == kBpRowsMaxBin, "pad postings of a binary list carry document id kBpRowsMaxBin");
     static_assert(NB % LG == 0 || LG % NB == 0 || (LG == 8 && NB <= 8), "lane l of a group owns the directory words of lists l, l + LG, ... of a slot");
@@ -566,14 +574,17 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
     const int K = a.k;
     uint64_t* my_gcand = a.gcand + (size_t)blockIdx.x * QT * kBpCap;
     const int64_t n_blocks = (a.n_rows + a.rows - 1) / a.rows;
-    const int64_t items = (int64_t)(a.n_tiles_dev ? a.n_tiles_dev[0] : a.n_tiles) * a.nchunk;
+    int n_tiles_all = a.n_tiles_dev ? a.n_tiles_dev[0] : a.n_tiles;
+    if (a.tile_cnt > 0) n_tiles_all = max(0, min(n_tiles_all - a.tile0, a.tile_cnt));       // a pass over a range of tiles
+    const int64_t items = (int64_t)n_tiles_all * a.nchunk;
     bool pace_off = false;                      // the lock-step wait timed out once (pace_wait): this workgroup runs free from then on
     const size_t dir_ld = (size_t)a.n_cols + 1;
 
     const unsigned long long k_rt0 = a.timing ? __builtin_amdgcn_s_memrealtime() : 0ull;
     // Work items = (tile, chunk), taken round-robin (the host picks nchunk so that an XCD keeps to few chunks, see the launch)
     for (int64_t item = blockIdx.x; item < items; item += gridDim.x) {
-        const int tile = (int)(item / a.nchunk), c = (int)(item % a.nchunk);
+        const int tile_rel = (int)(item / a.nchunk), c = (int)(item % a.nchunk);
+        const int tile = (a.tile_cnt > 0 ? a.tile0 : 0) + tile_rel;
         const int q0 = a.tiles[tile].x, nq = a.tiles[tile].y;
         long long tm = a.timing ? (long long)__builtin_readcyclecounter() : 0;
         uint32_t tacc[6] = {0u, 0u, 0u, 0u, 0u, 0u};              // (flushed once per item: 6 atomics per wave)
@@ -590,7 +601,7 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
         int n_ent = (int)(e1 - e0);
         const int n_head = HD ? a.n_head : 0;
         const int ldb = bp_head_pad(n_head) + 8;                 // + 8 halves: the 16 rows a b128 operand read touches fall in different banks
-        if (n_head > 0) {
+        if (HD == 1 && n_head > 0) {
             uint32_t* z = reinterpret_cast<uint32_t*>(hw);
             for (int i = tid; i < 16 * ldb / 2; i += kScanThreads) z[i] = 0u;
             __syncthreads();
@@ -611,10 +622,13 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
                     const uint32_t hx = n_head > 0 ? a.hmap[col] : 0xFFFFu;
                     if (hx != 0xFFFFu) {
                         // a head column: no list to walk, its weight joins the dense part as two fp16 numbers hi + lo (22 bits)
-                        const float ws = w * a.head_pre;
-                        const _Float16 hi = (_Float16)ws;
-                        hw[qs * ldb + hx] = hi;
-                        hw[(8 + qs) * ldb + hx] = (_Float16)(ws - (float)hi);
+                        // (HD = 2: the head pre-pass has multiplied it already)
+                        if constexpr (HD == 1) {
+                            const float ws = w * a.head_pre;
+                            const _Float16 hi = (_Float16)ws;
+                            hw[qs * ldb + hx] = hi;
+                            hw[(8 + qs) * ldb + hx] = (_Float16)(ws - (float)hi);
+                        }
                     }
                     else {
                         // Lists of similar length are dealt together: the sort key leads with a length class (rounds of the group's
@@ -684,7 +698,7 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
         // ... and for the headless valued kernels too since the waves take chunks dynamically (B = 16 at 21 M docs: -4 %, B = 1024:
         // -0.3 %; before, with static dealing, holding the words across the epilogue cost more than it hid).  Not with dense chunks:
         // there the kind of a wave's first chunk depends on the block.
-        const bool pairs_ahead = kPairsAhead || HD == 0;
+        const bool pairs_ahead = kPairsAhead || HD != 1;
         if (pairs_ahead && b0 < b1) first_pairs(b0, wv_id);          // (no dense chunks: chunk = list chunk)
         for (int64_t b = b0; b < b1 || b == b0; ++b) {
             const bool have = b < b1;
@@ -706,16 +720,16 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
                 // them, and a wave streaming a strip from L2 runs next to waves whose time goes into LDS adds.
                 const int n_lc = (n_ent + CW - 1) / CW;
                 constexpr int kDenseDocs = 64;                      // documents of a dense chunk (4 operand rows; 32: re-reads the weights twice as often and streams worse -- 489 vs 370 ms at 21 M docs)
-                const int n_dc = (HD && n_head > 0) ? (rows_b + kDenseDocs - 1) / kDenseDocs : 0;
+                const int n_dc = (HD == 1 && n_head > 0) ? (rows_b + kDenseDocs - 1) / kDenseDocs : 0;
                 const int n_ch = n_lc + n_dc;
                 // chunk c is dense iff floor((c + 1) n_dc / n_ch) > floor(c n_dc / n_ch); floor(c n_dc / n_ch) dense chunks precede it
                 auto dense_before = [&](int c) { return (int)(((uint32_t)c * (uint32_t)n_dc) / (uint32_t)max(n_ch, 1)); };
                 auto list_index = [&](int c) {
-                    if constexpr (HD == 0) return c < n_ch ? c : -1;              // (no dense chunks: no division in the headless kernels)
+                    if constexpr (HD != 1) return c < n_ch ? c : -1;              // (no dense chunks: no division in the headless kernels)
                     else return (c < n_ch && dense_before(c + 1) == dense_before(c)) ? c - dense_before(c) : -1;
                 };
                 [[maybe_unused]] auto dense_chunk = [&](int dj) {
-                    if constexpr (HD != 0) {
+                    if constexpr (HD == 1) {
                         static_assert(QT == 8 && RMAX == 16 * 128, "dense part: 8 slots x (hi, lo) = the 16 columns of the MFMA");
                         // [64 documents] x [head columns] (fp16 strip, MFMA A-operand order) times [head columns] x [8 slots x (hi, lo)]
                         // (the tile's weights) -- v_mfma_f32_16x16x32_f16, fp32 accumulate; the strip streams from L2 / Infinity
@@ -948,8 +962,19 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
                     const int64_t row = b * a.rows + d;
                     acc_t* pa = acc + (size_t)d * PITCH;
                     acc_t sums[QT];
+                    [[maybe_unused]] int32_t pre[QT];
+                    if constexpr (HD == 2) {
+                        // the dense part of this document's sums (head pre-pass): 8 loads of a slot's 16-document run, in flight together
+                        const int32_t* hp = a.head_out + head_out_offset((int64_t)tile_rel, n_blocks, b, a.rows, d);
+#pragma unroll
+                        for (int q = 0; q < QT; ++q) pre[q] = q < nq ? hp[q * 16] : 0;
+                    }
 #pragma unroll
                     for (int q = 0; q < QT; ++q) sums[q] = pa[q];         // independent reads, in flight together
+                    if constexpr (HD == 2 && AM == AM_FIX) {
+#pragma unroll
+                        for (int q = 0; q < QT; ++q) sums[q] += (acc_t)pre[q];
+                    }
 #pragma unroll
                     for (int q = 0; q < QT; ++q) pa[q] = (acc_t)0;
 #pragma unroll

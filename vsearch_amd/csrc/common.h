@@ -213,6 +213,10 @@ struct vs_index {
     vs::DevBuf bp_strip; // fp16 [n_blocks][bp_n_head][bp_rows]: values of the head columns
     int bp_n_head = 0;
     float bp_vmax_f = 1.f;   // max |value| of the index (bp_build)
+    int bp_head_gemm_pref = -1;   // option "postings_head_gemm": -1 auto (= 1), 1 = the head columns' part of the sums by the head pre-pass (bp_head.h: up to 1024 columns
+                                  // present in >= 1/8 of the documents), 0 = multiplied inside the walk, tile by tile (up to 512 columns in >= 1/4)
+    int bp_head_tiles = 0;        // option "postings_head_tiles": tiles per pass of the head pre-pass (0 = as many as the scratch HBM holds)
+    bool bp_head_gemm = false;    // this copy's strips are served by the head pre-pass
     int bp_head_pref = -1;   // option "postings_head": -1 auto (columns present in >= 1/4 of the documents, at most 512), 0 = none, N = share 1/N
     vs::DevBuf bp_vmax;  // [2] uint32: float bits of max |value| (bounds the fixed-point walk's products), any-value-negative flag
     int bp_lanes = 0;    // option "postings_lanes": lanes per posting list of a valued index (4 | 8, auto = 8); binary index: records in flight per lane (auto = 8)
@@ -248,6 +252,7 @@ struct vs_index {
     vs::DevBuf mat;      // [n_rows, n_cols] store_dtype
     // scratch owned by the handle (grow-only)
     vs::DevBuf ws_q, ws_cand, ws_out_ids, ws_out_scores, ws_misc, ws_mq_meta, ws_mq_q, ws_mq_cand, ws_fb, ws_pace;
+    vs::DevBuf ws_head_w, ws_head_out;   // head pre-pass (bp_head.h): the pass's weight operands, the dense part of the sums
     bool logical_dense = false;   // dense Index stored as CSR packets (sparsity-aware dense index)
     int qt_pref = 0;     // 0 = auto (multi-query pass when the batch qualifies), 1 = force the dense-image pass
     int last_qt = 0;     // queries per pass of the most recent search
