@@ -173,6 +173,7 @@ __global__ __launch_bounds__(kScanThreads) void refine_topk_kernel(RefineArgs a)
                 // Quantised records (values v >= 0 stored as fp16(v), weights w >= 0): |v - fp16(v)| <= 2^-11 v + 2^-25, so the exact sum
                 // E of a document and the sum Q over its stored values satisfy E (1 - 2^-11) <= Q + 2^-25 sum |w|.
                 if (a.quant) bound = (bound + (double)a.qwsum[b] * 0x1p-25) / (1.0 - 0x1p-11);
+                if (a.quant >= 2) bound = bound / (1.0 - 0x1p-11);          // head weights rounded to ONE fp16 number: 2^-11 relative once more
                 float bf = (float)bound;
                 if ((double)bf < bound) bf = nextafterf(bf, INFINITY);
                 ok = ex[K - 1] != 0ull && key_score(ex[K - 1]) > bf;

@@ -492,11 +492,12 @@ int bp_filter_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64
         int tpp = (int)std::min<size_t>(std::max<size_t>(have, std::min<size_t>(room, (size_t)48 << 30)) / std::max<size_t>(per_tile, 1), (size_t)ceil_div(B, qt));
         if (tpp_env > 0) tpp = std::min(tpp, tpp_env);
         if (idx->bp_head_tiles > 0) tpp = std::min(tpp, idx->bp_head_tiles);
-        if (tpp >= 32) tpp = tpp / 32 * 32;                                   // whole groups of the product's workgroups (4 waves x 8 tiles)
+        if (tpp >= 64) tpp = tpp / 64 * 64;                                   // whole groups of the product's workgroups (4 tile waves x 16 tiles)
+        else if (tpp >= 2) tpp &= ~1;                                          // (a weight operand holds two tiles: passes start on even tiles)
         if (tpp < 1) return fail(VS_ENOMEM, "head pre-pass: no HBM for the dense sums of one tile (%.2f GB)", (double)per_tile / 1e9);
         tiles_per_pass = tpp;
         VS_TRY(idx->ws_head_out.reserve((size_t)tpp * per_tile));
-        VS_TRY(idx->ws_head_w.reserve((size_t)tpp * head_ks * 1024));
+        VS_TRY(idx->ws_head_w.reserve((size_t)((tpp + 1) / 2) * head_ks * 1024));
         n_pass = ceil_div(B, tpp);                                           // (a tile holds >= 1 query: passes beyond the batch's tiles return at once)
     }
     const int n_tiles_est = head_gemm ? std::min(tiles_per_pass, ceil_div(B, qt)) : ceil_div(B, qt);
@@ -599,14 +600,7 @@ int bp_filter_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64
             else if (shape_env == 42) hipLaunchKernelGGL((head_gemm_kernel<4, 2>), dim3(hgrid), dim3(512), 0, s, h);
             else if (shape_env == 14) hipLaunchKernelGGL((head_gemm_kernel<1, 4>), dim3(hgrid), dim3(256), 0, s, h);
             else if (shape_env == 22) hipLaunchKernelGGL((head_gemm_kernel<2, 2>), dim3(hgrid), dim3(256), 0, s, h);
-            else if (shape_env == 240) hipLaunchKernelGGL((head_gemm_kernel<2, 4>), dim3(hgrid), dim3(512), 0, s, h);
-            else {
-                // (default) operands through LDS by LDS-DMA: 2 x 4 waves, 3 images of 40 KB
-                constexpr size_t hl = head_gemm_lds_bytes<2, 4, 3>();
-                void (*hk)(HeadArgs) = head_gemm_lds_kernel<2, 4, 3>;
-                VS_HIP(hipFuncSetAttribute((const void*)hk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hl));
-                hipLaunchKernelGGL(hk, dim3(hgrid), dim3(512), hl, s, h);
-            }
+            else hipLaunchKernelGGL((head_gemm_kernel<2, 4>), dim3(hgrid), dim3(512), 0, s, h);
             VS_HIP(hipGetLastError());
         }
         ProfScope prof("csr_scan_topk", s);
@@ -689,6 +683,7 @@ int bp_filter_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64
     r.qslack = qslack;
     r.qwsum = qwsum;
     r.quant = (idx->bp_quant || idx->bp_n_head > 0) ? 1 : 0;       // fp16-rounded values in the records and / or the dense strips
+    if (head_gemm) r.quant = 2;                                     // ... and the head pre-pass's weights rounded to one fp16 number each (bp_head.h)
     r.force_flag = idx->bp_force_fb ? 1 : 0;
     r.id_offset = id_offset;
     r.out_ids = d_ids;
