@@ -41,7 +41,7 @@ LDS_ADD_U32_RANDOM = 5.0e12  # the same at random addresses (profiles/r02_lds_sc
 L2_PEAK_GBS = 34500.0        # aggregate L2 -> L1 bandwidth, 256 CUs x 64 B / clk (MI355X_MICROARCH.md): the bound of a walk whose bytes are L2-served
 SHADER_CLOCK_HZ = 2.4e9      # (cycles-per-chunk figures are quoted at this clock)
 MFMA_F32_PEAK_TF = 157.3     # fp32-input MFMA = the fp32 vector peak (MI355X_MICROARCH.md)
-WALK_KERNEL = {-1: "csr_scan_topk_mq", 0: "bp_walk_topk", 4: "bp_quad_topk", 5: "bp_bin_topk"}     # vs_index_info_t.postings_walk -> the filter's kernel
+WALK_KERNEL = {-1: "csr_scan_topk_mq", 0: "bp_walk_topk", 4: "bp_quad_topk", 5: "bp_bin_topk", 6: "bp_bq_topk"}     # vs_index_info_t.postings_walk -> the filter's kernel
 
 
 def parse():

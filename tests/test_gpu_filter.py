@@ -231,23 +231,28 @@ def test_signed_values_and_weights():
     compare.check_topk_valid(allsc, got[0], got[1], rtol=RTOL)
 
 
-@pytest.mark.parametrize("nnz", [86, 600], ids=["short-lists", "long-lists"])
+@pytest.mark.parametrize("nnz", [86, 200, 600], ids=["short-lists", "linked-lists", "long-lists"])
 @pytest.mark.parametrize("law", [synth.VAL_DYADIC, synth.VAL_GRID], ids=["dyadic", "fp32-weights"])
 def test_binary_index_on_the_postings_walk(law, nnz):
     """Bag-of-token index (no values): dyadic weights are exact in fixed point (nothing to prove, scores and ids bit-equal to the
     oracle); arbitrary fp32 weights go through the refine step.  600 tokens a document: lists of ~40 postings, five records --
-    the walk's path for lists beyond the two prefetched records (bp_bin.h) on every list; and the list walk (postings_walk = 0)."""
+    the walk's path for lists beyond the two prefetched records (bp_bin.h) on every list, and a LINKED chain of three 16-cell chunks
+    per list on the bag-of-token chunks (bp_bq.h, the default copy: postings_walk 6); the records (5) and the list walk (0) as well."""
     n = 30_000 if nnz == 86 else 12_000
     ip, ix, _ = oracle.synth_csr(3, 0, n, V, nnz, synth.KIND_BOT)
     q = oracle.synth_queries(8, 21, val_law=law)
     idx = DeviceIndex.from_csr(ip, ix, None, V)
     ref = _search(idx, q, 100, blocked_postings=0)
     got = _search(idx, q, 100, blocked_postings=1)
-    assert got[2].last_path == 3 and got[2].aux_bytes > 0
+    # (600 tokens a document: 80 k overflow chunks a block, more than a link's 15 bits address -- the build keeps the records;
+    #  200 tokens: lists of ~14 postings, one in four continues in an overflow chunk)
+    chunks = 6 if nnz <= 200 else 5
+    assert got[2].last_path == 3 and got[2].aux_bytes > 0 and got[2].postings_walk == chunks
     assert (got[0] == ref[0]).all() and (got[1] == ref[1]).all()
-    lw = _search(idx, q, 100, blocked_postings=1, postings_walk=0)
+    for walk, kind in ((5, 5), (0, 0), (6, chunks)):
+        lw = _search(idx, q, 100, blocked_postings=1, postings_walk=walk)
+        assert lw[2].last_path == 3 and lw[2].postings_walk == kind and (lw[0] == ref[0]).all() and (lw[1] == ref[1]).all(), walk
     idx.set_option("postings_walk", -1)
-    assert lw[2].last_path == 3 and (lw[0] == ref[0]).all() and (lw[1] == ref[1]).all()
     forced = _search(idx, q, 100, blocked_postings=1, postings_force_fallback=1)
     assert forced[2].last_fallbacks == q.shape[0]
     assert (forced[0] == ref[0]).all() and (forced[1] == ref[1]).all()

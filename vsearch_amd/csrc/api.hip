@@ -151,14 +151,15 @@ extern "C" int vs_index_set_option(vs_index* idx, const char* name, int value) {
         return VS_OK;
     }
     if (n == "postings_walk") {
-        if (value < -1 || value > 4)
-            return fail(VS_EINVAL, "postings_walk: -1 = auto, 4 = quad chunks, 0 = a list per lane group, 1 = flat worklists, 2 = list walk on two accumulator sets, 3 = streamed flat walk");
+        if (value < -1 || value > 6)
+            return fail(VS_EINVAL, "postings_walk: -1 = auto, 4 = quad chunks (valued index), 6 = bag-of-token chunks / 5 = prefetched records (binary index), 0 = a list per lane group, "
+                                   "1 = flat worklists, 2 = list walk on two accumulator sets, 3 = streamed flat walk");
 #ifndef VS_EXPERIMENTAL_WALKS
         if (value >= 1 && value <= 3) return fail(VS_EUNSUPPORTED, "postings_walk %d: the experimental walks are not part of this build (make EXPERIMENTAL=1)", value);
 #endif
         // quad chunks and records are different copies, and auto (-1) picks between them by size: any change rebuilds at the next search
         if (value != idx->bp_walk_pref) {
-            idx->bp_dir.release(); idx->bp_base.release(); idx->bp_rec.release(); idx->bp_quad = false; idx->bp_ready = false; idx->bp_tried = false;
+            idx->bp_dir.release(); idx->bp_base.release(); idx->bp_rec.release(); idx->bp_quad = false; idx->bp_bq = false; idx->bp_ready = false; idx->bp_tried = false;
         }
         idx->bp_walk_pref = value;
         return VS_OK;

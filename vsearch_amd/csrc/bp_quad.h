@@ -51,7 +51,10 @@ static_assert(2 * kQuadListBytes * kScanWaves <= kBpCap * 8, "the link lists fit
 constexpr int kQuadLinked = kQuadCells - 2;
 constexpr double kQuadMaxRatio = 3.0;                              // auto policy: quad chunks while their main area is within this multiple of the CSR bytes (bp_build)
 constexpr int kQuadPaceDefault = 8;                                // lock-step window in blocks (see the walk)
-__host__ __device__ constexpr uint32_t quad_overflow_chunks(uint32_t n) { return n > (uint32_t)kQuadCells ? (n - (uint32_t)kQuadCells + (uint32_t)kQuadLinked - 1u) / (uint32_t)kQuadLinked : 0u; }
+// overflow chunks of a list of n postings: a chunk holds CELLS postings when it is the list's last, LINKED when another follows it
+template <int CELLS, int LINKED>
+__host__ __device__ constexpr uint32_t chunk_overflow(uint32_t n) { return n > (uint32_t)CELLS ? (n - (uint32_t)CELLS + (uint32_t)LINKED - 1u) / (uint32_t)LINKED : 0u; }
+__host__ __device__ constexpr uint32_t quad_overflow_chunks(uint32_t n) { return chunk_overflow<kQuadCells, kQuadLinked>(n); }
 
 // ---- builder --------------------------------------------------------------------------------------------------------
 // A block's chunks: one MAIN chunk per column at chunk index = column -- a tile's descriptors for them are the same in every block,
@@ -61,7 +64,8 @@ __host__ __device__ constexpr uint32_t quad_overflow_chunks(uint32_t n) { return
 // add nothing, to a valid accumulator).  19 lists in 20 end in their main chunk on 768-nnz documents.
 // pass 1, one workgroup per block: postings per column -> overflow chunks, directory (first overflow chunk << 12 | overflow chunks:
 // the fill pass needs it, the search does not), block total (V + overflow chunks)
-template <int UNUSED>
+// (CELLS, LINKED: 64, 62 = quad chunks of a valued index; 16, 15 = the 32-byte chunks of a bag-of-token index, bp_bq.h)
+template <int CELLS, int LINKED>
 __global__ __launch_bounds__(kScanThreads) void quad_count_kernel(const uint32_t* pk_ptr, const uint4* cols, int64_t n_rows, int32_t n_cols, int32_t rows,
                                                                   uint32_t* dir, uint32_t* block_recs, unsigned long long* df_rec, unsigned long long* df_nnz,
                                                                   int32_t* overflow) {
@@ -89,12 +93,12 @@ __global__ __launch_bounds__(kScanThreads) void quad_count_kernel(const uint32_t
         __syncthreads();
         const int i0 = min(n_cols, tid * seg), i1 = min(n_cols, i0 + seg);
         int mine = 0;
-        for (int i = i0; i < i1; ++i) mine += (int)quad_overflow_chunks(cnt[i]);
+        for (int i = i0; i < i1; ++i) mine += (int)chunk_overflow<CELLS, LINKED>(cnt[i]);
         int tot = 0;
         int off = block_excl_scan(mine, scratch, tid, &tot);
         uint32_t* d = dir + (size_t)b * (n_cols + 1);
         for (int i = i0; i < i1; ++i) {
-            const uint32_t c = cnt[i], r = quad_overflow_chunks(c);
+            const uint32_t c = cnt[i], r = chunk_overflow<CELLS, LINKED>(c);
             d[i] = bp_dir_pack((uint32_t)off, r);
             if (r > kBpDirRecMask || (uint32_t)off > kBpDirUnitMax) overflow[0] = 1;
             off += (int)r;

@@ -15,6 +15,7 @@ namespace vs { constexpr int kDuoMaxK = 0, kDuoEntCap = 0, kDuoQT = 4; }
 #endif
 #include "bp_quad.h"
 #include "bp_head.h"
+#include "bp_bq.h"
 
 #include <chrono>
 #include <vector>
@@ -39,6 +40,7 @@ void bp_release(vs_index* idx) {
     idx->bp_head_gemm = false;
     idx->ws_head_w.release(); idx->ws_head_out.release();
     idx->bp_quad = false;
+    idx->bp_bq = false;
     idx->bp_ready = false;
 }
 
@@ -73,6 +75,11 @@ int launch_bp_walk(const vs_index* idx, const BpArgs& a, int grid, int ent_cap, 
         if (AM != AM_FIX || a.upper || ent_cap > kBpEntCap) return fail(VS_EUNSUPPORTED, "quad postings serve the filter walk only");
         kern = a.timing ? bp_quad_topk<1> : bp_quad_topk<0>;
         lds = quad_lds_bytes();
+    } else if (idx->bp_bq) {
+        // bag-of-token chunks (bp_bq.h): the fixed-point filter walk only
+        if (AM != AM_FIX || a.upper || ent_cap > kBpEntCap) return fail(VS_EUNSUPPORTED, "bag-of-token chunks serve the filter walk only");
+        kern = a.timing ? bp_bq_topk<1> : bp_bq_topk<0>;
+        lds = bq_lds_bytes();
 #ifdef VS_EXPERIMENTAL_WALKS
     } else if (AM == AM_FIX && bp_duo_ok(idx, a.k, a.upper) && ent_cap <= kDuoEntCap) {
         if (vm == VM_F32) kern = bp_duo_topk<VM_F32, kBpNB, kBpRowsMax>;
@@ -87,7 +94,7 @@ int launch_bp_walk(const vs_index* idx, const BpArgs& a, int grid, int ent_cap, 
         if (vm == VM_F32) { kern = bp_flat_topk<VM_F32, kFlRoundsF32, kBpRowsMax>; lds = bp_flat_lds_bytes<kFlRoundsF32, kBpRowsMax>(ent_cap); }
         else { kern = bp_flat_topk<VM_F16, kFlRoundsF16, kBpRowsMax>; lds = bp_flat_lds_bytes<kFlRoundsF16, kBpRowsMax>(ent_cap); }
 #endif
-    } else if (vm == VM_BIN && AM == AM_FIX && idx->bp_walk_pref != 0 && !a.upper && ent_cap <= kBpEntCap) {
+    } else if (vm == VM_BIN && AM == AM_FIX && idx->bp_walk_pref != 0 && !a.upper && ent_cap <= kBpEntCap) {          // (records: postings_walk = 5, or no room for the chunks)
         // bag-of-token index: the walk with the next block's records prefetched across the barrier (bp_bin.h); postings_walk = 0: the list walk
         kern = bp_bin_topk<kBpRowsMaxBin>;
         lds = bp_bin_lds_bytes<kBpRowsMaxBin>(ent_cap);
@@ -143,6 +150,10 @@ int bp_build(vs_index* idx, hipStream_t s) {
     const bool quad_dense_enough = idx->bp_walk_pref == 4 || quad_main <= kQuadMaxRatio * csr_bytes;
     const bool quad_pref = idx->store_dtype != VS_NONE && idx->bp_filter != 0 && idx->n_cols <= 32768 && (idx->bp_walk_pref == -1 || idx->bp_walk_pref == 4) && !idx->bp_no_quad &&
                            idx->bp_align_pref != 1 && idx->bp_arrange_pref != 1 && (idx->store_dtype == VS_F16 || idx->bp_quant_pref != 0) && quad_dense_enough;
+    // Bag-of-token chunks (bp_bq.h) -- the default copy of a binary index searched by filter + refine: every (block, column) list is a
+    // direct-mapped 32-byte chunk (n_blocks x n_cols x 32 bytes: 9.7 GB at 21 M docs against 3.6 GB of packets).  "postings_walk" = 5
+    // keeps the records of bp_bin.h, 0 the list walk; when the chunks do not fit HBM the records are built instead.
+    const bool bq_pref = idx->store_dtype == VS_NONE && idx->bp_filter != 0 && idx->n_cols <= 32768 && (idx->bp_walk_pref == -1 || idx->bp_walk_pref == 6) && !idx->bp_no_quad;
     idx->bp_no_quad = false;
     auto auto_rows = [&]() -> int {
         if (idx->store_dtype == VS_NONE) return kBpRowsMaxBin;
@@ -198,6 +209,7 @@ int bp_build(vs_index* idx, hipStream_t s) {
     memcpy(&vmax_f, &hv[0], 4);
     const bool lossy_ok = hv[1] == 0u && vmax_f < 60000.f;       // fp16 copies of the values: non-negative, no overflow
     const bool quad = quad_pref && lossy_ok;                        // (non-negative values: a set sign bit marks a link)
+    const bool bq = bq_pref && idx->bp_rows == kBpRowsMaxBin;        // (the spare documents behind a plane absorb the pad cells: 2048-document blocks)
     // Lossy filter copy of an fp32 index: values rounded to fp16 (4 instead of 6 bytes per posting); needs the filter-and-refine
     // search, non-negative values and no fp16 overflow
     idx->bp_quant = idx->store_dtype == VS_F32 && idx->bp_filter != 0 && idx->bp_quant_pref != 0 && lossy_ok;
@@ -216,8 +228,18 @@ int bp_build(vs_index* idx, hipStream_t s) {
             idx->bp_no_quad = true;
             return bp_build(idx, s);
         }
-        VS_HIP(hipFuncSetAttribute((const void*)quad_count_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(quad_count_kernel<0>, dim3(grid), dim3(kScanThreads), lds, s, idx->pk_ptr.as<uint32_t>(), idx->cols.as<uint4>(), idx->n_rows, V, idx->bp_rows,
+        VS_HIP(hipFuncSetAttribute((const void*)(quad_count_kernel<kQuadCells, kQuadLinked>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((quad_count_kernel<kQuadCells, kQuadLinked>), dim3(grid), dim3(kScanThreads), lds, s, idx->pk_ptr.as<uint32_t>(), idx->cols.as<uint4>(), idx->n_rows, V, idx->bp_rows,
+                           idx->bp_dir.as<uint32_t>(), block_recs.as<uint32_t>(), df_rec, df_nnz, ovf.as<int32_t>());
+    } else if (bq) {
+        const size_t b_main = (size_t)n_blocks * V * kBqChunkBytes;
+        if (free_b < b_dir + b_main + margin) {
+            fprintf(stderr, "[vsearch_hip] bag-of-token chunks need %.1f GB, %.1f GB of HBM free: building the record copy instead\n", (double)(b_dir + b_main) / 1e9, (double)free_b / 1e9);
+            idx->bp_no_quad = true;
+            return bp_build(idx, s);
+        }
+        VS_HIP(hipFuncSetAttribute((const void*)(quad_count_kernel<kBqCells, kBqLinked>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((quad_count_kernel<kBqCells, kBqLinked>), dim3(grid), dim3(kScanThreads), lds, s, idx->pk_ptr.as<uint32_t>(), idx->cols.as<uint4>(), idx->n_rows, V, idx->bp_rows,
                            idx->bp_dir.as<uint32_t>(), block_recs.as<uint32_t>(), df_rec, df_nnz, ovf.as<int32_t>());
     } else {
         VS_HIP(hipFuncSetAttribute((const void*)bp_count_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -293,11 +315,16 @@ int bp_build(vs_index* idx, hipStream_t s) {
         return VS_OK;
     }
     VS_STAGE("bp_vmax", s);
-    const int RS = quad ? kQuadChunkBytes : bp_rec_bytes(bp_record_vm(idx));
+    if (bq && (idx->bp_max_block_recs > 65535 || idx->bp_max_block_recs - V > 32767)) {
+        // (a chunk index is 16 bits of a descriptor, a link's payload 15: a block of extremely long lists keeps the records)
+        idx->bp_no_quad = true;
+        return bp_build(idx, s);
+    }
+    const int RS = quad ? kQuadChunkBytes : bq ? kBqChunkBytes : bp_rec_bytes(bp_record_vm(idx));
     const size_t b_rec = ((size_t)n_rec + 2) * RS;                       // + one record: a lane past the last list's end re-reads "the record at the end"
     VS_HIP(hipMemGetInfo(&free_b, &total_b));
     if (free_b < b_rec + margin || idx->bp_rec.alloc(b_rec) != VS_OK) {
-        if (quad) {                                                       // (overflow chunks took it past what is free: the record copy next)
+        if (quad || bq) {                                                       // (overflow chunks took it past what is free: the record copy next)
             (void)hipGetLastError();
             idx->bp_no_quad = true;
             return bp_build(idx, s);
@@ -305,8 +332,19 @@ int bp_build(vs_index* idx, hipStream_t s) {
         return no_room(b_rec);
     }
     idx->bp_records = (int64_t)n_rec;
-    VS_HIP(hipMemsetAsync(idx->bp_rec.p, 0, b_rec, s));                  // pad postings: document 0, value 0
-    if (quad) {
+    if (!bq) VS_HIP(hipMemsetAsync(idx->bp_rec.p, 0, b_rec, s));         // pad postings: document 0, value 0 (bag-of-token chunks: the fill writes the pads)
+    if (bq) {
+        VS_HIP(hipFuncSetAttribute((const void*)bq_fill_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(bq_fill_kernel<0>, dim3(grid), dim3(kScanThreads), lds, s, idx->pk_ptr.as<uint32_t>(), idx->cols.as<uint4>(), idx->n_rows, V, idx->bp_rows,
+                           idx->bp_dir.as<uint32_t>(), idx->bp_base.as<unsigned long long>(), idx->bp_rec.as<uint16_t>());
+        VS_HIP(hipGetLastError());
+        VS_STAGE("bq_fill", s);
+        // (the two spare records behind the array: pads too -- a lane never reads them, the allocation's tail is simply initialised)
+        VS_HIP(hipMemsetAsync(idx->bp_rec.as<char>() + (size_t)n_rec * RS, 0, 2 * (size_t)RS, s));
+        idx->bp_bq = true;
+        VS_HIP(hipStreamSynchronize(s));
+        idx->bp_dir.release();                                           // (the chunks link to their overflow themselves)
+    } else if (quad) {
         void (*fill)(const uint32_t*, const uint4*, const void*, int64_t, int32_t, int32_t, const uint32_t*, const unsigned long long*, uint32_t*) =
             idx->store_dtype == VS_F32 ? quad_fill_kernel<VM_F32> : quad_fill_kernel<VM_F16>;
         VS_HIP(hipFuncSetAttribute((const void*)fill, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -353,7 +391,7 @@ int bp_build(vs_index* idx, hipStream_t s) {
         std::vector<unsigned long long> hb((size_t)n_blocks + 1);
         std::vector<uint32_t> hd((size_t)V + 1);
         (void)hipMemcpy(hb.data(), idx->bp_base.p, hb.size() * 8, hipMemcpyDeviceToHost);
-        if (!idx->bp_quad) (void)hipMemcpy(hd.data(), idx->bp_dir.as<uint32_t>() + (size_t)(n_blocks - 1) * (V + 1), hd.size() * 4, hipMemcpyDeviceToHost);   // (quad chunks: the directory is gone)
+        if (!idx->bp_quad && !idx->bp_bq) (void)hipMemcpy(hd.data(), idx->bp_dir.as<uint32_t>() + (size_t)(n_blocks - 1) * (V + 1), hd.size() * 4, hipMemcpyDeviceToHost);   // (quad chunks: the directory is gone)
         bool mono = true;
         for (size_t i = 0; i + 1 < hb.size(); ++i) mono = mono && hb[i] <= hb[i + 1];
         bool dmono = true;
@@ -402,7 +440,9 @@ int bp_choose_chunks(const vs_index* idx, int n_tiles, int64_t n_blocks, int pla
         double best_eff = 0.0;
         // (a skewed corpus -- one with head columns -- keeps two items per CU: its tiles differ in weight, and with one item
         //  each the heaviest tile's CU finishes alone: zipf 21 M docs 441 ms against 289)
-        const int per_cu = idx->bp_n_head > 0 ? 2 : 1;
+        // (... with the strips multiplied inside the walk.  Behind the head pre-pass the tiles are even again -- what differed was their
+        //  share of head columns: 126 ms at one item per CU against 138 at two, 21 M docs x 1023 head columns)
+        const int per_cu = idx->bp_n_head > 0 && !idx->bp_head_gemm ? 2 : 1;
         const int c0 = (int)std::max<int64_t>(1, ceil_div64(per_cu * (int64_t)idx->cu_count, n_tiles));
         for (int c = c0; c <= c0 + 3; ++c) {
             const int64_t it = (int64_t)n_tiles * c;
@@ -540,15 +580,15 @@ int bp_filter_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64
     }
     idx->last_path = 3;
     idx->last_plan_dev = dplan;
-    idx->last_plan_rs = idx->bp_quad ? kQuadChunkBytes : bp_rec_bytes(bp_record_vm(idx));
+    idx->last_plan_rs = idx->bp_quad ? kQuadChunkBytes : idx->bp_bq ? kBqChunkBytes : bp_rec_bytes(bp_record_vm(idx));
     idx->last_plan_blocks = n_blocks;
     // lock-step window of the walk's work items (all walks; kernels ignore it when not every item is resident)
     static const int pace_env = getenv("VS_BP_PACE") ? atoi(getenv("VS_BP_PACE")) : -1;
     // (off by default for the list walk: it costs it 10 %; the bag-of-token walk of bp_bin.h runs ahead of its memory and
     //  NEEDS it: free running 81 ms, window 16: 66.7, 32: 56.5, 48: 57.2, 64: 58.7, 128: 73 -- the list walk: 61.3)
-    const bool bin_walk = idx->store_dtype == VS_NONE && idx->bp_walk_pref != 0;
+    const bool bin_walk = idx->store_dtype == VS_NONE && idx->bp_walk_pref != 0 && !idx->bp_bq;
     // (the two-set walk has no block barrier to keep its workgroups at one pace: 4 M docs 56.9 ms free running, window 1: 39.8, 2: 37.9, 4: 42.2)
-    const int pace_w = pace_env >= 0 ? pace_env : (idx->bp_pace >= 0 ? idx->bp_pace : (bin_walk ? 32 : (duo ? 2 : (idx->bp_quad ? kQuadPaceDefault : 0))));
+    const int pace_w = pace_env >= 0 ? pace_env : (idx->bp_pace >= 0 ? idx->bp_pace : (idx->bp_bq ? kBqPaceDefault : bin_walk ? 32 : (duo ? 2 : (idx->bp_quad ? kQuadPaceDefault : 0))));
     if (pace_w > 0) {
         VS_TRY(idx->ws_pace.reserve((size_t)nchunk * a.blocks_per_chunk * 4));
         VS_HIP(hipMemsetAsync(idx->ws_pace.p, 0, (size_t)nchunk * a.blocks_per_chunk * 4, s));

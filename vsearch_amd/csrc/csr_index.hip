@@ -529,7 +529,7 @@ extern "C" int vs_index_info(const vs_index* idx, vs_index_info_t* o) {
     o->last_walk_postings = idx->last_walk_postings;
     o->head_columns = idx->bp_ready ? idx->bp_n_head : 0;
     o->postings_state = idx->bp_ready ? 1 : idx->bp_state;
-    o->postings_walk = !idx->bp_ready ? -1 : idx->bp_quad ? 4 : (idx->store_dtype == VS_NONE && idx->bp_walk_pref != 0) ? 5 : 0;
+    o->postings_walk = !idx->bp_ready ? -1 : idx->bp_quad ? 4 : idx->bp_bq ? 6 : (idx->store_dtype == VS_NONE && idx->bp_walk_pref != 0) ? 5 : 0;
     o->reserved0 = 0;
     if (idx->last_path == 3 && idx->last_plan_dev) {               // the filter search keeps its plan on the device: read it now
         int64_t hp[6] = {0, 0, 0, 0, 0, 0};
@@ -538,7 +538,7 @@ extern "C" int vs_index_info(const vs_index* idx, vs_index_info_t* o) {
         VS_HIP(hipMemcpy(hp, idx->last_plan_dev, sizeof(hp), hipMemcpyDeviceToHost));
         // records + one directory word per (entry, block); quad chunks: every chunk the walk reads (main chunks, empty ones included, and
         // overflow chunks -- quad_count_kernel counts them all), no directory
-        o->last_scan_bytes = idx->bp_quad ? hp[4] * idx->last_plan_rs : hp[4] * idx->last_plan_rs + hp[2] * idx->last_plan_blocks * 4;
+        o->last_scan_bytes = (idx->bp_quad || idx->bp_bq) ? hp[4] * idx->last_plan_rs : hp[4] * idx->last_plan_rs + hp[2] * idx->last_plan_blocks * 4;
         o->last_walk_postings = hp[5];
     }
     if (idx->last_path == 3 && idx->last_flags && idx->last_flags_n > 0) {
