@@ -130,6 +130,12 @@ def parity_check(device, kind=0, nnz_doc=NNZ_DOC, store=0, val_law=0, expect_pat
     from vsearch_amd.device_index import DeviceIndex
     idx = DeviceIndex.synthetic(INDEX_SEED, 0, n, V, nnz_doc, kind, 0, store, device)
     q = oracle.synth_queries(QUERY_SEED, 8, V, NNZ_Q, val_law, kind=0 if kind == 1 else kind)
+    fp16 = store == nat.VS_F16
+    if fp16:
+        # the reference casts the query to the index dtype (index.py:89) and returns scores in it: the oracle sees the same fp16 images
+        # (export_csr returns the stored fp16 values), and the comparison allows the result's own fp16 rounding (2^-11)
+        q = q.astype(np.float16).astype(np.float32)
+    rtol = 1e-3 if fp16 else 1e-4
     ids, sc = idx.search(q, K)
     path = idx.info().last_path
     if expect_path is not None and path != expect_path:
@@ -137,10 +143,10 @@ def parity_check(device, kind=0, nnz_doc=NNZ_DOC, store=0, val_law=0, expect_pat
     ip, ix, d = idx.export_csr()
     binary = store == nat.VS_NONE
     o_ids, o_sc, allsc = oracle.csr_search(ip, ix.astype(np.int32), None if binary else d, V, q, K, acc64=True, return_all=True)
-    compare.check_topk_valid(allsc, ids, sc, rtol=1e-4, exact=exact, canonical=exact)
+    compare.check_topk_valid(allsc, ids, sc, rtol=rtol, exact=exact, canonical=exact)
     rel = float(np.max(np.abs(sc.astype(np.float64) - o_sc) / np.abs(o_sc)))
     idx.close()
-    return {"docs": n, "queries": 8, "scan_path": path, "recall_at_100_vs_oracle": compare.recall_at_k(o_ids, ids), "max_rel_score_err": rel,
+    return {"docs": n, "queries": 8, "scan_path": path, "recall_at_100_vs_oracle": compare.recall_at_k(o_ids, ids), "max_rel_score_err": rel, "rtol": rtol,
             "ids_bit_exact": bool((np.asarray(ids) == o_ids).all()) if exact else None}
 
 
@@ -219,7 +225,7 @@ def summarise(line):
             return bool(p["ok"])
         if p.get("ids_bit_exact") is not None:
             return bool(p["ids_bit_exact"])
-        return bool(p.get("recall_at_100_vs_oracle", 0) >= 0.999 and p.get("max_rel_score_err", 1) <= 1e-4)
+        return bool(p.get("recall_at_100_vs_oracle", 0) >= 0.999 and p.get("max_rel_score_err", 1) <= p.get("rtol", 1e-4))
     r3 = lambda x: None if x is None else float(f"{x:.4g}")
     out = {"_": "leg: [ms, q/s, roofline.frac, parity ok]", "headline": [r3(line["ms_per_step"]), r3(line["value"]), r3(line["roofline"]["frac"]), ok(line.get("parity"))]}
     short = {"C2_dense_100k": "C2", "C3_1m_sparse": "C3", "C5_bot_21m": "C5", "zipf_21m": "zipf", "fp16_21m": "fp16", "facade": "facade", "shard_group_8_on_one_gpu": "shards8",
@@ -470,6 +476,12 @@ def secondary(index, batches, args, local_rank, device, headline_s):
         byts = B * V * 4.0 + B * NNZ_DOC * 8.0
         out["dense_to_csr_B1024"] = {"what": "Tensor.to_sparse_csr() of the sparsified batch (retriever.py:304)", "ms": ms, "kernel_ms": kms, "kernel": "count_nz / scan_counts / fill_csr",
                                      "roofline": roof("hbm", byts / (kms * 1e6), HBM_PEAK_GBS, "GB/s", achieved_is="one read of [B, V] fp32 + the CSR written / kernel time (the kernels read the matrix twice)")}
+        # the two stages fused: the mask kernel ranks the kept elements and writes the CSR itself -- one read of [B, V]
+        ms, kms = kernel_ms("mask_to_csr", lambda: sp.embed_mask_to_csr(emb, tok, VOC, SHIFT, NNZ_DOC, True), 50)
+        byts = B * V * 4.0 + B * (NNZ_DOC + L) * 8.0 * 2
+        out["embed_to_csr_B1024"] = {"what": "mask stage + to_sparse_csr() fused (vdr.py:152-169 + retriever.py:304): [1024, 29523] fp32 in, CSR out; replaces the two legs above in build_index",
+                                     "ms": ms, "kernel_ms": kms, "kernel": "mask_rows_fast_kernel (CSR emission) + scan_counts + slots_compact",
+                                     "roofline": roof("hbm", byts / (kms * 1e6), HBM_PEAK_GBS, "GB/s", achieved_is="one read of [B, V] fp32 + the slot runs written and compacted / kernel time")}
         Bh, Lh, H = 64, 256, 768
         hid = torch.randn((Bh, Lh, H), device=device, generator=g)
         w = torch.randn((V, H), device=device, generator=g) * 0.05
@@ -654,9 +666,15 @@ def main():
         # without one, the algorithmic rate (bytes the kernel has to read / time), flagged as such -- on the postings path most of
         # those bytes come from L2 / Infinity Cache, so that rate can exceed the HBM peak and says nothing about HBM utilisation.
         hbm_rate = (traffic / avg_launch_s / 1e9) if traffic else None
+        # (no PMC profile of this kernel build: the algorithmic bytes are L2 / Infinity-Cache served -- priced against the L2 -> L1 aggregate,
+        #  never against the HBM peak)
+        l2_basis = hbm_rate is None and info.last_path >= 2
+        if l2_basis:
+            bound_note = "L2: no PMC pass of this kernel build -- algorithmic bytes (L2 / Infinity-Cache served) against the L2 -> L1 aggregate, not an HBM fraction"
+        peak = L2_PEAK_GBS if l2_basis else HBM_PEAK_GBS
         roofline = {
-            "bound": bound, "bound_note": bound_note, "achieved": hbm_rate if hbm_rate is not None else achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": (hbm_rate if hbm_rate is not None else achieved) / HBM_PEAK_GBS,
+            "bound": bound, "bound_note": bound_note, "achieved": hbm_rate if hbm_rate is not None else achieved, "peak": peak, "unit": "GB/s",
+            "frac": (hbm_rate if hbm_rate is not None else achieved) / peak,
             "achieved_is": "HBM traffic (PMC FETCH_SIZE / WRITE_SIZE of this command) / kernel time" if hbm_rate is not None
                            else "ALGORITHMIC bytes / kernel time (no PMC profile of this configuration: not an HBM fraction)",
             "traffic": traffic, "algorithmic_GBps": achieved, "algorithmic_over_hbm_peak": achieved / HBM_PEAK_GBS,

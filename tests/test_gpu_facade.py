@@ -507,6 +507,44 @@ def test_native_shard_file_roundtrip(tmp_path):
         SparseIndex(str(tmp_path / "a.vsx"), None, device="cuda", shift=999)
 
 
+@pytest.mark.parametrize("topk,lexical", [(768, False), (768, True), (32, True), (1, False), (5000, False)])
+def test_embed_mask_to_csr_equals_mask_then_to_sparse_csr(topk, lexical):
+    """SURVEY 8(f1) / VERDICT r4 item 7: the mask stage fused with to_sparse_csr() (vs_embed_mask_to_csr) returns exactly the CSR of the
+    masked dense batch (vs_embed_mask + vs_dense_to_csr; vdr.py:152-169 + retriever.py:304) -- row pointers, columns and value bits --
+    on rows with ties, exact zeros among the selected, negative values and a ragged batch; the input is not modified."""
+    g = torch.Generator().manual_seed(11)
+    B, L = 37, 23
+    emb = torch.rand((B, V), generator=g) * 3
+    emb[3] = 0.0                                                      # an all-zero row: top-k selects zeros, the CSR row is empty
+    emb[4, ::7] = 1.5                                                 # ties across the k-th value
+    emb[5] = -emb[5]                                                  # negative values (selected by rank, kept as they are)
+    emb[6, :100] = 0.0
+    emb = emb.cuda()
+    ids = torch.randint(SHIFT, VOCAB, (B, L), generator=g).cuda()
+    ids[7, :5] = torch.tensor([0, 101, 102, 999, VOCAB - 1])          # tokens below the shift are dropped
+    keep = emb.clone()
+    rp, ci, va = sp.embed_mask_to_csr(emb, ids, VOCAB, SHIFT, topk, lexical)
+    assert (emb == keep).all()
+    ref = emb.clone()
+    sp.apply_embed_mask_(ref, ids if lexical else None, VOCAB, SHIFT, topk, lexical)
+    r_rp, r_ci, r_va = sp.dense_to_csr(ref)
+    assert (rp == r_rp).all() and (ci == r_ci).all() and (va.view(torch.int32) == r_va.view(torch.int32)).all()
+    with pytest.raises(NotImplementedError):
+        sp.embed_mask_to_csr(emb, ids, VOCAB, SHIFT, 0, True)
+
+
+def test_encoder_embed_csr_equals_embed_then_to_sparse_csr(tiny_retriever):
+    enc = tiny_retriever.encoder_p
+    texts = make_texts(19, 3)
+    dense = enc.embed(texts, batch_size=8, activate_lexical=False)
+    rows = 0
+    for (rp, ci, va, n_cols), s in zip(enc.embed_csr(texts, batch_size=8, activate_lexical=False), range(0, 19, 8)):
+        r_rp, r_ci, r_va = sp.dense_to_csr(dense[s:s + 8].contiguous())
+        assert n_cols == V and (rp == r_rp).all() and (ci == r_ci).all() and (va == r_va).all()
+        rows += rp.numel() - 1
+    assert rows == 19
+
+
 def test_mean_pooling_with_pooling_topk():
     """vdr.py:76-79 (pooling = "mean" with pooling_topk): mean of the t largest elu1p activations per vocabulary dimension."""
     g = torch.Generator().manual_seed(3)

@@ -66,6 +66,7 @@ _SIGNATURES = {
     "vs_bow_mask": ([_vp, _i32, _i32, _i32, _i32, _int, _vp, _int, _vp], _int),
     "vs_embed_mask": ([_vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _int, _int, _int, _vp], _int),
     "vs_dense_to_csr": ([_vp, _i32, _i32, _i64, _vp, _vp, _vp, _i64, _int, _vp], _int),
+    "vs_embed_mask_to_csr": ([_vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _int, _vp, _vp, _vp, _i64, _int, _vp], _int),
     "vs_head_pool": ([_vp, _i32, _i32, _i32, _vp, _int, _vp], _int),
     "vs_head_project_pool": ([_vp, _vp, _i32, _i32, _i32, _i32, _vp, _int, _vp], _int),
     "vs_elu1p": ([_vp, _i64, _vp, _int, _vp], _int),

@@ -254,11 +254,16 @@ int launch_dense_scores(vs_index* idx, const float* dq, int B, int ldp, uint64_t
         const int64_t n_tail = N - n_begin, tail_tiles = ceil_div64(n_tail, 128) * q_tiles;
         const int chunks = ldp / kDenseKC;
         int S = (int)std::min<int64_t>(slots / std::max<int64_t>(tail_tiles, 1), chunks / 16);
-        if (main_doc_tiles > 0 && S >= 2) {
+        // (the split's workspace holds one partial per 512-column summation block: n_sum_blocks x B x n_tail floats -- 58 slices at V =
+        //  29 523.  ADVICE r4: when that passes 256 MB, or cannot be reserved, the 32 x 128 tail kernel does the tail -- same summation
+        //  order, no workspace -- instead of failing the search)
+        const int n_sum_blocks = ceil_div(chunks, 16);
+        const size_t ws_bytes = (size_t)n_sum_blocks * B * n_tail * 4;
+        bool split = main_doc_tiles > 0 && S >= 2 && ws_bytes <= ((size_t)256 << 20);
+        if (split && idx->ws_fb.reserve(ws_bytes) != VS_OK) { (void)hipGetLastError(); split = false; }
+        if (split) {
             const int cps = ceil_div(ceil_div(chunks, S), 16) * 16;
             S = ceil_div(chunks, cps);
-            const int n_sum_blocks = ceil_div(chunks, 16);
-            VS_TRY(idx->ws_fb.reserve((size_t)n_sum_blocks * B * n_tail * 4));
             hipLaunchKernelGGL((dense_scores_kernel<2, 2, 2, 2, 1>), dim3((unsigned)ceil_div64(n_tail, 128), (unsigned)q_tiles, (unsigned)S), dim3(256), 0, s, dq,
                                idx->mat.as<float>(), B, N, n_begin, ldp, (uint64_t*)nullptr, (float*)nullptr, 0, (uint32_t*)nullptr, idx->ws_fb.as<float>(), cps, n_tail);
             VS_HIP(hipGetLastError());

@@ -96,7 +96,8 @@ __device__ __forceinline__ uint32_t mr_pick(const int* hist, int* other, int* sc
 #define MR_T(i) do { } while (0)
 #endif
 
-template <int G>
+// CSR = 1: also emits the kept non-zero elements as CSR slot runs (step 4 below; vs_embed_mask_to_csr)
+template <int G, int CSR = 0>
 __global__ __launch_bounds__(kMrThreads) void mask_rows_fast_kernel(MaskArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* hist0 = reinterpret_cast<int*>(smem);                                 // [256 * kMrSub] x 2
@@ -279,6 +280,7 @@ __global__ __launch_bounds__(kMrThreads) void mask_rows_fast_kernel(MaskArgs a) 
         // and inf) and the product or the element itself is picked by the select bit -- a version with the obvious early-outs compiled
         // to ~ 40 scalar branches per 4 elements and took half the kernel's time.  The row goes back whole, 16 bytes a lane.
         const uint32_t lex_on = a.activate_lexical ? 0xFu : 0u, sel_all = take_all ? 0xFu : 0u;
+        [[maybe_unused]] uint32_t nzw[2] = {0u, 0u};                            // 4 bits per g: this thread's selected elements (CSR emission below)
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const int i = g * kMrStep + t4o;                                    // (4 columns of one bitmap word)
@@ -297,6 +299,7 @@ __global__ __launch_bounds__(kMrThreads) void mask_rows_fast_kernel(MaskArgs a) 
                 o[r] = sel ? xb : zb;
                 selm |= sel << r;
             }
+            if constexpr (CSR != 0) nzw[g >> 3] |= selm << (4 * (g & 7));
             if (a.mask) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) __builtin_amdgcn_raw_buffer_store_b8((uint8_t)((selm >> r) & 1u), rm, t4o + r, g * kMrStep, 0);
@@ -306,6 +309,81 @@ __global__ __launch_bounds__(kMrThreads) void mask_rows_fast_kernel(MaskArgs a) 
             __builtin_amdgcn_sched_barrier(0);
         }
         MR_T(7);
+        // ---- 4. CSR emission ("write CSR rows directly"): the kept non-zero elements as (column, value) pairs in column
+        // order into the row's slot run -- what Tensor.to_sparse_csr() of the masked row holds (retriever.py:304), without a second and
+        // third pass over the dense row.  Rank of a kept column = kept columns below it: a bitmap of the kept columns (the tie bitmaps
+        // of step 2 are free again) + prefix popcounts of its words, as step 2 ranks ties.
+        if constexpr (CSR != 0) {
+            static_assert(G <= 16, "4 bits per g in two words");
+            uint32_t* nzb = eqb;                                                // [1024] kept non-zero columns
+            int* nzp = eqp;                                                     // [1024] ... in the words below
+            mr_barrier();                                                       // (step 3's readers of selb / lex are done; eqb / eqp idle since step 2)
+            mr_clear<kMrWords / 4 / kMrThreads + 1>(reinterpret_cast<int*>(nzb), tid);           // (+ the head of selb: not read again this row)
+            mr_barrier();
+            // (what to_sparse_csr() keeps: selected, inside the row, and not +-0 -- tested here, on the few selected elements, not in the
+            //  write loop: there the test cost 50 VGPRs and with them the spill-free row prefetch)
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                __builtin_amdgcn_sched_barrier(0);
+                const uint32_t s4 = (nzw[g >> 3] >> (4 * (g & 7))) & 15u;
+                if (s4) {
+                    const int i = g * kMrStep + lane4();                        // (a multiple of 4: the four bits fall into one word)
+                    const uint2 lo = *reinterpret_cast<const uint2*>(lo16 + i);
+                    // (opaque copies: else the compiler keeps the write loop's 64 key halves alive for this loop instead of rebuilding the
+                    //  few it needs -- 80 spilled VGPRs, and a scratch reload waits for the next row's prefetch)
+                    uint32_t w0 = kk[g][0], w1 = kk[g][1];
+                    asm volatile("" : "+v"(w0), "+v"(w1));
+                    const uint32_t key[4] = {(w0 << 16) | (lo.x & 0xFFFFu), (w0 & 0xFFFF0000u) | (lo.x >> 16), (w1 << 16) | (lo.y & 0xFFFFu), (w1 & 0xFFFF0000u) | (lo.y >> 16)};
+                    uint32_t n4 = 0;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool zero = key[r] == 0x80000000u || key[r] == 0x7FFFFFFFu;       // flip_f32(+0), flip_f32(-0)
+                        n4 |= (uint32_t)(!zero && i + r < a.V) << r;
+                    }
+                    n4 &= s4;
+                    if (n4) atomicOr(&nzb[i >> 5], n4 << (i & 31));
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mr_barrier();
+            {
+                const int p0 = __popc(nzb[2 * tid]), p1 = __popc(nzb[2 * tid + 1]);       // (two bitmap words per thread)
+                const int below = mr_scan(p0 + p1, scratch, tid);
+                nzp[2 * tid] = below;
+                nzp[2 * tid + 1] = below + p0;
+                if (tid == kMrThreads - 1) a.row_nnz[b] = (int64_t)(below + p0 + p1);
+            }
+            mr_barrier();
+            int32_t* oc = a.slot_cols + (size_t)b * a.slot_cap;
+            float* ov = a.slot_vals + (size_t)b * a.slot_cap;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                __builtin_amdgcn_sched_barrier(0);          // (one g at a time: the next row's prefetch needs the registers)
+                if ((nzw[g >> 3] >> (4 * (g & 7))) & 15u) {
+                    const int i = g * kMrStep + lane4();
+                    const uint32_t word = nzb[i >> 5];
+                    const uint32_t n4 = (word >> (i & 31)) & 15u;                // this thread's kept non-zero elements of the group
+                    uint32_t pos = (uint32_t)nzp[i >> 5] + (uint32_t)__popc(word & ((1u << (i & 31)) - 1u));
+                    const uint2 lo = *reinterpret_cast<const uint2*>(lo16 + i);
+                    uint32_t w0 = kk[g][0], w1 = kk[g][1];
+                    asm volatile("" : "+v"(w0), "+v"(w1));
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if ((n4 >> r) & 1u) {
+                            const uint32_t key = r == 0 ? (w0 << 16) | (lo.x & 0xFFFFu) : r == 1 ? (w0 & 0xFFFF0000u) | (lo.x >> 16) : r == 2 ? (w1 << 16) | (lo.y & 0xFFFFu) : (w1 & 0xFFFF0000u) | (lo.y >> 16);
+                            if (pos < (uint32_t)a.slot_cap) {
+                                oc[pos] = i + r;
+                                ov[pos] = __uint_as_float(key ^ (~(uint32_t)((int32_t)key >> 31) | 0x80000000u));
+                            } else {
+                                atomicOr(a.flags, 2);                           // more kept elements than the slot run holds (the host sized it from topk + L)
+                            }
+                            ++pos;
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 #ifdef MR_TIMING
     if (tid == 0)

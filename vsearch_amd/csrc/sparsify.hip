@@ -71,7 +71,13 @@ struct MaskArgs {
     int activate_lexical;
     int bow;
     uint8_t* mask;         // optional [B, V] output (build_topk_mask)
-    int* flags;            // |1: token id out of range
+    int* flags;            // |1: token id out of range, |2: a row kept more elements than its slot run holds
+    // CSR emission (mask_rows_fast_kernel only): the kept non-zero elements of row b as (column, value) pairs in column order at
+    // slot_cols / slot_vals [b * slot_cap ...], their number in row_nnz[b]; null: off
+    int64_t* row_nnz;
+    int32_t* slot_cols;
+    float* slot_vals;
+    int32_t slot_cap;
 };
 
 // block-wide sum of one 64-bit value per thread (kSpThreads threads); red: kSpThreads / 64 slots in LDS
@@ -466,6 +472,77 @@ extern "C" int vs_embed_mask(float* emb, int64_t ld, const int64_t* ids, int32_t
     MaskArgs a{};
     a.V = V; a.ld = ld; a.B = B; a.L = L; a.vocab = vocab; a.shift = shift; a.topk = topk; a.activate_lexical = activate_lexical; a.bow = bow ? 1 : 0;
     return run_mask(a, nullptr, emb, ids, nullptr, device, (hipStream_t)stream);
+}
+
+namespace {
+// the slot runs of vs_embed_mask_to_csr -> the CSR arrays: one workgroup per row, coalesced copies
+template <int UNUSED>
+__global__ __launch_bounds__(256) void slots_compact_kernel(const int64_t* rowptr, const int32_t* slot_cols, const float* slot_vals, int32_t slot_cap, int32_t B,
+                                                            int32_t* cols, float* vals, int64_t cap, int* flags) {
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        const int64_t p0 = rowptr[b];
+        const int n = (int)min((int64_t)slot_cap, rowptr[b + 1] - p0);
+        if (p0 + n > cap) { if (threadIdx.x == 0) atomicOr(flags, 4); continue; }
+        for (int i = threadIdx.x; i < n; i += 256) {
+            cols[p0 + i] = slot_cols[(size_t)b * slot_cap + i];
+            vals[p0 + i] = slot_vals[(size_t)b * slot_cap + i];
+        }
+    }
+}
+}  // namespace
+
+// VDREncoder.embed's mask stage FUSED with Tensor.to_sparse_csr() (vdr.py:152-169 + retriever.py:304; SURVEY 8(f1) "write CSR rows
+// directly"): x [B, V] (the pooled activations, NOT modified) -> the CSR of  x * (topk_mask | lexical_mask).  The mask kernel ranks the
+// kept elements while it still holds the row in registers and writes (column, value) pairs; the dense masked row is never written nor
+// read back: one read of [B, V] instead of the five passes of vs_embed_mask + vs_dense_to_csr.
+//   rowptr int64 [B + 1] (device), cols int32 / vals fp32 [cap] (device), cap >= B * (topk + L) suffices; nnz = rowptr[B].
+//   VS_EUNSUPPORTED: outside the fast mask kernel's range (bow, topk <= 0, V > 32 Ki) -- use vs_embed_mask + vs_dense_to_csr.
+extern "C" int vs_embed_mask_to_csr(const float* x, int64_t ld, const int64_t* ids, int32_t B, int32_t L, int32_t vocab, int32_t shift, int32_t topk,
+                                    int activate_lexical, int64_t* rowptr, int32_t* cols, float* vals, int64_t cap, int device, void* stream) {
+    if (!x || !rowptr || !cols || !vals || B <= 0 || vocab <= 0 || shift < 0 || shift >= vocab || ld < vocab - shift || cap < 0) return fail(VS_EINVAL, "bad argument");
+    if (activate_lexical && (!ids || L <= 0)) return fail(VS_EINVAL, "token ids required for activate_lexical");
+    const int V = vocab - shift;
+    if (topk <= 0 || V > kMrCols) return fail(VS_EUNSUPPORTED, "vs_embed_mask_to_csr serves top-k masks of V <= %d columns", kMrCols);
+    if (topk > V) return fail(VS_ERANGE, "selected index k out of range (k = %d, V = %d)", topk, V);
+    if (!is_device_ptr(x) || !is_device_ptr(rowptr) || !is_device_ptr(cols) || !is_device_ptr(vals) || (ids && !is_device_ptr(ids)))
+        return fail(VS_EINVAL, "vs_embed_mask_to_csr takes device pointers");
+    VS_TRY(check_device(device));
+    hipStream_t s = (hipStream_t)stream;
+    const int32_t slot_cap = (int32_t)std::min<int64_t>(V, (int64_t)topk + (activate_lexical ? L : 0));
+    DevBuf& flags = device_scratch(device, 0);
+    DevBuf& counts = device_scratch(device, 1);
+    DevBuf& slots = device_scratch(device, 3);
+    VS_TRY(flags.reserve(128));
+    VS_TRY(counts.reserve((size_t)B * 8));
+    VS_TRY(slots.reserve((size_t)B * slot_cap * 8));
+    VS_HIP(hipMemsetAsync(flags.p, 0, 4, s));
+    MaskArgs a{};
+    a.x = x; a.emb = nullptr; a.ld = ld; a.ids = activate_lexical ? ids : nullptr;
+    a.V = V; a.B = B; a.L = L; a.vocab = vocab; a.shift = shift; a.topk = topk; a.activate_lexical = activate_lexical; a.bow = 0;
+    a.flags = flags.as<int>();
+    a.row_nnz = counts.as<int64_t>();
+    a.slot_cols = slots.as<int32_t>();
+    a.slot_vals = reinterpret_cast<float*>(slots.as<int32_t>() + (size_t)B * slot_cap);
+    a.slot_cap = slot_cap;
+    {
+        ProfScope prof("mask_to_csr", s);
+        void (*kern)(MaskArgs) = V <= 4 * kMrStep ? mask_rows_fast_kernel<4, 1> : V <= 8 * kMrStep ? mask_rows_fast_kernel<8, 1> : mask_rows_fast_kernel<16, 1>;
+        int cus = 0;
+        VS_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+        VS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mask_fast_lds_bytes()));
+        hipLaunchKernelGGL(kern, dim3(std::max(1, std::min(B, cus))), dim3(kMrThreads), mask_fast_lds_bytes(), s, a);
+        hipLaunchKernelGGL(scan_counts_kernel<0>, dim3(1), dim3(kSpThreads), 0, s, counts.as<int64_t>(), B, rowptr);
+        hipLaunchKernelGGL(slots_compact_kernel<0>, dim3(std::min(B, 4096)), dim3(256), 0, s, (const int64_t*)rowptr, (const int32_t*)a.slot_cols, (const float*)a.slot_vals, slot_cap, B,
+                           cols, vals, cap, flags.as<int>());
+        VS_HIP(hipGetLastError());
+    }
+    int hflags = 0;
+    VS_HIP(hipMemcpyAsync(&hflags, flags.p, 4, hipMemcpyDeviceToHost, s));
+    VS_HIP(hipStreamSynchronize(s));
+    if (hflags & 1) return fail(VS_EINVAL, "token id out of range [0, %d)", vocab);
+    if (hflags & 2) return fail(VS_ERANGE, "a row kept more than topk + L = %d elements", slot_cap);
+    if (hflags & 4) return fail(VS_ERANGE, "cols / vals hold %lld entries, the batch has more non-zeros", (long long)cap);
+    return VS_OK;
 }
 
 extern "C" int vs_dense_to_csr(const float* x, int32_t B, int32_t V, int64_t ld, int64_t* rowptr, int32_t* cols, float* vals,

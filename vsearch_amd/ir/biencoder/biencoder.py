@@ -70,6 +70,17 @@ class BiEncoder(PreTrainedModel):
         return self.encoder_p.embed(flat, batch_size, max_len=max_len, to_cpu=to_cpu, convert_to_tensor=convert_to_tensor,
                                     activate_lexical=False, **kwargs)
 
+    def encode_corpus_csr(self, corpus: Union[List[str], List[Dict[str, str]]], batch_size=None, max_len=None):
+        """`encode_corpus(...)` batch by batch as CSR (encoder.embed_csr: mask stage + to_sparse_csr fused, no dense masked batch)."""
+        batch_size = batch_size or self.default_batch_size
+        flat = []
+        for p in corpus:
+            if isinstance(p, dict):
+                flat.append(f"{p['title']} [SEP] {p['text']}" if p.get("title") else p["text"])
+            elif isinstance(p, str):
+                flat.append(p)
+        return self.encoder_p.embed_csr(flat, batch_size, max_len=max_len, activate_lexical=False)
+
     def explain(self, q, p, topk=768, visual=False, max_words=100, log_scale=True, save_file=None):
         """Per-token contribution q_w * p_w, largest first (biencoder.py:111-123)."""
         if visual:

@@ -144,6 +144,36 @@ class VDREncoder(PreTrainedModel):
             self.train()
         return out
 
+    def embed_csr(self, texts: Union[List[str], str], batch_size: int = 128, max_len: int = None, topk: int = None,
+                  activate_lexical: bool = True):
+        """Generator over the batches of `embed(texts, ...)`, each as CSR: (rowptr int64 [b+1], cols int32, vals fp32, V) CUDA tensors --
+        what `embed(batch).to_sparse_csr()` holds (vdr.py:97-179 + retriever.py:304), with the mask stage and the CSR conversion fused
+        in one kernel (`vs_embed_mask_to_csr`): the masked dense batch is never written.  Falls back to embed + dense_to_csr outside
+        the fused kernel's range (topk <= 0, norm, V > 32 Ki)."""
+        max_len = max_len or self.config.max_len
+        topk = topk if topk is not None else self.config.topk
+        texts = [texts] if isinstance(texts, str) else texts
+        was_training = self.training
+        if was_training:
+            self.eval()
+        V = self.config.vocab_size - self.config.shift_vocab_num
+        try:
+            with torch.no_grad():
+                for s in range(0, len(texts), batch_size):
+                    enc = self.encode(texts[s:s + batch_size], max_len=max_len)
+                    emb = self(**enc).contiguous()
+                    fused = topk is not None and int(topk) > 0 and V <= 32768 and emb.dtype == torch.float32
+                    if fused:
+                        rp, ci, va = sp.embed_mask_to_csr(emb, enc["input_ids"], self.config.vocab_size, self.config.shift_vocab_num, int(topk), activate_lexical)
+                    else:
+                        sp.apply_embed_mask_(emb, enc["input_ids"] if activate_lexical else None, self.config.vocab_size, self.config.shift_vocab_num,
+                                             topk, activate_lexical)
+                        rp, ci, va = sp.dense_to_csr(emb)
+                    yield rp, ci, va, V
+        finally:
+            if was_training:
+                self.train()
+
     def disentangle(self, text: str, topk: int = 768, visual=False, save_file=None):
         """Top-k (token, weight) pairs of a text's representation (vdr.py:181-192)."""
         if visual:

@@ -161,15 +161,23 @@ class Retriever(BiEncoder):
         n = len(texts)
         dev_index, row_cap, pk_cap = None, n, 0
         pending = []                                        # batches embedded before the first reservation / beyond it
+        # the mask stage and to_sparse_csr() fused (encoder.embed_csr -> vs_embed_mask_to_csr: the masked dense batch is never written) when
+        # the encoder offers it; else embed + vs_dense_to_csr
+        fused = hasattr(self.encoder_p, "embed_csr") and type(self).encode_corpus is BiEncoder.encode_corpus
+        batches = self.encode_corpus_csr(texts, batch_size=batch_size, max_len=max_len) if fused else None
         for s in range(0, n, batch_size):
-            emb = self.encode_corpus(texts[s:s + batch_size], batch_size=batch_size, max_len=max_len, convert_to_tensor=True)
-            rp, ci, va = sp.dense_to_csr(emb.float().contiguous())        # device tensors
+            if fused:
+                rp, ci, va, n_cols = next(batches)
+            else:
+                emb = self.encode_corpus(texts[s:s + batch_size], batch_size=batch_size, max_len=max_len, convert_to_tensor=True)
+                rp, ci, va = sp.dense_to_csr(emb.float().contiguous())        # device tensors
+                n_cols = int(emb.shape[1])
             if dev_index is None:
                 # reserve from the first batch: the encoder keeps at most topk (+ the lexical tokens) non-zeros per passage
                 per_row = int((rp[1:] - rp[:-1]).max().item()) if rp.numel() > 1 else 0
                 bound = max(per_row, int(getattr(getattr(self.encoder_p, "config", None), "topk", 0) or 0)) + int(max_len)
-                pk_cap = n * ((min(bound, emb.shape[1]) + 7) // 8)
-                dev_index = DeviceIndex.reserved(row_cap, max(pk_cap, 1), int(emb.shape[1]), nat.VS_F32, device=emb.device.index or 0)
+                pk_cap = n * ((min(bound, n_cols) + 7) // 8)
+                dev_index = DeviceIndex.reserved(row_cap, max(pk_cap, 1), n_cols, nat.VS_F32, device=rp.device.index or 0)
             try:
                 dev_index.append_csr(rp, ci, va)
             except (nat.VsearchNativeError, ValueError):

@@ -91,6 +91,32 @@ def apply_embed_mask_(emb: torch.Tensor, input_ids, vocab_size: int, shift_num: 
     return emb
 
 
+def embed_mask_to_csr(emb: torch.Tensor, input_ids, vocab_size: int, shift_num: int, topk: int, activate_lexical: bool):
+    """The mask stage of VDREncoder.embed (vdr.py:152-169) fused with Tensor.to_sparse_csr() (retriever.py:304): pooled activations
+    emb [B, V] (CUDA fp32, NOT modified) -> (rowptr int64 [B+1], cols int32 [nnz], vals fp32 [nnz]) of emb * (topk_mask | lexical_mask).
+    One read of [B, V]; the masked dense batch is never written.  NotImplementedError outside the fused kernel's range (topk <= 0,
+    V > 32 Ki): callers then use apply_embed_mask_ + dense_to_csr."""
+    assert emb.is_cuda and emb.dtype == torch.float32 and emb.is_contiguous()
+    dev = _dev_of(emb)
+    B, V = emb.shape
+    ids, L = None, 0
+    if activate_lexical:
+        ids = input_ids.detach().to(device=emb.device, dtype=torch.int64).contiguous()
+        L = ids.shape[1]
+    tk = -1 if topk is None else int(topk)
+    if tk <= 0 or V > 32768:
+        raise NotImplementedError("embed_mask_to_csr serves top-k masks of V <= 32 Ki columns")
+    cap = B * min(V, tk + L)
+    rowptr = torch.empty(B + 1, dtype=torch.int64, device=emb.device)
+    cols = torch.empty(max(cap, 1), dtype=torch.int32, device=emb.device)
+    vals = torch.empty(max(cap, 1), dtype=torch.float32, device=emb.device)
+    nat.check(nat.lib().vs_embed_mask_to_csr(C.c_void_p(emb.data_ptr()), V, C.c_void_p(ids.data_ptr()) if ids is not None else None, B, L,
+                                             int(vocab_size), int(shift_num), tk, int(bool(activate_lexical)), C.c_void_p(rowptr.data_ptr()),
+                                             C.c_void_p(cols.data_ptr()), C.c_void_p(vals.data_ptr()), cap, dev, current_stream(dev)))
+    nnz = int(rowptr[-1].item())
+    return rowptr, cols[:nnz], vals[:nnz]
+
+
 def head_pool(logits: torch.Tensor):
     """elu1p then max over the sequence axis of [B, L, V] logits (vdr.py:73-75) -> [B, V]."""
     assert logits.is_cuda and logits.dim() == 3
