@@ -79,9 +79,11 @@ __global__ __launch_bounds__(256) void head_weights_kernel(HeadArgs a) {
 // MFMAs per k-step on 12 KB of operands, 128 accumulator registers.  Work items = (block, run of WD x 64 documents, group of WT x 16
 // tiles), the tile groups of one document run on consecutive items (the strip run is re-read from L2 / Infinity Cache).  Operands
 // come straight from global memory in operand order (one coalesced 16-byte load per lane each), the next k-step's in flight.
-template <int WD, int WT>
+// WIDE = 1: a wave takes 128 documents (8 strip operands per k-step), accumulators in AGPRs -- 256-thread workgroups, one wave per SIMD
+template <int WD, int WT, int WIDE = 0>
 __global__ __launch_bounds__(WD * WT * 64) void head_gemm_kernel(HeadArgs a) {
-    constexpr int NT = 8, TW = 2 * NT;                                        // weight operands / tiles of a wave (x 4 strip operands: tools/gen_head_asm.py)
+    constexpr int NT = 8, TW = 2 * NT;                                        // weight operands / tiles of a wave (tools/gen_head_asm.py)
+    constexpr int WDOCS = WIDE ? 128 : 64;                                    // documents of a wave
     const int n_tiles = a.n_tiles_dev[0];
     const int nt = max(0, min(n_tiles - a.tile0, a.tile_cnt));
     if (nt <= 0) return;
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(WD * WT * 64) void head_gemm_kernel(HeadArgs a) {
     const int wd = wv / WT, wt_ = wv % WT;
     const int ks = bp_head_pad(a.n_head) / 32, mbk = a.rows / 16;
     const int tgroups = (nt + WT * TW - 1) / (WT * TW);
-    const int druns = a.rows / (WD * 64);
+    const int druns = a.rows / (WD * WDOCS);
     const int64_t items = a.n_blocks * druns * tgroups;
     const uint4* strip4 = reinterpret_cast<const uint4*>(a.strip);
     for (int64_t item = blockIdx.x; item < items; item += gridDim.x) {
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(WD * WT * 64) void head_gemm_kernel(HeadArgs a) {
         const int64_t r = item / tgroups;
         const int dr = (int)(r % druns);
         const int64_t b = r / druns;
-        const int d0 = (dr * WD + wd) * 64;                                    // this wave's first document in the block
+        const int d0 = (dr * WD + wd) * WDOCS;                                 // this wave's first document in the block
         const int t0 = (tg * WT + wt_) * TW;                                   // ... first tile (relative to tile0), an even one
         const int rows_b = (int)min((int64_t)a.rows, a.n_rows - b * a.rows);
         if (d0 >= rows_b || t0 >= nt) continue;                                // (no barrier in this kernel: waves are independent)
@@ -113,7 +115,8 @@ __global__ __launch_bounds__(WD * WT * 64) void head_gemm_kernel(HeadArgs a) {
         const unsigned long long obase = (unsigned long long)(a.out + head_out_index(t0, a.n_blocks, b, a.rows, d0, 0));
         const unsigned long long ostride = (unsigned long long)a.n_blocks * (unsigned long long)mbk * 512ull;      // bytes between the tiles of a (block, document group)
         const uint32_t so = (uint32_t)(lane & 7) * 64u + (uint32_t)(lane >> 4) * 16u;                             // slot row + the lane's 4 documents
-        head_item_asm(abase, bbase, (uint32_t)mbk * 1024u, boff, l16, (uint32_t)ks, obase, ostride, so, (uint32_t)min(TW, nt - t0), a.head_mul);
+        if constexpr (WIDE != 0) head_item_asm_wide(abase, bbase, (uint32_t)mbk * 1024u, boff, l16, (uint32_t)ks, obase, ostride, so, (uint32_t)min(TW, nt - t0), a.head_mul);
+        else head_item_asm(abase, bbase, (uint32_t)mbk * 1024u, boff, l16, (uint32_t)ks, obase, ostride, so, (uint32_t)min(TW, nt - t0), a.head_mul);
     }
 }
 

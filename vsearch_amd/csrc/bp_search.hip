@@ -644,13 +644,11 @@ int bp_filter_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64
             if (a.pace && pass > 0) VS_HIP(hipMemsetAsync(idx->ws_pace.p, 0, (size_t)nchunk * a.blocks_per_chunk * 4, s));
             ProfScope prof("head_gemm", s);
             hipLaunchKernelGGL(head_weights_kernel<0>, dim3(tiles_per_pass), dim3(256), 0, s, h);
-            static const int shape_env = getenv("VS_HEAD_SHAPE") ? atoi(getenv("VS_HEAD_SHAPE")) : 24;     // (developer: waves of a workgroup, documents x tiles)
-            const int hgrid = idx->cu_count * (shape_env == 14 || shape_env == 22 ? 2 : 1);
-            if (shape_env == 18) hipLaunchKernelGGL((head_gemm_kernel<1, 8>), dim3(hgrid), dim3(512), 0, s, h);
-            else if (shape_env == 42) hipLaunchKernelGGL((head_gemm_kernel<4, 2>), dim3(hgrid), dim3(512), 0, s, h);
-            else if (shape_env == 14) hipLaunchKernelGGL((head_gemm_kernel<1, 4>), dim3(hgrid), dim3(256), 0, s, h);
-            else if (shape_env == 22) hipLaunchKernelGGL((head_gemm_kernel<2, 2>), dim3(hgrid), dim3(256), 0, s, h);
-            else hipLaunchKernelGGL((head_gemm_kernel<2, 4>), dim3(hgrid), dim3(512), 0, s, h);
+            // (developer: waves of a workgroup, documents x tiles; 1xx = wide waves.  21 M docs x 1023 head columns x 1024 queries: 114: 56.4 ms,
+            //  24: 76.5, 122: ~ 60 -- the product is bound by operand traffic, and a wide wave moves a third fewer bytes per MFMA)
+            static const int shape_env = getenv("VS_HEAD_SHAPE") ? atoi(getenv("VS_HEAD_SHAPE")) : 114;
+            if (shape_env == 24) hipLaunchKernelGGL((head_gemm_kernel<2, 4>), dim3(idx->cu_count), dim3(512), 0, s, h);
+            else hipLaunchKernelGGL((head_gemm_kernel<1, 4, 1>), dim3(idx->cu_count), dim3(256), 0, s, h);
             VS_HIP(hipGetLastError());
         }
         ProfScope prof("csr_scan_topk", s);
