@@ -965,6 +965,9 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
                     [[maybe_unused]] int32_t pre[QT];
                     if constexpr (HD == 2) {
                         // the dense part of this document's sums (head pre-pass): 8 loads of a slot's 16-document run, in flight together
+                        // (tried and dropped, 21 M docs: the same loads issued BEFORE the block's barrier, or for both of the thread's
+                        //  documents at once right behind it -- the walk went from 126 ms to 161 - 186, the waves' wait at the barrier
+                        //  from 6 k to 22 - 26 k cycles a block: docs/EXPERIMENTS.md)
                         const int32_t* hp = a.head_out + head_out_offset((int64_t)tile_rel, n_blocks, b, a.rows, d);
 #pragma unroll
                         for (int q = 0; q < QT; ++q) pre[q] = q < nq ? hp[q * 16] : 0;
