@@ -311,9 +311,11 @@ def run_leg(name, docs, nnz, kind, store, val_law, steps, B, k, local_rank, devi
         extra["frac_of_lds_add_peak"] = info.last_walk_postings / per_search_s / peak
         extra["lds_add_peak_per_s"] = peak
     if pmc:
-        hbm = pmc["hbm_bytes_per_launch"] / per_search_s / 1e9
+        # (a corpus with head columns: the profiled bytes are the list walk's AND the head pre-pass product's -- so is the time)
+        t_pmc = per_search_s + (pre_ms / 1e3 / max(1, steps + 1) if any("head_gemm" in k for k in pmc.get("kernels", [])) else 0.0)
+        hbm = pmc["hbm_bytes_per_launch"] / t_pmc / 1e9
         rl = roof("hbm", hbm, HBM_PEAK_GBS, "GB/s", traffic=pmc["hbm_bytes_per_launch"],
-                  achieved_is="HBM traffic (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this leg, profiles/pmc_summary.json) / scan kernel time",
+                  achieved_is="HBM traffic (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this leg, profiles/pmc_summary.json) / scan kernel time (+ the head pre-pass product's, where there is one)",
                   traffic_source=pmc.get("source"), **extra)
     else:
         rl = roof("hbm", algo, L2_PEAK_GBS, "GB/s", traffic=None, bound_note="L2: the walk's bytes are L2 / Infinity-Cache served; no PMC pass of this leg on this kernel "

@@ -91,7 +91,7 @@ def main():
         # warm-up search is excluded) of the leg's scan kernel (+ its head pre-pass), divided by the full-batch searches profiled
         pmc_path = os.path.join(a.out, "pmc_summary.json")
         pmc = json.load(open(pmc_path)) if os.path.exists(pmc_path) else {}
-        scan_kernels = ("bp_quad_topk", "bp_walk_topk", "bp_bin_topk", "csr_scan_topk_mq", "head_gemm")
+        scan_kernels = ("bp_quad_topk", "bp_walk_topk", "bp_bin_topk", "bp_bq_topk", "csr_scan_topk_mq", "head_gemm")
         def total(rows):
             vals = [r["KiB"] for r in rows if any(k in r["kernel"] for k in scan_kernels)]
             big = [v for v in vals if v >= 0.2 * max(vals)] if vals else []
@@ -111,7 +111,7 @@ def main():
         # bench-sized launch (largest) of each scan kernel present -> profiles/pmc_summary.json, read by bench.py for roofline.traffic
         pmc_path = os.path.join(a.out, "pmc_summary.json")
         pmc = json.load(open(pmc_path)) if os.path.exists(pmc_path) else {}
-        scan_kernels = ("bp_quad_topk", "bp_walk_topk", "bp_bin_topk", "csr_scan_topk_mq")
+        scan_kernels = ("bp_quad_topk", "bp_walk_topk", "bp_bin_topk", "bp_bq_topk", "csr_scan_topk_mq")
         pmc = {k: v for k, v in pmc.items() if k in scan_kernels or k == "legs"}
         for key in scan_kernels:
             scan = lambda rows: max((r["KiB"] for r in rows if key in r["kernel"]), default=0.0)
