@@ -23,6 +23,9 @@ import sys
 
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 OUT = sys.argv[2] if len(sys.argv) > 2 else "vsearch_amd/csrc/bp_bq_asm.h"
+# experiment ("mask"): pad cells (document >= 2048) sit out their ds_add (v_cmpx_gt_u16_sdwa) -- fewer lanes per bank, 3 more instructions a
+# step: 51.9 ms against 51.0 at 21 M docs (profiles/r05_bq_mask.txt): the LDS conflicts are not what the walk waits for.  Off.
+MASK = (sys.argv[3] if len(sys.argv) > 3 else "nomask") == "mask"
 NW = 16
 STEP = NW * 8 * 8            # bytes between a wave's consecutive steps of the table (8 descriptors of 8 bytes per step); own list: 8 * 8
 V0 = 64
@@ -36,7 +39,7 @@ def d(i, j): return f"v{V0 + 2 * i + j}"
 def p(i): return f"v{V0 + 2 * S + i}"
 def drange(i): return f"v[{V0 + 2 * i}:{V0 + 2 * i + 1}]"
 T0 = (V0 + 3 * S + 1) & ~1
-A0, A1, SO, VOFF, T2 = (f"v{T0 + k}" for k in range(5))
+A0, A1, SO, VOFF, T2, LIM = (f"v{T0 + k}" for k in range(6))
 
 def load(j):
     emit(f"v_and_b32 {VOFF}, 0xffff, {d(j, 0)}")
@@ -65,6 +68,7 @@ def append_links(i):
 def build():
     global out
     out = []
+    emit(f"v_mov_b32 {LIM}, 0x800")                                 # first document id that is not one (pads 2048 .. 2111, links >= 0x8000)
     for k in range(S):
         emit(f"ds_read_b64 {drange(k)}, %[dptr] offset:{k * STEP}")
     emit("s_waitcnt lgkmcnt(0)")
@@ -89,8 +93,16 @@ def build():
             emit(f"v_lshrrev_b32 {SO}, 16, {d(i, 0)}")
             emit(f"v_mad_u32_u16 {A0}, {p(i)}, 4, {SO}")
             emit(f"v_mad_u32_u16 {A1}, {p(i)}, 4, {SO} op_sel:[1,0,0,0]")
-            emit(f"ds_add_u32 {A0}, {d(i, 1)}")
-            emit(f"ds_add_u32 {A1}, {d(i, 1)}")
+            if MASK:
+                # 10 of a list's 16 cells are pads: masked out, a ds_add's active lanes rarely share a bank (a link cell, bit 15, sits out too)
+                emit(f"v_cmpx_gt_u16_sdwa vcc, {LIM}, {p(i)} src0_sel:DWORD src1_sel:WORD_0")
+                emit(f"ds_add_u32 {A0}, {d(i, 1)}")
+                emit(f"v_cmpx_gt_u16_sdwa vcc, {LIM}, {p(i)} src0_sel:DWORD src1_sel:WORD_1")
+                emit(f"ds_add_u32 {A1}, {d(i, 1)}")
+                emit("s_mov_b64 exec, -1")
+            else:
+                emit(f"ds_add_u32 {A0}, {d(i, 1)}")
+                emit(f"ds_add_u32 {A1}, {d(i, 1)}")
             emit(f"6{i}:")
             # set i is consumed: its descriptor registers take the descriptor of step t + S
             emit(f"ds_read_b64 {drange(i)}, %[dptr] offset:{i * STEP}")
@@ -129,7 +141,7 @@ body_list = build()
 STEP = NW * 8 * 8
 COLLECT = True
 body_collect = build()
-vregs = [f"v{r}" for r in range(V0, T0 + 5)]
+vregs = [f"v{r}" for r in range(V0, T0 + 6)]
 def stmt(lines): return "\\n\\t\"\n        \"".join(lines)
 clob = ", ".join(f'"{r}"' for r in vregs)
 def fn(name, lines, what):
@@ -170,4 +182,4 @@ constexpr int kBqOverRead = {S};              // steps a wave reads descriptors 
 }  // namespace vs
 '''
 open(OUT, "w").write(hdr)
-print(f"{OUT}: S {S}, VGPRs v{V0}..v{T0 + 4}, {len(body_add)} + {len(body_list)} + {len(body_collect)} instructions")
+print(f"{OUT}: S {S}, VGPRs v{V0}..v{T0 + 5}, {len(body_add)} + {len(body_list)} + {len(body_collect)} instructions")
