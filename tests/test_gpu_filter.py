@@ -460,8 +460,8 @@ def test_baseline_sized_bag_of_token_index():
 
 
 def test_baseline_sized_skewed_index_with_head_strips():
-    """C3's secondary column law at C4's size: 21 015 324 docs x 768 nnz with Zipf column popularity; 511 head columns become dense
-    strips scored on the matrix cores.  Bit-equal to the CSR scan on a batch slice, no query falls back."""
+    """C3's secondary column law at C4's size: 21 015 324 docs x 768 nnz with Zipf column popularity; 1023 head columns become dense
+    strips, their part of the sums comes from the head pre-pass (bp_head.h).  Bit-equal to the CSR scan on a batch slice, no query falls back."""
     n = 21_015_324
     idx = DeviceIndex.synthetic(0, 0, n, V, 768, synth.KIND_SKEW, 0, nat.VS_F32)
     q = oracle.synth_queries(1, 64, kind=synth.KIND_SKEW)
@@ -471,6 +471,26 @@ def test_baseline_sized_skewed_index_with_head_strips():
     assert info.last_path == 1
     assert (ids[20:28] == ref_ids).all() and (sc[20:28] == ref_sc).all()
     _oracle_pin(0, n, q[20:24], ids[20:24], sc[20:24], 100, kind=synth.KIND_SKEW, windows=24)
+    # the bench's batch shape (1024 queries = 128 tiles: two passes of the head pre-pass over its 43 GB scratch), a slice against the CSR scan
+    qb = oracle.synth_queries(2, 1024, kind=synth.KIND_SKEW)
+    ids_b, sc_b, info = _search(idx, qb, 100, blocked_postings=-1)
+    assert info.last_path == 3 and info.last_fallbacks == 0 and info.head_columns > 512
+    ref_ids, ref_sc, _ = _search(idx, qb[700:708], 100, blocked_postings=0)
+    assert (ids_b[700:708] == ref_ids).all() and (sc_b[700:708] == ref_sc).all()
+
+
+def test_c3_shape_one_million_docs_1024_queries():
+    """BASELINE.json configs[2] at its exact shape: 1 M synthetic docs x 768 nnz sparse CSR, batch 1024, k = 100 -- the filter path against
+    the CSR scan on a slice, bit for bit, and pinned to the CPU oracle."""
+    n = 1_000_000
+    idx = DeviceIndex.synthetic(0, 0, n, V, 768, 0, 0, nat.VS_F32)
+    q = oracle.synth_queries(1, 1024)
+    ids, sc, info = _search(idx, q, 100, blocked_postings=-1)
+    assert info.last_path == 3 and info.last_fallbacks == 0 and info.postings_walk == 4
+    ref_ids, ref_sc, info = _search(idx, q[300:316], 100, blocked_postings=0)
+    assert info.last_path == 1
+    assert (ids[300:316] == ref_ids).all() and (sc[300:316] == ref_sc).all()
+    _oracle_pin(0, n, q[300:304], ids[300:304], sc[300:304], 100, windows=16)
 
 
 def test_head_strips_edge_cases_empty_queries_and_append():

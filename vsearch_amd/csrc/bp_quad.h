@@ -50,7 +50,8 @@ static_assert(2 * kQuadListBytes * kScanWaves <= kBpCap * 8, "the link lists fit
 // postings a chunk holds when its list goes on in another chunk (the last two cells are the link), overflow chunks of a list of n postings
 constexpr int kQuadLinked = kQuadCells - 2;
 constexpr double kQuadMaxRatio = 3.0;                              // auto policy: quad chunks while their main area is within this multiple of the CSR bytes (bp_build)
-constexpr int kQuadPaceDefault = 8;                                // lock-step window in blocks (see the walk)
+constexpr int kQuadPaceDefault = 0;                                // lock-step window in blocks (see the walk): off since the work items take FOUR block chunks
+                                                                   // (round 5: free running 67.0 / 36.5 / 7.57 ms against 69.8 / 37.7 / 7.71 in lock step, 21 M docs B = 512 / 256, 1 M docs B = 1024)
 // overflow chunks of a list of n postings: a chunk holds CELLS postings when it is the list's last, LINKED when another follows it
 template <int CELLS, int LINKED>
 __host__ __device__ constexpr uint32_t chunk_overflow(uint32_t n) { return n > (uint32_t)CELLS ? (n - (uint32_t)CELLS + (uint32_t)LINKED - 1u) / (uint32_t)LINKED : 0u; }
@@ -358,8 +359,9 @@ __global__ __launch_bounds__(kScanThreads) void bp_quad_topk(BpArgs a) {
             }
             lap(1);
             // Lock step (BpArgs::pace): the tiles of a chunk of blocks sweep the same blocks; a workgroup that falls behind the pack loses
-            // the L2 / Infinity Cache copies the others left behind and falls further behind (21 M docs: most workgroups take 133 ms,
-            // a handful 165 - 170, and the launch ends with the last).  An item counts its arrival at the end of block j and waits while
+            // the L2 / Infinity Cache copies the others left behind and falls further behind (21 M docs, TWO block chunks: most workgroups
+            // take 133 ms, a handful 165 - 170, and the launch ends with the last; with the four chunks of round 5 free running is stable
+            // and faster -- the option "postings_pace" still turns the lock step on).  An item counts its arrival at the end of block j and waits while
             // the slowest item of its chunk has not reached block j - window (bounded: pace_wait, bp_walk.h).  Window 2 - 8 blocks: 141 - 143 ms,
             // 16: 152, 32: 161, free running: 134 - 166 (run to run).
             if (a.pace && items <= (int64_t)gridDim.x && tid == 0 && have && !pace_off) {
