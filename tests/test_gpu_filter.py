@@ -231,22 +231,22 @@ def test_signed_values_and_weights():
     compare.check_topk_valid(allsc, got[0], got[1], rtol=RTOL)
 
 
-@pytest.mark.parametrize("nnz", [86, 200, 600], ids=["short-lists", "linked-lists", "long-lists"])
+@pytest.mark.parametrize("nnz,rows,chunks", [(86, 0, 6), (200, 0, 6), (600, 0, 6), (600, 2048, 6), (600, 8192, 5)],
+                         ids=["short-lists", "four-slot-tiles", "small-blocks", "linked-lists", "long-lists"])
 @pytest.mark.parametrize("law", [synth.VAL_DYADIC, synth.VAL_GRID], ids=["dyadic", "fp32-weights"])
-def test_binary_index_on_the_postings_walk(law, nnz):
+def test_binary_index_on_the_postings_walk(law, nnz, rows, chunks):
     """Bag-of-token index (no values): dyadic weights are exact in fixed point (nothing to prove, scores and ids bit-equal to the
-    oracle); arbitrary fp32 weights go through the refine step.  600 tokens a document: lists of ~40 postings, five records --
-    the walk's path for lists beyond the two prefetched records (bp_bin.h) on every list, and a LINKED chain of three 16-cell chunks
-    per list on the bag-of-token chunks (bp_bq.h, the default copy: postings_walk 6); the records (5) and the list walk (0) as well."""
+    oracle); arbitrary fp32 weights go through the refine step.  The default copy is the bag-of-token chunks (bp_bq.h, postings_walk
+    6): 86 tokens a document -> blocks of 6144 documents, two query slots; 200 -> 2048 documents, four slots; 600 -> 768 documents;
+    600 tokens in blocks of 2048: lists of ~42 postings, EVERY list goes on in a linked overflow chunk; in blocks of 8192: 150 k
+    overflow chunks a block, more than a link's 15 bits address -- the build keeps the records of bp_bin.h (5), whose walk then takes
+    its path for lists beyond the two prefetched records on every list.  The records (5) and the list walk (0) are checked as well."""
     n = 30_000 if nnz == 86 else 12_000
     ip, ix, _ = oracle.synth_csr(3, 0, n, V, nnz, synth.KIND_BOT)
     q = oracle.synth_queries(8, 21, val_law=law)
     idx = DeviceIndex.from_csr(ip, ix, None, V)
     ref = _search(idx, q, 100, blocked_postings=0)
-    got = _search(idx, q, 100, blocked_postings=1)
-    # (600 tokens a document: 80 k overflow chunks a block, more than a link's 15 bits address -- the build keeps the records;
-    #  200 tokens: lists of ~14 postings, one in four continues in an overflow chunk)
-    chunks = 6 if nnz <= 200 else 5
+    got = _search(idx, q, 100, blocked_postings=1, postings_rows=rows)
     assert got[2].last_path == 3 and got[2].aux_bytes > 0 and got[2].postings_walk == chunks
     assert (got[0] == ref[0]).all() and (got[1] == ref[1]).all()
     for walk, kind in ((5, 5), (0, 0), (6, chunks)):

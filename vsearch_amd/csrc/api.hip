@@ -89,7 +89,7 @@ extern "C" int vs_index_set_option(vs_index* idx, const char* name, int value) {
         return VS_OK;
     }
     if (n == "postings_rows") {
-        if (value != 0 && (value < 256 || value > 2048 || value % 64)) return fail(VS_EINVAL, "postings_rows: 0 = auto, else a multiple of 64 in 256..2048");
+        if (value != 0 && (value < 256 || value > 8192 || value % 64)) return fail(VS_EINVAL, "postings_rows: 0 = auto, else a multiple of 64 in 256..8192 (clipped to what the index's walk holds: 2048, bag-of-token chunks 8192)");
         idx->bp_rows_pref = value;
         idx->bp_dir.release(); idx->bp_base.release(); idx->bp_rec.release(); idx->bp_ready = false; idx->bp_tried = false;
         return VS_OK;

@@ -1,19 +1,25 @@
-// bp_bq.h -- "bag-of-token chunks": the column-grouped copy of a BINARY (bag-of-token) index as direct-mapped 32-byte chunks, and its
-// walk -- the quad walk (bp_quad.h) re-cut for lists of ~6 postings without values (round 5).
+// bp_bq.h -- "bag-of-token chunks": the column-grouped copy of a BINARY (bag-of-token) index as direct-mapped chunks of uint16 cells, and
+// its walk -- the quad walk (bp_quad.h) re-cut for short lists without values (round 5).
 //
 // What bounds the record walk (bp_bin.h, 17.5 k q/s at 21 M docs): instructions.  A (tile, block) is 6 208 lists of ~6 postings; per
 // list the walk reads a directory word, computes a record address, loads 16 bytes, unpacks 8 ids into 8 addresses, predicates the second
 // record of 1 list in 6: ~ 1 700 instructions per wave and block, 2.3 of per-list bookkeeping for every posting (DESIGN r4 8.2).
 //
-// Here the list of (block b, column c) is chunk c of block b: 32 bytes = 16 cells of uint16 (document in the block); unused cells
-// hold one of the 64 spare documents behind the block's 2048 (their sums are never read; spread, so that a wave's pad cells do not pile
-// up on one LDS address).  No directory is read at search time: a tile's descriptor table {chunk | plane address << 16, integer
-// weight} is built once per work item and serves all its blocks.  A wave step serves EIGHT lists -- an 8-lane group each, a lane
-// loads dword i of the chunk (cells 2 i, 2 i + 1) -- with one ds_read_b64, one global_load_dword and 2 x (v_mad_u32_u16, ds_add_u32):
-// ~ 10 instructions per 8 lists (tools/gen_bq_asm.py; the loop is one generated asm statement with counted waits).  A list of more
-// than 16 postings (1 in 7 000) keeps 15 in its chunk, cell 15 LINKS to an overflow chunk behind the block's main chunks; a wave
-// collects the links it meets in a list of its own and walks that after the table (as the quad walk does).
-// Copy size: n_blocks x n_cols x 32 bytes (9.7 GB at 21 M docs, V = 29 523) against 3.6 GB of CSR packets.
+// Here the list of (block b, column c) is chunk c of block b: kBqCells cells of uint16 (document in the block); unused cells hold one
+// of the kBqSpare spare documents behind a slot's plane (their sums are never read; spread, so that a wave's pad cells do not pile up
+// on one LDS address).  No directory is read at search time: a tile's descriptor table {chunk | plane address << 16, integer weight} is
+// built once per work item and serves all its blocks.  A wave step serves 64 / kBqGroupLanes lists -- a lane group each, a lane loads
+// kBqLaneDwords dwords of the chunk -- with one ds_read_b64, one global_load and 2 x kBqLaneDwords x (v_mad_u32_u16, ds_add_u32)
+// (tools/gen_bq_asm.py; the loop is one generated asm statement with counted waits).  A list longer than a chunk keeps kBqLinked
+// postings in it, the last cell LINKS to an overflow chunk behind the block's main chunks; a wave collects the links it meets in a
+// list of its own and walks that after the table (as the quad walk does).
+//
+// BLOCK SHAPE.  What the walk waits for is line requests (a CU's L1 gets ~ 0.19 lines a clock from L2 whatever they hold) and LDS adds;
+// both are paid per LIST VISIT, and a visit serves as many (document, query) pairs as the block has documents -- the query slots only
+// share the block's barriers.  So: as many documents per block as keep a list inside its chunk (18 postings a list on average for 32
+// cells: 1 list in ~ 700 overflows), and as many query slots as the LDS then has room for: 2 slots of up to 8192 documents, or 4 of up
+// to 4096 (the first form: 16-cell chunks, 2048 documents x 8 slots, 50.9 ms at 21 M docs x 1024 queries; this one: see DESIGN 4).
+// Copy size: n_blocks x n_cols x 64 bytes (6.5 GB at 21 M docs, V = 29 523, 6144-document blocks) against 3.6 GB of CSR packets.
 //
 // Same arithmetic as bp_bin_topk: integer weight (the query's weight x its power-of-two scale: exact for dyadic weights) added
 // with ds_add_u32 into slot-major int32 planes -- sums, candidates and results are bit-identical (tests/test_gpu_filter.py).
@@ -24,32 +30,49 @@
 
 namespace vs {
 
-constexpr int kBqCells = 16, kBqLinked = 15, kBqChunkBytes = 32;
-constexpr int kBqPaceDefault = 0;                                     // lock-step window in blocks: off (21 M docs: free running 50.9 ms, window 4: 61.2, 16: 56.8, 32: 52.6)
-constexpr int kBqStepDesc = 8;                                        // descriptors (lists) of a wave step
-constexpr int kBqTableStep = kScanWaves * kBqStepDesc;               // descriptors of one step of all 16 waves: 128
-constexpr uint32_t kBqPlane = (uint32_t)(kBpRowsMaxBin + kBinSpare) * 4u;     // bytes of a slot plane (bp_bin.h: 2048 documents + 66 spare)
-static_assert(7u * kBqPlane < 65536u, "plane addresses fit the descriptor's high half");
-__host__ __device__ constexpr size_t bq_fixed_lds() { return (size_t)8 * kBqPlane + (size_t)kFlCap * 8 + 8 * 16 + 32 * 4; }
-__host__ __device__ constexpr size_t bq_lds_bytes() { return bq_fixed_lds() + (size_t)(kBpEntCap + kBqTableStep + kBqTableStep * kBqOverRead) * 8; }
-static_assert(bq_lds_bytes() <= (size_t)160 * 1024, "the chunk walk's LDS");
-// a wave's two link lists live in its share of the candidate sort buffer (32 KB / 16 waves = 2 KB): 64 descriptors each, of which
-// 8 * kBqOverRead are the null ones a walk over-reads
-constexpr int kBqListCap = 64 - kBqStepDesc * kBqOverRead, kBqListBytes = 64 * 8;
-static_assert(kBqListCap >= 16 && 2 * kBqListBytes * kScanWaves <= kFlCap * 8, "the link lists fit the sort buffer");
-// pad cell of (column c, cell j): one of the 64 spare documents, spread over lanes and neighbouring columns
-__host__ __device__ constexpr uint16_t bq_pad(uint32_t c, uint32_t j) { return (uint16_t)(kBpRowsMaxBin + (((c & 7u) << 3) | (j >> 1))); }
+constexpr int kBqCells = 2 * kBqGroupLanes * kBqLaneDwords, kBqLinked = kBqCells - 1, kBqChunkBytes = 2 * kBqCells;
+constexpr int kBqRowsMax = 8192;                                      // documents per block, at most (2 query slots; <= 4096: 4 slots)
+constexpr int kBqSpare = 256;                                         // spare documents behind a slot's plane: the pad cells' targets
+constexpr int kBqFill = 18;                                           // postings a list should hold on average (of kBqLinked + 1 cells)
+constexpr int kBqPaceDefault = 0;                                     // lock-step window in blocks: off (16-cell form, 21 M docs: free running 50.9 ms, window 4: 61.2, 16: 56.8, 32: 52.6)
+constexpr int kBqStepDesc = 64 / kBqGroupLanes;                       // descriptors (lists) of a wave step
+constexpr int kBqTableStep = kScanWaves * kBqStepDesc;               // descriptors of one step of all 16 waves
+__host__ __device__ constexpr int bq_slots(int rows) { return rows > 4096 ? 2 : 4; }                 // query slots of a tile
+__host__ __device__ constexpr int bq_rmax(int qt) { return qt == 2 ? 8192 : 4096; }                  // documents a slot's plane holds
+__host__ __device__ constexpr uint32_t bq_plane(int qt) { return (uint32_t)(bq_rmax(qt) + kBqSpare) * 4u; }     // bytes of a slot plane
+static_assert(3u * bq_plane(4) < 65536u && bq_plane(2) < 65536u, "plane addresses fit the descriptor's high half");
+static_assert((size_t)2 * bq_plane(2) >= 65536 && (size_t)4 * bq_plane(4) >= 65536, "the planes double as the 8192-key entry sort buffer");
+__host__ __device__ constexpr size_t bq_fixed_lds(int qt) { return (size_t)qt * bq_plane(qt) + (size_t)kFlCap * 8 + 8 * 16 + 32 * 4; }
+// (query, column) entries per tile: whole thousands, as many as the LDS holds beside the planes of a four-slot tile, the candidate sort
+// buffer and the null steps a walk over-reads (and the 8192-key entry sort: kBpEntCap)
+constexpr int bq_ent_cap() {
+    const int room = (160 * 1024 - (int)bq_fixed_lds(4)) / 8 - kBqTableStep * (1 + kBqOverRead);
+    return room / 1024 * 1024 < kBpEntCap ? room / 1024 * 1024 : kBpEntCap;
+}
+constexpr int kBqEntCap = bq_ent_cap();
+static_assert(kBqEntCap >= 4096, "a tile holds two queries of 2048 tokens");
+__host__ __device__ constexpr size_t bq_lds_bytes(int qt) { return bq_fixed_lds(qt) + (size_t)(kBqEntCap + kBqTableStep + kBqTableStep * kBqOverRead) * 8; }
+static_assert(bq_lds_bytes(2) <= (size_t)160 * 1024 && bq_lds_bytes(4) <= (size_t)160 * 1024, "the chunk walk's LDS");
+// a wave's two link lists live in its share of the candidate sort buffer (32 KB / 16 waves = 2 KB): 128 descriptors each, of which
+// kBqStepDesc * kBqOverRead are the null ones a walk over-reads
+constexpr int kBqListSlots = kFlCap / kScanWaves / 2, kBqListCap = kBqListSlots - kBqStepDesc * kBqOverRead, kBqListBytes = kBqListSlots * 8;
+static_assert(kBqListCap >= 16 && kBqListCap % kBqStepDesc == 0, "the link lists fit the sort buffer");
+// pad cell of (column c, cell j): one of the spare documents behind the plane (pad0 = the plane's document capacity), spread over the
+// cells of a chunk and over neighbouring columns
+__host__ __device__ constexpr uint16_t bq_pad(uint32_t pad0, uint32_t c, uint32_t j) { return (uint16_t)(pad0 + (((c & 15u) << 4) | ((j >> 1) & 15u))); }
+static_assert(kBqCells <= 64 && kBqRowsMax + kBqSpare < 32768, "a cell is a document below 2^15 or a link (bit 15)");
 
-// ---- builder: quad_count_kernel<16, 15> (postings per column -> overflow chunks, directory for the fill) -> bp_base_kernel -> fill --------
+// ---- builder: quad_count_kernel<kBqCells, kBqLinked> (postings per column -> overflow chunks, directory for the fill) -> bp_base_kernel -> fill --
 // fill: one workgroup per block: pad cells first (every main chunk, then the overflow chunks), then the block's non-zeros in arrival
 // order, then the links
 template <int UNUSED>
-__global__ __launch_bounds__(kScanThreads) void bq_fill_kernel(const uint32_t* pk_ptr, const uint4* cols, int64_t n_rows, int32_t n_cols, int32_t rows,
+__global__ __launch_bounds__(kScanThreads) void bq_fill_kernel(const uint32_t* pk_ptr, const uint4* cols, int64_t n_rows, int32_t n_cols, int32_t rows, uint32_t pad0,
                                                                const uint32_t* dir, const unsigned long long* base, uint16_t* rec) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint32_t* cur = reinterpret_cast<uint32_t*>(smem);                  // [n_cols + 1] postings placed so far
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int64_t n_blocks = (n_rows + rows - 1) / rows;
+    constexpr uint32_t kParts = kBqCells / 8;                           // 16-byte parts of a chunk
     for (int64_t b = blockIdx.x; b < n_blocks; b += gridDim.x) {
         const int64_t r0 = b * rows, r1 = min(n_rows, r0 + rows);
         const uint32_t* d = dir + (size_t)b * (n_cols + 1);
@@ -58,11 +81,11 @@ __global__ __launch_bounds__(kScanThreads) void bq_fill_kernel(const uint32_t* p
         uint16_t* brec = rec + (size_t)base[b] * kBqCells;
         const uint32_t n_over = d[n_cols] >> 12;                        // (quad_count_kernel: the block's overflow chunks)
         // pads: 8 cells (16 bytes) per thread and turn
-        for (uint32_t i = tid; i < ((uint32_t)n_cols + n_over) * 2u; i += kScanThreads) {
-            const uint32_t chunk = i >> 1, j0 = (i & 1u) * 8u;
+        for (uint32_t i = tid; i < ((uint32_t)n_cols + n_over) * kParts; i += kScanThreads) {
+            const uint32_t chunk = i / kParts, j0 = (i % kParts) * 8u;
             uint32_t wds[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) wds[k] = (uint32_t)bq_pad(chunk, j0 + 2 * k) | ((uint32_t)bq_pad(chunk, j0 + 2 * k + 1) << 16);
+            for (int k = 0; k < 4; ++k) wds[k] = (uint32_t)bq_pad(pad0, chunk, j0 + 2 * k) | ((uint32_t)bq_pad(pad0, chunk, j0 + 2 * k + 1) << 16);
             reinterpret_cast<uint4*>(brec)[i] = make_uint4(wds[0], wds[1], wds[2], wds[3]);
         }
         __syncthreads();
@@ -77,8 +100,8 @@ __global__ __launch_bounds__(kScanThreads) void bq_fill_kernel(const uint32_t* p
                     const uint32_t c = (i & 1) ? (cwv[i >> 1] >> 16) : (cwv[i >> 1] & 0xFFFFu);
                     if (c < (uint32_t)n_cols) {
                         const uint32_t pos = atomicAdd(&cur[c], 1u);
-                        // chunk k of the list (0: the main chunk = chunk c, k >= 1: overflow chunk first + k - 1) holds 15 postings when
-                        // another follows it, up to 16 when it is the last
+                        // chunk k of the list (0: the main chunk = chunk c, k >= 1: overflow chunk first + k - 1) holds kBqLinked postings
+                        // when another follows it, up to kBqCells when it is the last
                         const uint32_t wd = d[c], m = wd & kBpDirRecMask;
                         const uint32_t k = m ? min(pos / (uint32_t)kBqLinked, m) : 0u;
                         const size_t chunk = k == 0 ? (size_t)c : (size_t)n_cols + (wd >> 12) + (k - 1);
@@ -93,29 +116,34 @@ __global__ __launch_bounds__(kScanThreads) void bq_fill_kernel(const uint32_t* p
             const uint32_t wd = d[c], m = wd & kBpDirRecMask;
             for (uint32_t k = 0; k < m; ++k) {
                 const size_t chunk = k == 0 ? (size_t)c : (size_t)n_cols + (wd >> 12) + (k - 1);
-                brec[chunk * kBqCells + 15] = (uint16_t)(0x8000u | ((wd >> 12) + k));
+                brec[chunk * kBqCells + (kBqCells - 1)] = (uint16_t)(0x8000u | ((wd >> 12) + k));
             }
         }
     }
 }
 
 // ---- walk -----------------------------------------------------------------------------------------------------------
-// Work items, tiles, thresholds and candidate handling as bp_bin_topk (epilogue: a thread finishes documents 2 t and 2 t + 1).
-// BpArgs::rec = the chunks, base[b] = first chunk of block b.
-template <int TM>          // TM = 1: phase clocks (VS_BP_TIMING)
+// Work items, tiles, thresholds and candidates as bp_bin_topk.  BpArgs::rec = the chunks, base[b] = first chunk of block b.
+// Epilogue: thread t finishes documents 4 t .. 4 t + 3 (and 4096 + 4 t ..: two-slot tiles) of every slot: 16 sums in registers from
+// 4 ds_read_b128, zeroed with 4 ds_write_b128.  A block may hold more candidates than the candidate buffer has room for (a slot keeps
+// kFlCap keys per workgroup, a block has up to 8192 documents): a push that finds no room stays PENDING in its thread, the buffer is
+// sorted and cut to the best K' (which raises the threshold), and the pending sums are tested again -- a few turns in a work item's
+// first block, none later.
+template <int QT, int TM>          // QT = query slots (2: blocks of up to 8192 documents, 4: up to 4096); TM = 1: phase clocks (VS_BP_TIMING)
 __global__ __launch_bounds__(kScanThreads) void bp_bq_topk(BpArgs a) {
-    constexpr int QT = 8, RMAX = kBpRowsMaxBin;
-    static_assert(RMAX == 2 * kScanThreads, "a thread finishes documents 2 t and 2 t + 1");
+    constexpr int RMAX = bq_rmax(QT), NH = RMAX / (4 * kScanThreads);
+    constexpr uint32_t PLANE = bq_plane(QT);
+    static_assert(QT * NH * 4 == 16 && (QT == 2 || QT == 4), "a thread finishes 16 sums");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int32_t* acc = reinterpret_cast<int32_t*>(smem);                                        // [QT][RMAX + spare], LDS address 0 (no static LDS in this kernel)
-    uint64_t* sortbuf = reinterpret_cast<uint64_t*>(smem + (size_t)QT * kBqPlane);          // [kFlCap]; during a walk: the waves' link lists
+    uint64_t* sortbuf = reinterpret_cast<uint64_t*>(smem + (size_t)QT * PLANE);             // [kFlCap]; during a walk: the waves' link lists
     unsigned long long* tau = reinterpret_cast<unsigned long long*>(sortbuf + kFlCap);      // [8]
     unsigned long long* upper_sh = tau + 8;                                                 // [8]
     int* scratch = reinterpret_cast<int*>(upper_sh + 8);                                    // [16]
     unsigned int* ccnt = reinterpret_cast<unsigned int*>(scratch + 16);                     // [16]
-    uint2* desc = reinterpret_cast<uint2*>(ccnt + 16);                                      // [n_static + 128 * kBqOverRead]
-    const uint32_t desc_lds = (uint32_t)bq_fixed_lds();
-    const uint32_t sort_lds = (uint32_t)QT * kBqPlane;
+    uint2* desc = reinterpret_cast<uint2*>(ccnt + 16);                                      // [n_static + kBqTableStep * kBqOverRead]
+    const uint32_t desc_lds = (uint32_t)bq_fixed_lds(QT);
+    const uint32_t sort_lds = (uint32_t)QT * PLANE;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int K = a.k;
@@ -125,7 +153,8 @@ __global__ __launch_bounds__(kScanThreads) void bp_bq_topk(BpArgs a) {
     const unsigned long long k_rt0 = TM ? __builtin_amdgcn_s_memrealtime() : 0ull;
     auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
     const uint32_t list_a = sort_lds + (uint32_t)wv * 2u * kBqListBytes, list_b = list_a + kBqListBytes;
-    const uint32_t g8 = (uint32_t)(lane >> 3) * 8u, l4 = (uint32_t)(lane & 7) * 4u;
+    const uint32_t g8 = (uint32_t)(lane / kBqGroupLanes) * 8u, l4 = (uint32_t)(lane % kBqGroupLanes) * (uint32_t)(kBqLaneDwords * 4);
+    constexpr uint32_t kWaveStep = kBqStepDesc * 8u;                    // bytes of a wave's descriptors of one step
 
     for (int64_t item = blockIdx.x; item < items; item += gridDim.x) {
         const int tile = (int)(item / a.nchunk), c = (int)(item % a.nchunk);
@@ -164,13 +193,13 @@ __global__ __launch_bounds__(kScanThreads) void bp_bq_topk(BpArgs a) {
                 if (i < n_ent) {
                     const uint64_t key = skey[i];
                     const uint32_t col = 0xFFFFu - ((uint32_t)(key >> 40) & 0xFFFFu), qs = (uint32_t)(key >> 32) & 0xFFu;
-                    dsc = make_uint2(col | ((qs * kBqPlane) << 16), (uint32_t)(int32_t)__uint_as_float((uint32_t)key));       // integer weight (bp_bin.h)
+                    dsc = make_uint2(col | ((qs * PLANE) << 16), (uint32_t)(int32_t)__uint_as_float((uint32_t)key));       // integer weight (bp_bin.h)
                 }
                 desc[i] = dsc;
             }
             __syncthreads();
         }
-        for (int i = tid; i < (int)(QT * kBqPlane / 4); i += kScanThreads) acc[i] = 0;
+        for (int i = tid; i < (int)(QT * PLANE / 4); i += kScanThreads) acc[i] = 0;
         if (tid < 8) { tau[tid] = 0ull; ccnt[tid] = 0u; upper_sh[tid] = (a.upper && tid < nq) ? a.upper[q0 + tid] : ~0ull; }
         __syncthreads();
         const uint32_t trips = (uint32_t)(n_static / kBqTableStep);
@@ -180,29 +209,34 @@ __global__ __launch_bounds__(kScanThreads) void bp_bq_topk(BpArgs a) {
         for (int64_t b = b0; b < b1 || b == b0; ++b) {
             const bool have = b < b1;
             const int rows_b = have ? (int)min((int64_t)a.rows, a.n_rows - b * a.rows) : 0;
+            // (the other workgroups' thresholds: asked for before the walk, used behind it -- read after the walk, the load's latency is
+            //  what every wave waits for at the block's barrier)
+            const unsigned long long g_tau = (a.gtau && tid < nq) ? __builtin_nontemporal_load(a.gtau + q0 + tid) : 0ull;
+            const unsigned long long base_next = b + 1 < b1 ? a.base[b + 1] : 0ull;       // (likewise: the next block's first chunk)
             if (have && trips > 0) {
                 const char* brec = a.rec + (size_t)base_cur * kBqChunkBytes;
                 // the overflow chunks a walk found: the wave's list `cur` holds n of them; their own links go to the other list
                 auto chain = [&](uint32_t n, uint32_t cur, uint32_t nxt) {
-                    // (a list has at most RMAX / 15 + 1 chunks: the bound keeps a corrupt link from hanging the GPU)
+                    // (a list has at most RMAX / kBqLinked + 1 chunks: the bound keeps a corrupt link from hanging the GPU)
                     for (int depth = 0; n > 0 && depth < RMAX / kBqLinked + 2; ++depth) {
-                        const uint32_t n_pad = (n + 7u) & ~7u;
-                        if ((uint32_t)lane < n_pad - n + 8u * kBqOverRead)
-                            reinterpret_cast<uint2*>(smem + cur)[n + (uint32_t)lane] = make_uint2(0u, 0u);      // null descriptors behind the list (smem = LDS address 0)
+                        const uint32_t n_pad = (n + (uint32_t)kBqStepDesc - 1u) / (uint32_t)kBqStepDesc * (uint32_t)kBqStepDesc;
+                        for (uint32_t i = (uint32_t)lane; i < n_pad - n + (uint32_t)(kBqStepDesc * kBqOverRead); i += 64u)
+                            reinterpret_cast<uint2*>(smem + cur)[n + i] = make_uint2(0u, 0u);       // null descriptors behind the list (smem = LDS address 0)
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                        n = bq_list_asm(cur + g8, n_pad / 8u, brec, l4, (uint32_t)a.n_cols, nxt, (uint32_t)kBqListCap);
+                        n = bq_list_asm(cur + g8, n_pad / (uint32_t)kBqStepDesc, brec, l4, (uint32_t)a.n_cols, nxt, (uint32_t)kBqListCap);
                         const uint32_t t = cur; cur = nxt; nxt = t;
                     }
                 };
-                const uint32_t n_link = bq_walk_asm(desc_lds + (uint32_t)wv * 64u + g8, trips, brec, l4, (uint32_t)a.n_cols, list_a, (uint32_t)kBqListCap);
+                const uint32_t n_link = bq_walk_asm(desc_lds + (uint32_t)wv * kWaveStep + g8, trips, brec, l4, (uint32_t)a.n_cols, list_a, (uint32_t)kBqListCap);
                 if (n_link <= (uint32_t)kBqListCap) {
                     chain(n_link, list_a, list_b);
                 } else {
                     // more links than the list holds (a tile of very long lists): the table's chunks are added, their links are collected
                     // again, as many steps at a time as the list has room for
-                    constexpr uint32_t kSeg = kBqListCap / 8;
+                    constexpr uint32_t kSeg = kBqListCap / kBqStepDesc;
                     for (uint32_t t0 = 0; t0 < trips; t0 += kSeg) {
-                        const uint32_t n = bq_collect_asm(desc_lds + (uint32_t)wv * 64u + g8 + t0 * 1024u, min(kSeg, trips - t0), brec, l4, (uint32_t)a.n_cols, list_a, (uint32_t)kBqListCap);
+                        const uint32_t n = bq_collect_asm(desc_lds + (uint32_t)wv * kWaveStep + g8 + t0 * (uint32_t)(kBqTableStep * 8), min(kSeg, trips - t0), brec, l4,
+                                                          (uint32_t)a.n_cols, list_a, (uint32_t)kBqListCap);
                         chain(n, list_a, list_b);
                     }
                 }
@@ -218,75 +252,112 @@ __global__ __launch_bounds__(kScanThreads) void bp_bq_topk(BpArgs a) {
                     if (!pace_wait(pc + rel - a.pace_window, need)) pace_off = true;
                 }
             }
-            if (b + 1 < b1) base_cur = a.base[b + 1];
-            if (a.gtau && tid < nq) { const unsigned long long g = a.gtau[q0 + tid]; if (g > tau[tid]) tau[tid] = g; }
+            if (b + 1 < b1) base_cur = base_next;
+            if (a.gtau && tid < nq && g_tau > tau[tid]) tau[tid] = g_tau;
             lds_barrier();                                               // the block's sums are complete
             lap(2);
             {
-                const int d = 2 * tid;
                 uint32_t thi[QT];
                 {
                     const uint4* t4 = reinterpret_cast<const uint4*>(tau);
 #pragma unroll
                     for (int i = 0; i < QT / 2; ++i) { const uint4 t = t4[i]; thi[2 * i] = t.y; thi[2 * i + 1] = t.w; }
                 }
-                if (d < rows_b) {
-                    const int64_t row = (int64_t)b * a.rows + d;
-                    uint2 sums[QT];
+                // fast test first: the epilogue is bound by VALU issue (4 waves a SIMD), and behind a work item's first blocks hardly a
+                // sum passes its threshold -- the largest of a thread's 4 sums of a (slot, half) against it (signed: the raw sum against
+                // the biased threshold), one wave-uniform branch; only a wave with a hit works out which sums they are
+                int32_t raw[QT][NH][4];
+                bool hit = false;
 #pragma unroll
-                    for (int q = 0; q < QT; ++q) sums[q] = *reinterpret_cast<const uint2*>(acc + q * (RMAX + kBinSpare) + d);
+                for (int q = 0; q < QT; ++q) {
+                    const int32_t thr = q < nq ? (int32_t)(thi[q] ^ 0x80000000u) : 0x7FFFFFFF;
 #pragma unroll
-                    for (int q = 0; q < QT; ++q) *reinterpret_cast<uint2*>(acc + q * (RMAX + kBinSpare) + d) = make_uint2(0u, 0u);
-#pragma unroll
-                    for (int q = 0; q < QT; ++q) {
-                        const uint32_t h0 = sums[q].x ^ 0x80000000u, h1 = sums[q].y ^ 0x80000000u;
-                        if (q < nq && (h0 >= thi[q] || h1 >= thi[q])) {
-                            const uint64_t k0 = ((uint64_t)h0 << 32) | (uint32_t)(~(uint32_t)row);
-                            const uint64_t k1 = ((uint64_t)h1 << 32) | (uint32_t)(~(uint32_t)(row + 1));
-                            const unsigned long long tq = tau[q], uq = upper_sh[q];
-                            if (k0 > tq && k0 < uq) {
-                                const uint32_t pos = atomicAdd(&ccnt[q], 1u);
-                                my_gcand[(size_t)q * kFlCap + pos] = k0;
-                            }
-                            if (d + 1 < rows_b && k1 > tq && k1 < uq) {
-                                const uint32_t pos = atomicAdd(&ccnt[q], 1u);
-                                my_gcand[(size_t)q * kFlCap + pos] = k1;
-                            }
-                        }
+                    for (int h = 0; h < NH; ++h) {
+                        uint4* p4 = reinterpret_cast<uint4*>(acc + q * (RMAX + kBqSpare) + h * 4096 + 4 * tid);
+                        const uint4 v = *p4;
+                        *p4 = make_uint4(0u, 0u, 0u, 0u);
+                        raw[q][h][0] = (int32_t)v.x; raw[q][h][1] = (int32_t)v.y; raw[q][h][2] = (int32_t)v.z; raw[q][h][3] = (int32_t)v.w;
+                        hit = hit || max(max(raw[q][h][0], raw[q][h][1]), max(raw[q][h][2], raw[q][h][3])) >= thr;
                     }
                 }
-                lds_barrier();
+                uint32_t sums[QT][NH][4];
+                uint32_t pend = 0u;                                      // bit (q * NH + h) * 4 + j: a candidate not yet in the buffer
+                if (__builtin_amdgcn_ballot_w64(hit) != 0ull) {
+#pragma unroll
+                    for (int q = 0; q < QT; ++q)
+#pragma unroll
+                        for (int h = 0; h < NH; ++h)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                sums[q][h][j] = (uint32_t)raw[q][h][j] ^ 0x80000000u;
+                                if (q < nq && h * 4096 + 4 * tid + j < rows_b && sums[q][h][j] >= thi[q]) pend |= 1u << ((q * NH + h) * 4 + j);
+                            }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < QT; ++q)
+#pragma unroll
+                        for (int h = 0; h < NH; ++h)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) sums[q][h][j] = 0u;
+                }
                 const bool last = b + 1 >= b1;
-                uint32_t cnts[QT];
-                {
-                    const uint4* c4 = reinterpret_cast<const uint4*>(ccnt);
-                    const uint4 c0 = c4[0], c1 = c4[1];
-                    cnts[0] = c0.x; cnts[1] = c0.y; cnts[2] = c0.z; cnts[3] = c0.w; cnts[4] = c1.x; cnts[5] = c1.y; cnts[6] = c1.z; cnts[7] = c1.w;
-                }
-                bool any = last;
+                for (;;) {
+                    if (pend != 0u) {
 #pragma unroll
-                for (int q = 0; q < QT; ++q) any = any || cnts[q] > (uint32_t)(kFlCap - RMAX);
-                if (any) __syncthreads();                        // (the candidates pushed above are read back: a full barrier)
-                if (any)
-                for (int qs = 0; qs < nq; ++qs) {
-                    const uint32_t cn = ccnt[qs];
-                    if (last || cn > (uint32_t)(kFlCap - RMAX)) {
-                        for (int i = tid; i < kFlCap; i += kScanThreads) sortbuf[i] = (uint32_t)i < cn ? my_gcand[(size_t)qs * kFlCap + i] : 0ull;
-                        wg_sort_desc<kScanThreads>(sortbuf, kFlCap, tid);
-                        if (last) {
-                            uint64_t* out = a.cand + ((size_t)(q0 + qs) * a.nchunk + c) * (size_t)K;
-                            for (int i = tid; i < K; i += kScanThreads) out[i] = sortbuf[i];
-                        } else if (cn > (uint32_t)K) {
-                            for (int i = tid; i < K; i += kScanThreads) my_gcand[(size_t)qs * kFlCap + i] = sortbuf[i];
-                            if (tid == 0) {
-                                const unsigned long long kth = sortbuf[K - 1];
-                                if (kth > tau[qs]) tau[qs] = kth;
-                                if (a.gtau && kth != 0ull) atomicMax(a.gtau + q0 + qs, kth);
-                                ccnt[qs] = (uint32_t)K;
-                            }
-                        }
-                        __syncthreads();
+                        for (int q = 0; q < QT; ++q)
+#pragma unroll
+                            for (int h = 0; h < NH; ++h)
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+                                    const uint32_t bit = 1u << ((q * NH + h) * 4 + j);
+                                    if (pend & bit) {
+                                        const int64_t row = (int64_t)b * a.rows + h * 4096 + 4 * tid + j;
+                                        const uint64_t key = ((uint64_t)sums[q][h][j] << 32) | (uint32_t)(~(uint32_t)row);
+                                        bool keep = false;
+                                        if (key > tau[q] && key < upper_sh[q]) {
+                                            const uint32_t pos = atomicAdd(&ccnt[q], 1u);
+                                            if (pos < (uint32_t)kFlCap) my_gcand[(size_t)q * kFlCap + pos] = key;
+                                            else keep = true;               // no room: again after the buffer's cut
+                                        }
+                                        if (!keep) pend &= ~bit;
+                                    }
+                                }
                     }
+                    lds_barrier();
+                    uint32_t cnts[QT];
+                    {
+                        const uint4 c0 = *reinterpret_cast<const uint4*>(ccnt);
+                        cnts[0] = c0.x; cnts[1] = c0.y;
+                        if constexpr (QT == 4) { cnts[2] = c0.z; cnts[3] = c0.w; }
+                    }
+                    bool over = false, any = last;
+#pragma unroll
+                    for (int q = 0; q < QT; ++q) { over = over || cnts[q] > (uint32_t)kFlCap; any = any || cnts[q] > (uint32_t)(kFlCap / 2); }
+                    if (!any) break;
+                    __syncthreads();                                 // (the candidates pushed above are read back: a full barrier)
+                    for (int qs = 0; qs < nq; ++qs) {
+                        const uint32_t cn = min(cnts[qs], (uint32_t)kFlCap);
+                        if (last || cn > (uint32_t)(kFlCap / 2)) {
+                            for (int i = tid; i < kFlCap; i += kScanThreads) sortbuf[i] = (uint32_t)i < cn ? my_gcand[(size_t)qs * kFlCap + i] : 0ull;
+                            wg_sort_desc<kScanThreads>(sortbuf, kFlCap, tid);
+                            if (last && !over) {
+                                uint64_t* out = a.cand + ((size_t)(q0 + qs) * a.nchunk + c) * (size_t)K;
+                                for (int i = tid; i < K; i += kScanThreads) out[i] = sortbuf[i];
+                            } else if (cn > (uint32_t)K) {
+                                for (int i = tid; i < K; i += kScanThreads) my_gcand[(size_t)qs * kFlCap + i] = sortbuf[i];
+                                if (tid == 0) {
+                                    const unsigned long long kth = sortbuf[K - 1];
+                                    if (kth > tau[qs]) tau[qs] = kth;
+                                    if (a.gtau && kth != 0ull) atomicMax(a.gtau + q0 + qs, kth);
+                                    ccnt[qs] = (uint32_t)K;
+                                }
+                            } else if (tid == 0) {
+                                ccnt[qs] = cn;
+                            }
+                            __syncthreads();
+                        }
+                    }
+                    if (!over) break;
                 }
             }
             lap(4);

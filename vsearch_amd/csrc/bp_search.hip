@@ -77,9 +77,10 @@ int launch_bp_walk(const vs_index* idx, const BpArgs& a, int grid, int ent_cap, 
         lds = quad_lds_bytes();
     } else if (idx->bp_bq) {
         // bag-of-token chunks (bp_bq.h): the fixed-point filter walk only
-        if (AM != AM_FIX || a.upper || ent_cap > kBpEntCap) return fail(VS_EUNSUPPORTED, "bag-of-token chunks serve the filter walk only");
-        kern = a.timing ? bp_bq_topk<1> : bp_bq_topk<0>;
-        lds = bq_lds_bytes();
+        if (AM != AM_FIX || a.upper || ent_cap > kBqEntCap) return fail(VS_EUNSUPPORTED, "bag-of-token chunks serve the filter walk only");
+        const int bq_qt = bq_slots(idx->bp_rows);
+        kern = bq_qt == 2 ? (a.timing ? bp_bq_topk<2, 1> : bp_bq_topk<2, 0>) : (a.timing ? bp_bq_topk<4, 1> : bp_bq_topk<4, 0>);
+        lds = bq_lds_bytes(bq_qt);
 #ifdef VS_EXPERIMENTAL_WALKS
     } else if (AM == AM_FIX && bp_duo_ok(idx, a.k, a.upper) && ent_cap <= kDuoEntCap) {
         if (vm == VM_F32) kern = bp_duo_topk<VM_F32, kBpNB, kBpRowsMax>;
@@ -151,18 +152,25 @@ int bp_build(vs_index* idx, hipStream_t s) {
     const bool quad_pref = idx->store_dtype != VS_NONE && idx->bp_filter != 0 && idx->n_cols <= 32768 && (idx->bp_walk_pref == -1 || idx->bp_walk_pref == 4) && !idx->bp_no_quad &&
                            idx->bp_align_pref != 1 && idx->bp_arrange_pref != 1 && (idx->store_dtype == VS_F16 || idx->bp_quant_pref != 0) && quad_dense_enough;
     // Bag-of-token chunks (bp_bq.h) -- the default copy of a binary index searched by filter + refine: every (block, column) list is a
-    // direct-mapped 32-byte chunk (n_blocks x n_cols x 32 bytes: 9.7 GB at 21 M docs against 3.6 GB of packets).  "postings_walk" = 5
+    // direct-mapped 64-byte chunk (n_blocks x n_cols x 64 bytes: 6.5 GB at 21 M docs against 3.6 GB of packets).  "postings_walk" = 5
     // keeps the records of bp_bin.h, 0 the list walk; when the chunks do not fit HBM the records are built instead.
     const bool bq_pref = idx->store_dtype == VS_NONE && idx->bp_filter != 0 && idx->n_cols <= 32768 && (idx->bp_walk_pref == -1 || idx->bp_walk_pref == 6) && !idx->bp_no_quad;
     idx->bp_no_quad = false;
     auto auto_rows = [&]() -> int {
+        const double avg_nnz = idx->n_rows > 0 ? (double)idx->nnz / (double)idx->n_rows : 1.0;
+        // (chunks: blocks of as many documents as keep kBqFill postings a list on average -- whole thousands up to kBqRowsMax, quarters
+        //  of a thousand below 1024; bp_bq.h)
+        if (bq_pref) {
+            const int r = (int)std::min(65536.0, (double)kBqFill * (double)idx->n_cols / std::max(avg_nnz, 1.0));
+            return std::max(256, std::min(r >= 1024 ? r / 1024 * 1024 : r / 256 * 256, kBqRowsMax));
+        }
         if (idx->store_dtype == VS_NONE) return kBpRowsMaxBin;
         const double avg = idx->n_rows > 0 ? (double)idx->nnz / (double)idx->n_rows : 1.0;
         // (quad chunks: at 50 postings a list 1 list in 40 goes on in an overflow chunk; 2048 documents per block measured the same)
         const int r = (int)(50.0 * (double)idx->n_cols / std::max(avg, 1.0)) / 128 * 128;
         return std::max(256, std::min(r, kBpRowsMax));
     };
-    idx->bp_rows = idx->bp_rows_pref > 0 ? std::min(idx->bp_rows_pref, idx->store_dtype == VS_NONE ? kBpRowsMaxBin : kBpRowsMax)
+    idx->bp_rows = idx->bp_rows_pref > 0 ? std::min(idx->bp_rows_pref, bq_pref ? kBqRowsMax : idx->store_dtype == VS_NONE ? kBpRowsMaxBin : kBpRowsMax)
                    : idx->bp_rows_forced > 0 ? idx->bp_rows_forced : auto_rows();
     idx->bp_rows_forced = 0;
     const int64_t n_blocks = ceil_div64(idx->n_rows, idx->bp_rows);
@@ -209,7 +217,7 @@ int bp_build(vs_index* idx, hipStream_t s) {
     memcpy(&vmax_f, &hv[0], 4);
     const bool lossy_ok = hv[1] == 0u && vmax_f < 60000.f;       // fp16 copies of the values: non-negative, no overflow
     const bool quad = quad_pref && lossy_ok;                        // (non-negative values: a set sign bit marks a link)
-    const bool bq = bq_pref && idx->bp_rows == kBpRowsMaxBin;        // (the spare documents behind a plane absorb the pad cells: 2048-document blocks)
+    const bool bq = bq_pref;
     // Lossy filter copy of an fp32 index: values rounded to fp16 (4 instead of 6 bytes per posting); needs the filter-and-refine
     // search, non-negative values and no fp16 overflow
     idx->bp_quant = idx->store_dtype == VS_F32 && idx->bp_filter != 0 && idx->bp_quant_pref != 0 && lossy_ok;
@@ -336,7 +344,7 @@ int bp_build(vs_index* idx, hipStream_t s) {
     if (bq) {
         VS_HIP(hipFuncSetAttribute((const void*)bq_fill_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(bq_fill_kernel<0>, dim3(grid), dim3(kScanThreads), lds, s, idx->pk_ptr.as<uint32_t>(), idx->cols.as<uint4>(), idx->n_rows, V, idx->bp_rows,
-                           idx->bp_dir.as<uint32_t>(), idx->bp_base.as<unsigned long long>(), idx->bp_rec.as<uint16_t>());
+                           (uint32_t)bq_rmax(bq_slots(idx->bp_rows)), idx->bp_dir.as<uint32_t>(), idx->bp_base.as<unsigned long long>(), idx->bp_rec.as<uint16_t>());
         VS_HIP(hipGetLastError());
         VS_STAGE("bq_fill", s);
         // (the two spare records behind the array: pads too -- a lane never reads them, the allocation's tail is simply initialised)
@@ -484,12 +492,12 @@ int bp_filter_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64
     const int kp = k + std::max(28, k / 4);
     const bool duo = bp_duo_ok(idx, kp, nullptr);
     static const int qt_env = getenv("VS_BP_QT") ? atoi(getenv("VS_BP_QT")) : 0;                       // (developer: smaller tiles on the 8-slot walk)
-    const int qt = qt_env > 0 ? std::min(qt_env, kQT) : idx->store_dtype == VS_NONE ? kBpBinQT : (duo ? kDuoQT : kQT);
+    const int qt = idx->bp_bq ? bq_slots(idx->bp_rows) : qt_env > 0 ? std::min(qt_env, kQT) : idx->store_dtype == VS_NONE ? kBpBinQT : (duo ? kDuoQT : kQT);
     // (dense strips: their weight matrix takes 16 KB of the LDS the entries would use)
-    const int vals_cap = std::min(mq_vals_cap(idx), duo ? kDuoEntCap : (idx->bp_n_head > 0 ? kBpEntCap - 512 : kBpEntCap));
+    const int vals_cap = std::min(mq_vals_cap(idx), idx->bp_bq ? kBqEntCap : duo ? kDuoEntCap : (idx->bp_n_head > 0 ? kBpEntCap - 512 : kBpEntCap));
     const int64_t qcap = (int64_t)B * vals_cap;                               // bound of the batch's (query, column) entries that enter a tile
     const int64_t n_blocks = ceil_div64(idx->n_rows, idx->bp_rows);
-    if (idx->bp_rows > (idx->store_dtype == VS_NONE ? kBpRowsMaxBin : kBpRowsMax)) return fail(VS_EINVAL, "postings_rows beyond the walk's block capacity");
+    if (idx->bp_rows > (idx->bp_bq ? kBqRowsMax : idx->store_dtype == VS_NONE ? kBpRowsMaxBin : kBpRowsMax)) return fail(VS_EINVAL, "postings_rows beyond the walk's block capacity");
     // scratch: per-query metadata (counts, qptr, plan, tiles, flags, scale, slack, weight sums), column frequencies, the sparse batch
     const size_t off_counts = 0, off_qptr = off_counts + (size_t)B * 8, off_plan = off_qptr + (size_t)(B + 1) * 8, off_tiles = off_plan + 64,
                  off_fb = off_tiles + (size_t)B * 8, off_scale = off_fb + (size_t)B * 8, off_slack = off_scale + (size_t)B * 4,

@@ -243,7 +243,7 @@ struct vs_index {
     int bp_chunks = 0;   // option "postings_chunks": 0 = auto, else block runs per tile on the postings path
     int bp_walk_pref = -1;   // option "postings_walk": -1 auto (= 4 where it applies, else 0), 4 = quad chunks (bp_quad.h), 0 = one list per lane group (bp_walk.h), 1 = flat worklists (bp_flat.h), 2 = list walk on two accumulator sets (bp_duo.h), 3 = streamed flat walk (bp_stream.h)
     bool bp_quad = false;       // bp_rec holds quad chunks (bp_quad.h): 64-cell chunks of one-dword postings; dir / base count chunks
-    bool bp_bq = false;         // bp_rec holds bag-of-token chunks (bp_bq.h): 16-cell chunks of uint16 postings of a binary index; base counts chunks
+    bool bp_bq = false;         // bp_rec holds bag-of-token chunks (bp_bq.h): chunks of uint16 postings of a binary index; base counts chunks
     bool bp_no_quad = false;    // bp_build restarting itself without quad chunks (head columns found): consumed by the next bp_build
     int bp_arrange_pref = -1;   // option "postings_arrange": 1 = bank-aware order inside the lists (bp_arrange_kernel), -1 / 0 = as filled
     int bp_pace = -1;        // option "postings_pace": blocks a work item may run ahead of the slowest item of its chunk (-1 auto, 0 = free running)
