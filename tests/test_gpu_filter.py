@@ -263,6 +263,28 @@ def test_binary_index_on_the_postings_walk(law, nnz, rows, chunks):
         compare.compare_topk(o_ids, o_sc, got[0], got[1], rtol=RTOL)
 
 
+@pytest.mark.parametrize("n,nnz,rows", [(3_000, 20, 0), (70_000, 40, 0), (20_000, 86, 256), (20_000, 86, 1024), (40_000, 86, 4096), (40_000, 86, 4160),
+                                        (40_000, 86, 8192), (9_000, 300, 0)])
+def test_bag_of_token_chunks_block_shapes(n, nnz, rows):
+    """The bag-of-token chunks (bp_bq.h) over their block shapes: two query slots (blocks above 4096 documents) and four, blocks from
+    256 to 8192 documents (8192 at 86 tokens: 24 postings a list, 1 list in 18 goes on in a linked overflow chunk), a partial last
+    block, batches of 1 .. 33 queries (tiles with fewer queries than slots), k from 1 to 500 -- and the candidate buffer's overflow
+    path: with k = 500 a work item's first block pushes thousands of candidates per slot into 4096 places.  Bit-equal to the CSR scan,
+    dyadic weights bit-equal to the oracle."""
+    ip, ix, _ = oracle.synth_csr(11, 0, n, V, nnz, synth.KIND_BOT)
+    idx = DeviceIndex.from_csr(ip, ix, None, V)
+    idx.set_option("postings_rows", rows)
+    for B, k in ((1, 1), (3, 500), (7, 100), (33, 10)):
+        q = oracle.synth_queries(12 + B, B, val_law=synth.VAL_DYADIC)
+        ref = _search(idx, q, k, blocked_postings=0)
+        got = _search(idx, q, k, blocked_postings=1)
+        assert got[2].last_path == 3 and got[2].postings_walk == 6, (B, k)
+        assert (got[0] == ref[0]).all() and (got[1] == ref[1]).all(), (B, k)
+        if B == 3:
+            o_ids, o_sc = oracle.csr_search(ip, ix, None, V, q, k)
+            assert (got[0] == o_ids).all() and (got[1] == o_sc).all()
+
+
 def test_prepare_builds_the_postings_copy_ahead_of_the_first_search():
     """vs_index_prepare (the facade calls it from move_to_device / load_index): the copy exists before any search, and
     vs_index_info_t.postings_state says why an index has none."""
