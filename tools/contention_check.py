@@ -1,0 +1,54 @@
+"""N processes sharing ONE GPU, each searching its own synthetic shard over and over: every filter + refine result against the CSR scan of
+the same index.  python tools/contention_check.py [processes] [searches] [plain|bot|zipf]
+
+Why: with four or more processes the GPU's queues are oversubscribed and a kernel's workgroups start far apart in time (and waves are
+context-switched); round 5 had a version of the quad walk that passed every single-process test and lost whole blocks of candidates in
+10 - 25 % of the searches here (docs/EXPERIMENTS.md, round 5, "a base held in a VGPR across the walk").  tests/test_gpu_search.py runs it."""
+import os, subprocess, sys
+import numpy as np
+repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, repo)
+
+KINDS = {"plain": (20_000, 768, 0, "VS_F32"), "bot": (60_000, 86, 1, "VS_NONE"), "zipf": (40_000, 768, 2, "VS_F32")}
+
+
+def child(rank, reps, kind):
+    import bench, torch
+    from collections import Counter
+    from vsearch_amd import _native as nat
+    from vsearch_amd.device_index import DeviceIndex
+    n, nnz, k, store = KINDS[kind]
+    idx = DeviceIndex.synthetic(bench.INDEX_SEED, rank * n, n, 29523, nnz, k, 0, getattr(nat, store))
+    qb = bench.make_query_batches(2, 32, torch.device("cuda", 0), kind=k)
+    idx.set_option("blocked_postings", 0)
+    ref = []
+    for q in qb:
+        ids, sc = idx.search(q, 100)
+        ref.append((ids.cpu().numpy().copy(), sc.cpu().numpy().copy()))
+    idx.set_option("blocked_postings", 1)
+    for kv in filter(None, os.environ.get("VS_CHECK_OPTS", "").split(",")):
+        name, val = kv.split("=")
+        idx.set_option(name, int(val))
+    nbad = 0
+    for i in range(reps):
+        ids, sc = idx.search(qb[i & 1], 100)
+        got, want = (ids.cpu().numpy(), sc.cpu().numpy()), ref[i & 1]
+        bad = np.argwhere((got[0] != want[0]) | (got[1] != want[1]))
+        if len(bad):
+            nbad += 1
+            if nbad <= 3:
+                miss = sorted(set(want[0].ravel().tolist()) - set(got[0].ravel().tolist()))
+                print(f"rank {rank} search {i}: {len(bad)} mismatches; missing documents by 2048-row block: {sorted(Counter(m // 2048 for m in miss).items())}", flush=True)
+    inf = idx.info()
+    print(f"rank {rank} {kind}: {nbad} bad searches of {reps} (path {inf.last_path}, walk {inf.postings_walk})", flush=True)
+    return 1 if nbad else 0
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "child":
+        raise SystemExit(child(int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]))
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+    reps = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+    kind = sys.argv[3] if len(sys.argv) > 3 else "plain"
+    ps = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "child", str(r), str(reps), kind]) for r in range(n)]
+    raise SystemExit(max(p.wait() for p in ps))

@@ -200,6 +200,15 @@ __global__ __launch_bounds__(kScanThreads) void bp_bq_topk(BpArgs a) {
             __syncthreads();
         }
         for (int i = tid; i < (int)(QT * PLANE / 4); i += kScanThreads) acc[i] = 0;
+        // the sums are never zeroed again: a thread finishes the SAME 16 cells in every block and keeps what they held after the last
+        // one -- a block's sum is the difference (mod 2^32: exact), and the epilogue's LDS traffic is reads only
+        uint32_t prev[QT][NH][4];
+#pragma unroll
+        for (int q = 0; q < QT; ++q)
+#pragma unroll
+            for (int h = 0; h < NH; ++h)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) prev[q][h][j] = 0u;
         if (tid < 8) { tau[tid] = 0ull; ccnt[tid] = 0u; upper_sh[tid] = (a.upper && tid < nq) ? a.upper[q0 + tid] : ~0ull; }
         __syncthreads();
         const uint32_t trips = (uint32_t)(n_static / kBqTableStep);
@@ -209,10 +218,6 @@ __global__ __launch_bounds__(kScanThreads) void bp_bq_topk(BpArgs a) {
         for (int64_t b = b0; b < b1 || b == b0; ++b) {
             const bool have = b < b1;
             const int rows_b = have ? (int)min((int64_t)a.rows, a.n_rows - b * a.rows) : 0;
-            // (the other workgroups' thresholds: asked for before the walk, used behind it -- read after the walk, the load's latency is
-            //  what every wave waits for at the block's barrier)
-            const unsigned long long g_tau = (a.gtau && tid < nq) ? __builtin_nontemporal_load(a.gtau + q0 + tid) : 0ull;
-            const unsigned long long base_next = b + 1 < b1 ? a.base[b + 1] : 0ull;       // (likewise: the next block's first chunk)
             if (have && trips > 0) {
                 const char* brec = a.rec + (size_t)base_cur * kBqChunkBytes;
                 // the overflow chunks a walk found: the wave's list `cur` holds n of them; their own links go to the other list
@@ -252,8 +257,10 @@ __global__ __launch_bounds__(kScanThreads) void bp_bq_topk(BpArgs a) {
                     if (!pace_wait(pc + rel - a.pace_window, need)) pace_off = true;
                 }
             }
-            if (b + 1 < b1) base_cur = base_next;
-            if (a.gtau && tid < nq && g_tau > tau[tid]) tau[tid] = g_tau;
+            // (loaded HERE, behind the walk: the next base held in a VGPR across the walk -- loaded ahead of it to hide the latency -- came
+            //  back wrong in some waves when four processes shared the GPU: tests/test_gpu_search.py, docs/EXPERIMENTS.md round 5)
+            if (b + 1 < b1) base_cur = a.base[b + 1];
+            if (a.gtau && tid < nq) { const unsigned long long g = a.gtau[q0 + tid]; if (g > tau[tid]) tau[tid] = g; }
             lds_barrier();                                               // the block's sums are complete
             lap(2);
             {
@@ -273,14 +280,13 @@ __global__ __launch_bounds__(kScanThreads) void bp_bq_topk(BpArgs a) {
                     const int32_t thr = q < nq ? (int32_t)(thi[q] ^ 0x80000000u) : 0x7FFFFFFF;
 #pragma unroll
                     for (int h = 0; h < NH; ++h) {
-                        uint4* p4 = reinterpret_cast<uint4*>(acc + q * (RMAX + kBqSpare) + h * 4096 + 4 * tid);
-                        const uint4 v = *p4;
-                        *p4 = make_uint4(0u, 0u, 0u, 0u);
-                        raw[q][h][0] = (int32_t)v.x; raw[q][h][1] = (int32_t)v.y; raw[q][h][2] = (int32_t)v.z; raw[q][h][3] = (int32_t)v.w;
+                        const uint4 v = *reinterpret_cast<const uint4*>(acc + q * (RMAX + kBqSpare) + h * 4096 + 4 * tid);
+                        raw[q][h][0] = (int32_t)(v.x - prev[q][h][0]); raw[q][h][1] = (int32_t)(v.y - prev[q][h][1]);
+                        raw[q][h][2] = (int32_t)(v.z - prev[q][h][2]); raw[q][h][3] = (int32_t)(v.w - prev[q][h][3]);
+                        prev[q][h][0] = v.x; prev[q][h][1] = v.y; prev[q][h][2] = v.z; prev[q][h][3] = v.w;
                         hit = hit || max(max(raw[q][h][0], raw[q][h][1]), max(raw[q][h][2], raw[q][h][3])) >= thr;
                     }
                 }
-                uint32_t sums[QT][NH][4];
                 uint32_t pend = 0u;                                      // bit (q * NH + h) * 4 + j: a candidate not yet in the buffer
                 if (__builtin_amdgcn_ballot_w64(hit) != 0ull) {
 #pragma unroll
@@ -288,17 +294,8 @@ __global__ __launch_bounds__(kScanThreads) void bp_bq_topk(BpArgs a) {
 #pragma unroll
                         for (int h = 0; h < NH; ++h)
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                sums[q][h][j] = (uint32_t)raw[q][h][j] ^ 0x80000000u;
-                                if (q < nq && h * 4096 + 4 * tid + j < rows_b && sums[q][h][j] >= thi[q]) pend |= 1u << ((q * NH + h) * 4 + j);
-                            }
-                } else {
-#pragma unroll
-                    for (int q = 0; q < QT; ++q)
-#pragma unroll
-                        for (int h = 0; h < NH; ++h)
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) sums[q][h][j] = 0u;
+                            for (int j = 0; j < 4; ++j)
+                                if (q < nq && h * 4096 + 4 * tid + j < rows_b && ((uint32_t)raw[q][h][j] ^ 0x80000000u) >= thi[q]) pend |= 1u << ((q * NH + h) * 4 + j);
                 }
                 const bool last = b + 1 >= b1;
                 for (;;) {
@@ -312,7 +309,7 @@ __global__ __launch_bounds__(kScanThreads) void bp_bq_topk(BpArgs a) {
                                     const uint32_t bit = 1u << ((q * NH + h) * 4 + j);
                                     if (pend & bit) {
                                         const int64_t row = (int64_t)b * a.rows + h * 4096 + 4 * tid + j;
-                                        const uint64_t key = ((uint64_t)sums[q][h][j] << 32) | (uint32_t)(~(uint32_t)row);
+                                        const uint64_t key = ((uint64_t)((uint32_t)raw[q][h][j] ^ 0x80000000u) << 32) | (uint32_t)(~(uint32_t)row);
                                         bool keep = false;
                                         if (key > tau[q] && key < upper_sh[q]) {
                                             const uint32_t pos = atomicAdd(&ccnt[q], 1u);

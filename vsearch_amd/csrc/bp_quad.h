@@ -330,10 +330,6 @@ __global__ __launch_bounds__(kScanThreads) void bp_quad_topk(BpArgs a) {
         for (int64_t b = b0; b < b1 || b == b0; ++b) {
             const bool have = b < b1;
             const int rows_b = have ? (int)min((int64_t)a.rows, a.n_rows - b * a.rows) : 0;
-            // (the other workgroups' thresholds and the next block's first chunk: asked for before the walk, used behind it -- loaded
-            //  behind the walk, their latency is what every wave waits for at the block's barrier)
-            const unsigned long long g_tau = (a.gtau && tid < nq) ? a.gtau[q0 + tid] : 0ull;
-            const unsigned long long base_next = b + 1 < b1 ? a.base[b + 1] : 0ull;
             if (have && trips > 0) {
                 const char* brec = a.rec + (size_t)base_cur * kQuadChunkBytes;
                 // the overflow chunks a walk found: the wave's list `cur` holds n of them; their own links go to the other list
@@ -378,8 +374,8 @@ __global__ __launch_bounds__(kScanThreads) void bp_quad_topk(BpArgs a) {
                     if (!pace_wait(pc + rel - a.pace_window, need)) pace_off = true;
                 }
             }
-            if (b + 1 < b1) base_cur = base_next;
-            if (a.gtau && tid < nq && g_tau > tau[tid]) tau[tid] = g_tau;
+            if (b + 1 < b1) base_cur = a.base[b + 1];
+            if (a.gtau && tid < nq) { const unsigned long long g = a.gtau[q0 + tid]; if (g > tau[tid]) tau[tid] = g; }
             lds_barrier();                                               // the block's sums are complete
             lap(2);
             // epilogue: 1024 documents at a time, one per thread: its QT sums -> order keys -> candidates; prune when a buffer could overflow
