@@ -200,7 +200,9 @@ VS_API int  vs_index_prepare(vs_index* index, void* stream);
  *   "blocked_postings"  -1 = auto (long-row valued indexes, when HBM has room for the second copy), 0 = off, 1 = on:
  *                       sparse queries are scored from a row-blocked, column-grouped copy of the index that is built on
  *                       first use -- a query tile reads only the posting lists of its own columns
-  *   "postings_rows"     0 = auto (a column's list in a block averages ~50 postings, at most 2048 documents), else documents per block of the copy
+ *   "postings_rows"     0 = auto (a column's list in a block averages ~50 postings, at most 2048 documents; the bag-of-token chunks of a
+ *                       binary index: ~18 postings, at most 8192), else documents per block of the copy (a multiple of 64 in 256..8192,
+ *                       clipped to what the index's walk holds)
  *   "postings_chunks"   0 = auto, else the number of block runs the postings scan cuts the index into (work items = tiles x runs)
  *   "postings_filter"   1 (default) = the postings walk accumulates int32 fixed-point sums (3.4x the LDS atomic rate of fp64 on
  *                       MI355X) and returns k + max(28, k/4) candidates per query, which are re-scored with the exact numerics
@@ -208,10 +210,16 @@ VS_API int  vs_index_prepare(vs_index* index, void* stream);
  *                       (exact_scan_topk_kernel).  Results are identical to 0 = fp64 walk only
  *   "postings_quant"    1 (default) = an fp32 index keeps fp16-rounded values in the postings copy (the filter only ranks
  *                       candidates; the refine step re-scores them from the fp32 CSR), 0 = fp32 values there too
- *   "postings_walk"     which kernel walks the postings for the filter: -1 / 0 = a list per 8-lane group (bp_walk.h, the default: the fastest
- *                       measured), 1 = flat per-wave worklists (bp_flat.h), 2 = the list walk on two accumulator sets without block
- *                       barrier (bp_duo.h), 3 = flat worklists with software-pipelined record loads (bp_stream.h).  All four return
- *                       identical results; 1 - 3 are kept as measured experiments.  Valued indexes without head strips only.
+ *   "postings_walk"     which copy / kernel serves the filter: -1 = auto -- a valued index gets QUAD CHUNKS (bp_quad.h: 256-byte chunks of 64
+ *                       postings per (block, column), walked by a generated asm loop) while they stay within 3 x the CSR bytes, else the
+ *                       list walk over records; a binary index gets BAG-OF-TOKEN CHUNKS (bp_bq.h: 64-byte chunks of 32 document ids);
+ *                       0 = the list walk over records (bp_walk.h: a list per 8-lane group), 4 = quad chunks whatever their size,
+ *                       5 = the record walk of a binary index (bp_bin.h), 6 = bag-of-token chunks; 1 - 3 = the experimental walks of round 3
+ *                       (flat worklists, two accumulator sets, streamed records: only in a `make EXPERIMENTAL=1` build).  A copy that does
+ *                       not fit HBM falls back to the records, then to the CSR scan.  All return identical results; a change rebuilds the copy.
+ *   "postings_head_gemm" -1 / 1 = the head columns' part of the filter sums comes from the head pre-pass (bp_head.h: one MFMA product per
+ *                       pass of query tiles, columns in >= 1/8 of the documents, up to 1024), 0 = multiplied inside the walk (round 4)
+ *   "postings_head_tiles" 0 = auto, else query tiles per pass of the head pre-pass (its scratch: 64 KB per tile and block)
  *   "postings_pace"     lock-step window of the walk's work items in blocks (-1 / 0 = free running, the default)
  *   "postings_arrange"  1 = bank-aware order inside each posting list at build time (off by default: no measured gain)
  *   "postings_lanes"    0 = auto; valued index: lanes per posting list (4 | 8, auto 8); binary index: records in flight per lane (4 | 8, auto 8)
