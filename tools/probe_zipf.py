@@ -20,4 +20,4 @@ for _ in range(reps):
 torch.cuda.synchronize(); dt = (time.time() - t) / reps
 w, n = Profile.read("csr_scan_topk"); g, _ = Profile.read("head_gemm")
 inf = idx.info()
-print(f"zipf N={N} B={B}: {dt*1e3:.2f} ms/search = {B/dt:.0f} q/s | walk {w/reps:.2f} ms ({n/reps:.0f} launches) head gemm {g/reps:.2f} ms | heads {inf.head_columns} fallbacks {inf.last_fallbacks} path {inf.last_path}")
+print(f"zipf N={N} B={B}: {dt*1e3:.2f} ms/search = {B/dt:.0f} q/s | walk {w/reps:.2f} ms ({n/reps:.0f} launches) head gemm {g/reps:.2f} ms | heads {inf.head_columns} walk {inf.postings_walk} copy {inf.aux_bytes/1e9:.1f} GB fallbacks {inf.last_fallbacks} path {inf.last_path}")
