@@ -61,6 +61,28 @@ __global__ __launch_bounds__(1024) void requests(const char* buf, uint32_t line_
     if (acc == 0x12345678u) sink[0] = acc;
 }
 
+// the SCALAR path (scalar cache -> L2): a wave issues K s_load_dwordx16 (64 bytes each) of random 64-byte lines and waits for all of them
+// (scalar loads return out of order: lgkmcnt(0)); W waves per CU.  Is it a second road into L2 beside the L1's?
+template <int K>
+__global__ __launch_bounds__(1024) void scalar_requests(const char* buf, uint32_t line_mask, int iters, uint32_t* sink) {
+    const uint32_t wave = (blockIdx.x * 1024u + threadIdx.x) >> 6;
+    uint32_t x = (uint32_t)__builtin_amdgcn_readfirstlane(wave * 2654435761u + 999u);
+    uint32_t acc = 0;
+    for (int it = 0; it < iters; ++it) {
+        uint32_t o[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) { x = x * 1664525u + 1013904223u; o[k] = ((x >> 8) & line_mask) << 6; }
+        typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+        u32x16 r[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) asm volatile("s_load_dwordx16 %0, %1, %2" : "=s"(r[k]) : "s"(buf), "s"(o[k]) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc ^= r[k].x;
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+
 // round trip of ONE dependent load chain per wave (latency under no load, and -- launched beside nothing else -- the base line)
 __global__ void chase(const uint32_t* buf, int iters, uint32_t* sink, unsigned long long* clocks) {
     uint32_t p = threadIdx.x * 32u;
@@ -116,6 +138,21 @@ int main() {
         for (int waves : {4, 16}) {
             if (run<2, 2>(d_buf, footprint, waves, cus, clk_hz, d_sink, "16 lanes x dword")) return 1;
             if (run<8, 2>(d_buf, footprint, waves, cus, clk_hz, d_sink, "16 lanes x dword")) return 1;
+        }
+        for (int waves : {1, 4}) {
+            const uint32_t mask = (uint32_t)((footprint >> 6) - 1) & 0xFFFFFFu;
+            const int iters = 2000;
+            hipEvent_t e0, e1;
+            CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+            hipLaunchKernelGGL((scalar_requests<4>), dim3(cus), dim3(waves * 64), 0, 0, d_buf, mask, 20, d_sink);
+            CK(hipEventRecord(e0, 0));
+            hipLaunchKernelGGL((scalar_requests<4>), dim3(cus), dim3(waves * 64), 0, 0, d_buf, mask, iters, d_sink);
+            CK(hipEventRecord(e1, 0));
+            CK(hipEventSynchronize(e1));
+            float ms = 0.f;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            const double n = (double)cus * waves * iters * 4.0, clocks = ms * 1e-3 * clk_hz;
+            printf("scalar s_load_dwordx16  K  4 waves %2d: %8.3f ms  %6.3f 64-byte lines/clk/CU  (%.2f TB/s chip-wide)\n", waves, ms, n / cus / clocks, n * 64.0 / (ms * 1e-3) / 1e12);
         }
         if (run<1, 0>(d_buf, footprint, 16, cus, clk_hz, d_sink, "64 lanes x dword")) return 1;
         if (run<4, 0>(d_buf, footprint, 16, cus, clk_hz, d_sink, "64 lanes x dword")) return 1;
