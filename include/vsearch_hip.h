@@ -95,7 +95,8 @@ typedef struct vs_index_info_t {
     int32_t postings_walk;   /* which walk serves the filter on the copy that was built: 0 = list walk over 8-posting records,
                               * 4 = quad walk over 64-cell chunks (the default of a valued index), 5 = bag-of-token walk;
                               * -1 = no copy                                                                                     */
-    int32_t reserved0;
+    int32_t last_packed_tiles; /* path 3 on bag-of-token chunks: query tiles of the most recent search() that took the packed walk (four slots
+                              * on 16-bit sums, option "postings_packed"); the other tiles ran two int32 slots each                     */
 } vs_index_info_t;
 
 /* ---- library ------------------------------------------------------------------------------- */
@@ -220,6 +221,9 @@ VS_API int  vs_index_prepare(vs_index* index, void* stream);
  *   "postings_head_gemm" -1 / 1 = the head columns' part of the filter sums comes from the head pre-pass (bp_head.h: one MFMA product per
  *                       pass of query tiles, columns in >= 1/8 of the documents, up to 1024), 0 = multiplied inside the walk (round 4)
  *   "postings_head_tiles" 0 = auto, else query tiles per pass of the head pre-pass (its scratch: 64 KB per tile and block)
+ *   "postings_packed"   -1 / 1 = the bag-of-token chunk walk puts FOUR query slots on the two sum planes of a tile (16-bit sums, two to a dword)
+ *                       for the queries whose weights allow it (integer at a small power-of-two scale, longest row x largest weight < 65 536:
+ *                       checked per query on the device); 0 = two int32 slots a tile.  Identical results
  *   "postings_pace"     lock-step window of the walk's work items in blocks (-1 / 0 = free running, the default)
  *   "postings_arrange"  1 = bank-aware order inside each posting list at build time (off by default: no measured gain)
  *   "postings_lanes"    0 = auto; valued index: lanes per posting list (4 | 8, auto 8); binary index: records in flight per lane (4 | 8, auto 8)

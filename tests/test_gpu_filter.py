@@ -285,6 +285,61 @@ def test_bag_of_token_chunks_block_shapes(n, nnz, rows):
             assert (got[0] == o_ids).all() and (got[1] == o_sc).all()
 
 
+def test_bag_of_token_packed_sums():
+    """Four query slots a tile on packed 16-bit sums (bp_bq.h, option "postings_packed"): queries whose weights are integers at a small
+    power-of-two scale with longest row x largest weight < 65 536 take the packed walk; the others -- weights that are too large, weights
+    that are no dyadic numbers, a negative weight -- the two-slot int32 walk; a tile with one such query is cut in two.  Whatever the
+    mix, ids and scores equal the CSR scan's bit for bit, dyadic batches equal the oracle's."""
+    n = 40_000
+    ip, ix, _ = oracle.synth_csr(5, 0, n, V, 86, synth.KIND_BOT)
+    idx = DeviceIndex.from_csr(ip, ix, None, V)
+    for B, k in ((1, 10), (3, 100), (4, 100), (5, 500), (33, 100)):
+        q = oracle.synth_queries(40 + B, B, val_law=synth.VAL_DYADIC)
+        ref = _search(idx, q, k, blocked_postings=0)
+        got = _search(idx, q, k, blocked_postings=1, postings_packed=1)
+        assert got[2].last_path == 3 and got[2].postings_walk == 6 and got[2].last_packed_tiles == (B + 3) // 4, (B, k, got[2].last_packed_tiles)
+        assert (got[0] == ref[0]).all() and (got[1] == ref[1]).all(), (B, k)
+        off = _search(idx, q, k, blocked_postings=1, postings_packed=0)
+        assert off[2].last_packed_tiles == 0 and (off[0] == ref[0]).all() and (off[1] == ref[1]).all(), (B, k)
+        o_ids, o_sc = oracle.csr_search(ip, ix, None, V, q, k)
+        assert (got[0] == o_ids).all() and (got[1] == o_sc).all()
+    idx.set_option("postings_packed", -1)
+    # a common factor changes nothing (the scale is the smallest power of two that makes the weights integers: here 2^-4) ...
+    q = oracle.synth_queries(77, 9, val_law=synth.VAL_DYADIC)
+    big = (q * 1024.0).astype(np.float32)
+    ref = _search(idx, big, 100, blocked_postings=0)
+    got = _search(idx, big, 100, blocked_postings=1)
+    assert got[2].last_packed_tiles == 3 and (got[0] == ref[0]).all() and (got[1] == ref[1]).all()
+    # ... one weight 8192 x the others does (longest row x largest integer weight >> 65 536): every tile on the int32 walk
+    for b in range(9):
+        big[b, np.nonzero(big[b])[0][b]] *= 8192.0
+    ref = _search(idx, big, 100, blocked_postings=0)
+    got = _search(idx, big, 100, blocked_postings=1)
+    assert got[2].last_packed_tiles == 0 and (got[0] == ref[0]).all() and (got[1] == ref[1]).all()
+    # ... weights with 14 fractional bits (integers up to 49 315): int32 walk
+    grid = oracle.synth_queries(78, 9, val_law=synth.VAL_GRID)
+    ref = _search(idx, grid, 100, blocked_postings=0)
+    got = _search(idx, grid, 100, blocked_postings=1)
+    assert got[2].last_packed_tiles == 0 and (got[0] == ref[0]).all() and (got[1] == ref[1]).all()
+    # a mix: queries 2 and 7 of 11 do not qualify (too large / a negative weight) -> tiles {0..3} and {4..7} are cut in two, {8..10} is packed
+    mix = oracle.synth_queries(79, 11, val_law=synth.VAL_DYADIC)
+    mix[2, np.nonzero(mix[2])[0][5]] *= 8192.0
+    nzc = np.nonzero(mix[7])[0]
+    mix[7, nzc[0]] = -mix[7, nzc[0]]
+    ref = _search(idx, mix, 100, blocked_postings=0)
+    got = _search(idx, mix, 100, blocked_postings=1)
+    assert got[2].last_packed_tiles == 1, got[2].last_packed_tiles
+    assert (got[0] == ref[0]).all() and (got[1] == ref[1]).all()
+    # the bound is on what a document CAN reach: weights of 255 / 64 on rows of <= 176 tokens qualify, one weight of 512 no longer does
+    edge = oracle.synth_queries(80, 4, val_law=synth.VAL_DYADIC)
+    got = _search(idx, edge, 100, blocked_postings=1)
+    assert got[2].last_packed_tiles == 1
+    edge[1, np.nonzero(edge[1])[0][0]] = 512.0
+    ref = _search(idx, edge, 100, blocked_postings=0)
+    got = _search(idx, edge, 100, blocked_postings=1)
+    assert got[2].last_packed_tiles == 0 and (got[0] == ref[0]).all() and (got[1] == ref[1]).all()
+
+
 def test_prepare_builds_the_postings_copy_ahead_of_the_first_search():
     """vs_index_prepare (the facade calls it from move_to_device / load_index): the copy exists before any search, and
     vs_index_info_t.postings_state says why an index has none."""

@@ -16,7 +16,7 @@ idx = DeviceIndex.synthetic(0, 0, N, 29523, 86, 1, 0, nat.VS_NONE)
 q = torch.from_numpy(oracle.synth_queries(1, B, 29523, 776, 1)).cuda()
 first = None
 for rows, lanes, chunks in itertools.product(rows_l, lanes_l, chunks_l):
-    idx.set_option("postings_rows", rows); idx.set_option("postings_lanes", lanes); idx.set_option("postings_walk", int(os.environ.get("VS_PROBE_WALK", "-1"))); idx.set_option("postings_chunks", chunks)
+    idx.set_option("postings_rows", rows); idx.set_option("postings_lanes", lanes); idx.set_option("postings_walk", int(os.environ.get("VS_PROBE_WALK", "-1"))); idx.set_option("postings_chunks", chunks); idx.set_option("postings_packed", int(os.environ.get("VS_PROBE_PACKED", "-1")))
     idx.search(q, 100); torch.cuda.synchronize()
     Profile.enable(True); Profile.reset()
     t = time.perf_counter(); reps = 3

@@ -29,7 +29,7 @@ class IndexInfo(C.Structure):
                 ("bytes_per_pass", C.c_int64), ("lanes_per_row", C.c_int32), ("queries_per_pass", C.c_int32),
                 ("last_scan_bytes", C.c_int64), ("aux_bytes", C.c_int64), ("last_path", C.c_int32), ("last_fallbacks", C.c_int32),
                 ("last_walk_postings", C.c_int64), ("head_columns", C.c_int32), ("postings_state", C.c_int32),
-                ("postings_walk", C.c_int32), ("reserved0", C.c_int32)]
+                ("postings_walk", C.c_int32), ("last_packed_tiles", C.c_int32)]
 
 
 _vp, _i32, _i64, _int = C.c_void_p, C.c_int32, C.c_int64, C.c_int

@@ -175,6 +175,11 @@ extern "C" int vs_index_set_option(vs_index* idx, const char* name, int value) {
         idx->bp_pace = value;
         return VS_OK;
     }
+    if (n == "postings_packed") {
+        if (value < -1 || value > 1) return fail(VS_EINVAL, "postings_packed: -1 = auto (on), 1 = packed 16-bit sums of the bag-of-token chunk walk where the batch allows it, 0 = int32 sums");
+        idx->bp_packed_pref = value;
+        return VS_OK;
+    }
     if (n == "mq_variant") {
         if (value < -1 || value > 1) return fail(VS_EINVAL, "mq_variant: -1 = auto, 0 = plain, 1 = shared columns");
         idx->mq_variant = value;

@@ -28,6 +28,10 @@
 #include "bp_quad.h"
 #include "bp_bq_asm.h"
 
+#ifndef VS_BQ_ZERO
+#define VS_BQ_ZERO 1            // packed walk's epilogue: 1 = read AND zero a thread's 16 dwords of sums, 0 = never zero them, keep the last block's in registers (16 VGPRs live across the walk)
+#endif
+
 namespace vs {
 
 constexpr int kBqCells = 2 * kBqGroupLanes * kBqLaneDwords, kBqLinked = kBqCells - 1, kBqChunkBytes = 2 * kBqCells;
@@ -51,7 +55,9 @@ constexpr int bq_ent_cap() {
 }
 constexpr int kBqEntCap = bq_ent_cap();
 static_assert(kBqEntCap >= 4096, "a tile holds two queries of 2048 tokens");
-__host__ __device__ constexpr size_t bq_lds_bytes(int qt) { return bq_fixed_lds(qt) + (size_t)(kBqEntCap + kBqTableStep + kBqTableStep * kBqOverRead) * 8; }
+constexpr int kBqBaseWin = 64;                                        // block bases staged in LDS at a time (behind the descriptor table)
+__host__ __device__ constexpr size_t bq_base_lds(int qt) { return bq_fixed_lds(qt) + (size_t)(kBqEntCap + kBqTableStep + kBqTableStep * kBqOverRead) * 8; }
+__host__ __device__ constexpr size_t bq_lds_bytes(int qt) { return bq_base_lds(qt) + (size_t)kBqBaseWin * 8; }
 static_assert(bq_lds_bytes(2) <= (size_t)160 * 1024 && bq_lds_bytes(4) <= (size_t)160 * 1024, "the chunk walk's LDS");
 // a wave's two link lists live in its share of the candidate sort buffer (32 KB / 16 waves = 2 KB): 128 descriptors each, of which
 // kBqStepDesc * kBqOverRead are the null ones a walk over-reads
@@ -122,28 +128,77 @@ __global__ __launch_bounds__(kScanThreads) void bq_fill_kernel(const uint32_t* p
     }
 }
 
+// ---- packed sums: which tiles qualify ---------------------------------------------------------------------------------
+// longest row of the index in non-zeros (upper bound: its packets x 8) -- what a document can match of a query at most
+template <int UNUSED>
+__global__ __launch_bounds__(256) void bq_maxrow_kernel(const uint32_t* pk_ptr, int64_t n_rows, uint32_t* out) {
+    uint32_t m = 0u;
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n_rows; r += (int64_t)gridDim.x * 256) m = max(m, pk_ptr[r + 1] - pk_ptr[r]);
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m * 8u);
+}
+
+// The plan's tiles (up to four queries each) -> the tiles of the packed walk (every query's sums fit 16 bits: flag16, bp_qscale_kernel)
+// and two-slot tiles for the int32 walk (the others, cut in two).  One workgroup; order kept.
+template <int UNUSED>
+__global__ __launch_bounds__(kScanThreads) void bq_split_kernel(const int2* tiles, const int32_t* n_tiles_dev, const uint32_t* flag16, int2* tiles16, int2* tiles2, int32_t* n_out) {
+    __shared__ int scratch[32];
+    const int tid = threadIdx.x, nt = n_tiles_dev[0];
+    const int per = (nt + kScanThreads - 1) / kScanThreads;
+    const int t0 = min(nt, tid * per), t1 = min(nt, t0 + per);
+    auto packed = [&](int2 t) { bool ok = true; for (int i = 0; i < t.y; ++i) ok = ok && flag16[t.x + i] != 0u; return ok; };
+    int m16 = 0, m2 = 0;
+    for (int t = t0; t < t1; ++t) { const int2 tl = tiles[t]; if (packed(tl)) ++m16; else m2 += tl.y > 2 ? 2 : 1; }
+    int tot16 = 0, tot2 = 0;
+    int o16 = block_excl_scan(m16, scratch, tid, &tot16);
+    __syncthreads();
+    int o2 = block_excl_scan(m2, scratch, tid, &tot2);
+    for (int t = t0; t < t1; ++t) {
+        const int2 tl = tiles[t];
+        if (packed(tl)) tiles16[o16++] = tl;
+        else {
+            tiles2[o2++] = make_int2(tl.x, min(tl.y, 2));
+            if (tl.y > 2) tiles2[o2++] = make_int2(tl.x + 2, tl.y - 2);
+        }
+    }
+    if (tid == 0) { n_out[0] = tot16; n_out[1] = tot2; }
+}
+
 // ---- walk -----------------------------------------------------------------------------------------------------------
 // Work items, tiles, thresholds and candidates as bp_bin_topk.  BpArgs::rec = the chunks, base[b] = first chunk of block b.
-// Epilogue: thread t finishes documents 4 t .. 4 t + 3 (and 4096 + 4 t ..: two-slot tiles) of every slot: 16 sums in registers from
-// 4 ds_read_b128, zeroed with 4 ds_write_b128.  A block may hold more candidates than the candidate buffer has room for (a slot keeps
+// Epilogue: thread t finishes documents 4 t .. 4 t + 3 (and 4096 + 4 t ..: two-plane tiles) of every slot: 16 dwords in registers from
+// 4 ds_read_b128.  A block may hold more candidates than the candidate buffer has room for (a slot keeps
 // kFlCap keys per workgroup, a block has up to 8192 documents): a push that finds no room stays PENDING in its thread, the buffer is
 // sorted and cut to the best K' (which raises the threshold), and the pending sums are tested again -- a few turns in a work item's
 // first block, none later.
-template <int QT, int TM>          // QT = query slots (2: blocks of up to 8192 documents, 4: up to 4096); TM = 1: phase clocks (VS_BP_TIMING)
+//
+// PACKED SUMS (PK = 1, round 6): the walk of a (tile, block) is traffic and per-block work -- half of its chunk requests miss the L2 with
+// two query slots a tile (512 tiles each sweep their own chunks: 174 GB of HBM traffic a search), and 38 % of the wave-cycles are the
+// barriers and the epilogue, paid per (tile, block).  Both halve when a tile holds FOUR slots on the same two planes: slots 2 p and
+// 2 p + 1 share the dwords of plane p -- a descriptor's weight is pre-shifted by 16 (s & 1) bits, the add stays ONE ds_add_u32 (the
+// generated loop is unchanged) and the low half cannot carry into the high one while every document's sum stays below 2^16.  That is a
+// property of (index, query): a document matches at most min(longest row, query entries) of the query's columns, so
+// min(longest row, n) x the largest integer weight < 65 536 is sufficient -- bp_qscale_kernel checks it per query (and picks the
+// smallest power-of-two scale that makes the weights integers instead of the 2^30 one), bq_split_kernel sends the tiles whose queries
+// all qualify here and cuts the others into two-slot tiles for the int32 kernel.  The epilogue takes a block's sums as the difference
+// of the running dwords as before (mod 2^32 the carries of earlier blocks cancel) and splits the difference into its halves.
+template <int QT, int TM, int PK = 0>          // QT = query slots (2: blocks of up to 8192 documents, 4: up to 4096; PK: 4 on two planes of 8192); TM = 1: phase clocks (VS_BP_TIMING)
 __global__ __launch_bounds__(kScanThreads) void bp_bq_topk(BpArgs a) {
-    constexpr int RMAX = bq_rmax(QT), NH = RMAX / (4 * kScanThreads);
-    constexpr uint32_t PLANE = bq_plane(QT);
-    static_assert(QT * NH * 4 == 16 && (QT == 2 || QT == 4), "a thread finishes 16 sums");
+    constexpr int NP = PK ? QT / 2 : QT;                                                    // planes
+    constexpr int RMAX = bq_rmax(NP), NH = RMAX / (4 * kScanThreads);
+    constexpr uint32_t PLANE = bq_plane(NP);
+    static_assert(NP * NH * 4 == 16 && (NP == 2 || NP == 4) && (!PK || QT == 4), "a thread finishes 16 dwords of sums");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int32_t* acc = reinterpret_cast<int32_t*>(smem);                                        // [QT][RMAX + spare], LDS address 0 (no static LDS in this kernel)
-    uint64_t* sortbuf = reinterpret_cast<uint64_t*>(smem + (size_t)QT * PLANE);             // [kFlCap]; during a walk: the waves' link lists
+    int32_t* acc = reinterpret_cast<int32_t*>(smem);                                        // [NP][RMAX + spare], LDS address 0 (no static LDS in this kernel)
+    uint64_t* sortbuf = reinterpret_cast<uint64_t*>(smem + (size_t)NP * PLANE);             // [kFlCap]; during a walk: the waves' link lists
     unsigned long long* tau = reinterpret_cast<unsigned long long*>(sortbuf + kFlCap);      // [8]
     unsigned long long* upper_sh = tau + 8;                                                 // [8]
     int* scratch = reinterpret_cast<int*>(upper_sh + 8);                                    // [16]
     unsigned int* ccnt = reinterpret_cast<unsigned int*>(scratch + 16);                     // [16]
     uint2* desc = reinterpret_cast<uint2*>(ccnt + 16);                                      // [n_static + kBqTableStep * kBqOverRead]
-    const uint32_t desc_lds = (uint32_t)bq_fixed_lds(QT);
-    const uint32_t sort_lds = (uint32_t)QT * PLANE;
+    unsigned long long* bases = reinterpret_cast<unsigned long long*>(smem + bq_base_lds(NP));      // [kBqBaseWin] first chunks of the item's next blocks
+    const uint32_t desc_lds = (uint32_t)bq_fixed_lds(NP);
+    const uint32_t sort_lds = (uint32_t)NP * PLANE;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int K = a.k;
@@ -193,18 +248,20 @@ __global__ __launch_bounds__(kScanThreads) void bp_bq_topk(BpArgs a) {
                 if (i < n_ent) {
                     const uint64_t key = skey[i];
                     const uint32_t col = 0xFFFFu - ((uint32_t)(key >> 40) & 0xFFFFu), qs = (uint32_t)(key >> 32) & 0xFFu;
-                    dsc = make_uint2(col | ((qs * PLANE) << 16), (uint32_t)(int32_t)__uint_as_float((uint32_t)key));       // integer weight (bp_bin.h)
+                    const uint32_t wi = (uint32_t)(int32_t)__uint_as_float((uint32_t)key);                                   // integer weight (bp_bin.h)
+                    if constexpr (PK != 0) dsc = make_uint2(col | (((qs >> 1) * PLANE) << 16), (wi & 0xFFFFu) << (16u * (qs & 1u)));      // two slots share a plane's dwords
+                    else dsc = make_uint2(col | ((qs * PLANE) << 16), wi);
                 }
                 desc[i] = dsc;
             }
             __syncthreads();
         }
-        for (int i = tid; i < (int)(QT * PLANE / 4); i += kScanThreads) acc[i] = 0;
+        for (int i = tid; i < (int)(NP * PLANE / 4); i += kScanThreads) acc[i] = 0;
         // the sums are never zeroed again: a thread finishes the SAME 16 cells in every block and keeps what they held after the last
         // one -- a block's sum is the difference (mod 2^32: exact), and the epilogue's LDS traffic is reads only
-        uint32_t prev[QT][NH][4];
+        uint32_t prev[NP][NH][4];
 #pragma unroll
-        for (int q = 0; q < QT; ++q)
+        for (int q = 0; q < NP; ++q)
 #pragma unroll
             for (int h = 0; h < NH; ++h)
 #pragma unroll
@@ -213,11 +270,17 @@ __global__ __launch_bounds__(kScanThreads) void bp_bq_topk(BpArgs a) {
         __syncthreads();
         const uint32_t trips = (uint32_t)(n_static / kBqTableStep);
         bool pace_off = false;
-        unsigned long long base_cur = b0 < b1 ? a.base[b0] : 0ull;
+        // (a block's first chunk comes from a window of 64 staged in LDS: loaded per block behind the walk -- where it had to go after the
+        //  round-5 finding below -- its latency sat in front of every block's barrier)
         lap(0);
         for (int64_t b = b0; b < b1 || b == b0; ++b) {
             const bool have = b < b1;
             const int rows_b = have ? (int)min((int64_t)a.rows, a.n_rows - b * a.rows) : 0;
+            if (((b - b0) & (kBqBaseWin - 1)) == 0) {
+                if (tid < kBqBaseWin) bases[tid] = b + tid < b1 ? a.base[b + tid] : 0ull;
+                __syncthreads();
+            }
+            const unsigned long long base_cur = bases[(b - b0) & (kBqBaseWin - 1)];
             if (have && trips > 0) {
                 const char* brec = a.rec + (size_t)base_cur * kBqChunkBytes;
                 // the overflow chunks a walk found: the wave's list `cur` holds n of them; their own links go to the other list
@@ -257,9 +320,8 @@ __global__ __launch_bounds__(kScanThreads) void bp_bq_topk(BpArgs a) {
                     if (!pace_wait(pc + rel - a.pace_window, need)) pace_off = true;
                 }
             }
-            // (loaded HERE, behind the walk: the next base held in a VGPR across the walk -- loaded ahead of it to hide the latency -- came
-            //  back wrong in some waves when four processes shared the GPU: tests/test_gpu_search.py, docs/EXPERIMENTS.md round 5)
-            if (b + 1 < b1) base_cur = a.base[b + 1];
+            // (round 5: the next base loaded ahead of the walk and held in a VGPR across it came back wrong in some waves when four processes
+            //  shared the GPU: tests/test_gpu_search.py, docs/EXPERIMENTS.md -- hence the window in LDS)
             if (a.gtau && tid < nq) { const unsigned long long g = a.gtau[q0 + tid]; if (g > tau[tid]) tau[tid] = g; }
             lds_barrier();                                               // the block's sums are complete
             lap(2);
@@ -273,21 +335,68 @@ __global__ __launch_bounds__(kScanThreads) void bp_bq_topk(BpArgs a) {
                 // fast test first: the epilogue is bound by VALU issue (4 waves a SIMD), and behind a work item's first blocks hardly a
                 // sum passes its threshold -- the largest of a thread's 4 sums of a (slot, half) against it (signed: the raw sum against
                 // the biased threshold), one wave-uniform branch; only a wave with a hit works out which sums they are
-                int32_t raw[QT][NH][4];
+                // (packed sums: both halves of a dword against their slots' thresholds in ONE saturating v_pk_sub_u16 -- a half stays
+                //  non-zero exactly when its sum reaches the threshold)
+                uint32_t dif[NP][NH][4];                                 // a block's sums: int32 (PK = 0) or two 16-bit halves (PK = 1)
+                uint32_t pend = 0u;                                      // bit (q * NH + h) * 4 + j: a candidate not yet in the buffer
                 bool hit = false;
+                if constexpr (PK != 0) {
+                    uint32_t tm1[NP];
+                    bool fast_v = true;
 #pragma unroll
-                for (int q = 0; q < QT; ++q) {
-                    const int32_t thr = q < nq ? (int32_t)(thi[q] ^ 0x80000000u) : 0x7FFFFFFF;
+                    for (int p = 0; p < NP; ++p) {
+                        const int32_t tl = 2 * p < nq ? (int32_t)(thi[2 * p] ^ 0x80000000u) : 0x7FFFFFFF;
+                        const int32_t th = 2 * p + 1 < nq ? (int32_t)(thi[2 * p + 1] ^ 0x80000000u) : 0x7FFFFFFF;
+                        fast_v = fast_v && tl > 0 && th > 0;             // (a threshold of <= 0 lets every document pass: no short cut)
+                        tm1[p] = (uint32_t)min(max(tl - 1, 0), 65535) | ((uint32_t)min(max(th - 1, 0), 65535) << 16);
+                    }
+                    const bool fast = __builtin_amdgcn_readfirstlane((int)fast_v) != 0;       // (the thresholds are the workgroup's: say so to the compiler)
+                    // (fast: a dword's saturated difference against its two thresholds SAYS which halves pass -- the wave looks at a dword
+                    //  only when one of its lanes has a passing half (the compare's mask is the ballot: no vector instruction more than the
+                    //  OR it replaces), so a wave with one candidate in a block does one dword's worth of work, not 32 compares)
+                    uint32_t any = 0u;
 #pragma unroll
-                    for (int h = 0; h < NH; ++h) {
-                        const uint4 v = *reinterpret_cast<const uint4*>(acc + q * (RMAX + kBqSpare) + h * 4096 + 4 * tid);
-                        raw[q][h][0] = (int32_t)(v.x - prev[q][h][0]); raw[q][h][1] = (int32_t)(v.y - prev[q][h][1]);
-                        raw[q][h][2] = (int32_t)(v.z - prev[q][h][2]); raw[q][h][3] = (int32_t)(v.w - prev[q][h][3]);
-                        prev[q][h][0] = v.x; prev[q][h][1] = v.y; prev[q][h][2] = v.z; prev[q][h][3] = v.w;
-                        hit = hit || max(max(raw[q][h][0], raw[q][h][1]), max(raw[q][h][2], raw[q][h][3])) >= thr;
+                    for (int p = 0; p < NP; ++p)
+#pragma unroll
+                        for (int h = 0; h < NH; ++h) {
+                            uint4* pa = reinterpret_cast<uint4*>(acc + p * (RMAX + kBqSpare) + h * 4096 + 4 * tid);
+                            const uint4 v = *pa;
+                            if constexpr (VS_BQ_ZERO != 0) *pa = make_uint4(0u, 0u, 0u, 0u);
+                            const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                if constexpr (VS_BQ_ZERO != 0) dif[p][h][j] = vv[j];
+                                else { dif[p][h][j] = vv[j] - prev[p][h][j]; prev[p][h][j] = vv[j]; }
+                                uint32_t r;
+                                asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(r) : "v"(dif[p][h][j]), "v"(tm1[p]));
+                                if (fast) {
+                                    if (__builtin_amdgcn_ballot_w64(r != 0u) != 0ull) {
+                                        if (r & 0xFFFFu) pend |= 1u << (((2 * p) * NH + h) * 4 + j);
+                                        if (r >> 16) pend |= 1u << (((2 * p + 1) * NH + h) * 4 + j);
+                                    }
+                                } else any |= 1u;
+                            }
+                        }
+                    hit = any != 0u;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < QT; ++q) {
+                        const int32_t thr = q < nq ? (int32_t)(thi[q] ^ 0x80000000u) : 0x7FFFFFFF;
+#pragma unroll
+                        for (int h = 0; h < NH; ++h) {
+                            const uint4 v = *reinterpret_cast<const uint4*>(acc + q * (RMAX + kBqSpare) + h * 4096 + 4 * tid);
+                            dif[q][h][0] = v.x - prev[q][h][0]; dif[q][h][1] = v.y - prev[q][h][1];
+                            dif[q][h][2] = v.z - prev[q][h][2]; dif[q][h][3] = v.w - prev[q][h][3];
+                            prev[q][h][0] = v.x; prev[q][h][1] = v.y; prev[q][h][2] = v.z; prev[q][h][3] = v.w;
+                            hit = hit || max(max((int32_t)dif[q][h][0], (int32_t)dif[q][h][1]), max((int32_t)dif[q][h][2], (int32_t)dif[q][h][3])) >= thr;
+                        }
                     }
                 }
-                uint32_t pend = 0u;                                      // bit (q * NH + h) * 4 + j: a candidate not yet in the buffer
+                // the sum of (slot q, half h, document j of the thread's four)
+                auto sum_of = [&](int q, int h, int j) -> uint32_t {
+                    if constexpr (PK != 0) { const uint32_t d = dif[q >> 1][h][j]; return (q & 1) ? d >> 16 : d & 0xFFFFu; }
+                    else return dif[q][h][j];
+                };
                 if (__builtin_amdgcn_ballot_w64(hit) != 0ull) {
 #pragma unroll
                     for (int q = 0; q < QT; ++q)
@@ -295,8 +404,9 @@ __global__ __launch_bounds__(kScanThreads) void bp_bq_topk(BpArgs a) {
                         for (int h = 0; h < NH; ++h)
 #pragma unroll
                             for (int j = 0; j < 4; ++j)
-                                if (q < nq && h * 4096 + 4 * tid + j < rows_b && ((uint32_t)raw[q][h][j] ^ 0x80000000u) >= thi[q]) pend |= 1u << ((q * NH + h) * 4 + j);
+                                if (q < nq && h * 4096 + 4 * tid + j < rows_b && (sum_of(q, h, j) ^ 0x80000000u) >= thi[q]) pend |= 1u << ((q * NH + h) * 4 + j);
                 }
+                lap(3);                                                  // (phase clocks: "dense" = reading the sums and testing them)
                 const bool last = b + 1 >= b1;
                 for (;;) {
                     if (pend != 0u) {
@@ -304,12 +414,13 @@ __global__ __launch_bounds__(kScanThreads) void bp_bq_topk(BpArgs a) {
                         for (int q = 0; q < QT; ++q)
 #pragma unroll
                             for (int h = 0; h < NH; ++h)
+                                if (__builtin_amdgcn_ballot_w64((pend & (0xFu << ((q * NH + h) * 4))) != 0u) != 0ull)        // (wave-uniform: most groups of four hold nothing)
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) {
                                     const uint32_t bit = 1u << ((q * NH + h) * 4 + j);
                                     if (pend & bit) {
                                         const int64_t row = (int64_t)b * a.rows + h * 4096 + 4 * tid + j;
-                                        const uint64_t key = ((uint64_t)((uint32_t)raw[q][h][j] ^ 0x80000000u) << 32) | (uint32_t)(~(uint32_t)row);
+                                        const uint64_t key = ((uint64_t)(sum_of(q, h, j) ^ 0x80000000u) << 32) | (uint32_t)(~(uint32_t)row);
                                         bool keep = false;
                                         if (key > tau[q] && key < upper_sh[q]) {
                                             const uint32_t pos = atomicAdd(&ccnt[q], 1u);

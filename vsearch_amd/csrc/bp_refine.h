@@ -49,7 +49,8 @@ __global__ __launch_bounds__(256) void bp_vmax_kernel(const void* vals, int64_t 
 // goes straight to the exact pass.  One wave per query, fixed reduction order.
 template <int UNUSED>
 __global__ __launch_bounds__(256) void bp_qscale_kernel(const int64_t* qptr, const float* qvals, int32_t B, const uint32_t* vmax_bits, int binary, int quant,
-                                                        float* qscale, int32_t* qslack, float* qwsum, const int32_t* qcols, const uint16_t* hmap, int32_t head_slack) {
+                                                        float* qscale, int32_t* qslack, float* qwsum, const int32_t* qcols, const uint16_t* hmap, int32_t head_slack,
+                                                        int32_t pk_maxrow = 0, uint32_t* flag16 = nullptr) {
     const int lane = threadIdx.x & 63;
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= B) return;
@@ -73,6 +74,32 @@ __global__ __launch_bounds__(256) void bp_qscale_kernel(const int64_t* qptr, con
         e = 30 - be;
     }
     e = max(-60, min(60, e));
+    // Packed 16-bit sums of the bag-of-token chunk walk (bp_bq.h, flag16 != nullptr): the SMALLEST power-of-two scale that makes every weight
+    // an integer, when a document's sum then stays below 2^16 -- a document matches at most min(longest row, n) of the query's columns,
+    // each with at most the largest weight.  Weights >= 0 only (a negative one would borrow from the slot in the dword's upper half).
+    if (flag16) {
+        int need = -1000;                                            // the scale's exponent: - (exponent of the weights' lowest set bit)
+        float wmax = 0.f;
+        for (int64_t x = e0 + lane; x < e1; x += 64) {
+            const float w = qvals[x];
+            wmax = fmaxf(wmax, w);
+            if (w > 0.f && isfinite(w)) {
+                int we;
+                const float m = frexpf(w, &we);                      // w = m 2^we, m in [0.5, 1): 24 mantissa bits
+                const uint32_t mi = (uint32_t)ldexpf(m, 24);
+                need = max(need, 24 - we - (__ffs((int)mi) - 1));
+            } else if (w != 0.f) need = 1000;                        // NaN / inf: not here
+        }
+        for (int o = 32; o > 0; o >>= 1) { need = max(need, __shfl_xor(need, o, 64)); wmax = fmaxf(wmax, __shfl_xor(wmax, o, 64)); }
+        bool ok16 = binary != 0 && !neg && need >= -40 && need <= 40 && e1 > e0;
+        if (ok16) {
+            const double wi = (double)wmax * ldexp(1.0, need);       // the largest integer weight
+            const double terms = (double)min((int64_t)max(pk_maxrow, 1), e1 - e0);
+            ok16 = wi * terms < 65536.0;
+        }
+        if (ok16) e = need;
+        if (lane == 0) flag16[q] = ok16 ? 1u : 0u;
+    }
     const float S = ldexpf(1.f, e);
     bool exact = binary != 0;
     if (exact) {

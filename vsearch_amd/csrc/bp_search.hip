@@ -347,6 +347,18 @@ int bp_build(vs_index* idx, hipStream_t s) {
                            (uint32_t)bq_rmax(bq_slots(idx->bp_rows)), idx->bp_dir.as<uint32_t>(), idx->bp_base.as<unsigned long long>(), idx->bp_rec.as<uint16_t>());
         VS_HIP(hipGetLastError());
         VS_STAGE("bq_fill", s);
+        {   // the longest row: bounds a document's sum in the packed walk (bp_bq.h)
+            DevBuf mr;
+            VS_TRY(mr.alloc(4));
+            VS_HIP(hipMemsetAsync(mr.p, 0, 4, s));
+            hipLaunchKernelGGL(bq_maxrow_kernel<0>, dim3((unsigned)std::min<int64_t>(ceil_div64(idx->n_rows, 256), (int64_t)idx->cu_count * 8)), dim3(256), 0, s,
+                               idx->pk_ptr.as<uint32_t>(), idx->n_rows, mr.as<uint32_t>());
+            VS_HIP(hipGetLastError());
+            uint32_t h_mr = 0;
+            VS_HIP(hipMemcpyAsync(&h_mr, mr.p, 4, hipMemcpyDeviceToHost, s));
+            VS_HIP(hipStreamSynchronize(s));
+            idx->bp_bq_maxrow = (int)std::min<uint32_t>(h_mr, 1u << 30);
+        }
         // (the two spare records behind the array: pads too -- a lane never reads them, the allocation's tail is simply initialised)
         VS_HIP(hipMemsetAsync(idx->bp_rec.as<char>() + (size_t)n_rec * RS, 0, 2 * (size_t)RS, s));
         idx->bp_bq = true;
@@ -492,7 +504,10 @@ int bp_filter_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64
     const int kp = k + std::max(28, k / 4);
     const bool duo = bp_duo_ok(idx, kp, nullptr);
     static const int qt_env = getenv("VS_BP_QT") ? atoi(getenv("VS_BP_QT")) : 0;                       // (developer: smaller tiles on the 8-slot walk)
-    const int qt = idx->bp_bq ? bq_slots(idx->bp_rows) : qt_env > 0 ? std::min(qt_env, kQT) : idx->store_dtype == VS_NONE ? kBpBinQT : (duo ? kDuoQT : kQT);
+    // bag-of-token chunks in blocks of more than 4096 documents (two sum planes): tiles of FOUR queries -- the packed walk takes those whose
+    // queries all qualify for 16-bit sums, the others are cut into two-slot tiles for the int32 walk (bq_split_kernel, bp_bq.h)
+    const bool bq_pk = idx->bp_bq && bq_slots(idx->bp_rows) == 2 && idx->bp_packed_pref != 0 && idx->bp_bq_maxrow > 0;
+    const int qt = bq_pk ? 4 : idx->bp_bq ? bq_slots(idx->bp_rows) : qt_env > 0 ? std::min(qt_env, kQT) : idx->store_dtype == VS_NONE ? kBpBinQT : (duo ? kDuoQT : kQT);
     // (dense strips: their weight matrix takes 16 KB of the LDS the entries would use)
     const int vals_cap = std::min(mq_vals_cap(idx), idx->bp_bq ? kBqEntCap : duo ? kDuoEntCap : (idx->bp_n_head > 0 ? kBpEntCap - 512 : kBpEntCap));
     const int64_t qcap = (int64_t)B * vals_cap;                               // bound of the batch's (query, column) entries that enter a tile
@@ -502,7 +517,8 @@ int bp_filter_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64
     const size_t off_counts = 0, off_qptr = off_counts + (size_t)B * 8, off_plan = off_qptr + (size_t)(B + 1) * 8, off_tiles = off_plan + 64,
                  off_fb = off_tiles + (size_t)B * 8, off_scale = off_fb + (size_t)B * 8, off_slack = off_scale + (size_t)B * 4,
                  off_wsum = off_slack + (size_t)B * 4, off_flags = off_wsum + (size_t)B * 4, off_nfb = off_flags + (size_t)B * 4,
-                 off_gtau = (off_nfb + 64 + 15) & ~(size_t)15, off_freq = (off_gtau + (size_t)B * 8 + 15) & ~(size_t)15;
+                 off_t16 = off_nfb + 64, off_t2 = off_t16 + (size_t)B * 8, off_f16 = off_t2 + (size_t)B * 8, off_nsp = off_f16 + (size_t)B * 4,
+                 off_gtau = (off_nsp + 64 + 15) & ~(size_t)15, off_freq = (off_gtau + (size_t)B * 8 + 15) & ~(size_t)15;
     VS_TRY(idx->ws_mq_meta.reserve(off_freq + (size_t)(V + 4) * 4 + 8));
     char* meta = idx->ws_mq_meta.as<char>();
     unsigned long long* gtau = (unsigned long long*)(meta + off_gtau);
@@ -517,6 +533,10 @@ int bp_filter_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64
     uint32_t* flags = (uint32_t*)(meta + off_flags);
     int32_t* fb_n = (int32_t*)(meta + off_nfb);
     uint32_t* colfreq = (uint32_t*)(meta + off_freq);
+    int2* tiles16 = (int2*)(meta + off_t16);
+    int2* tiles2 = (int2*)(meta + off_t2);
+    uint32_t* flag16 = (uint32_t*)(meta + off_f16);
+    int32_t* n_split = (int32_t*)(meta + off_nsp);
     VS_TRY(idx->ws_mq_q.reserve(std::max<size_t>((size_t)qcap * 8, 16)));
     int32_t* qcols = idx->ws_mq_q.as<int32_t>();
     float* qvals = reinterpret_cast<float*>(qcols + qcap);
@@ -531,7 +551,10 @@ int bp_filter_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64
                            idx->bp_df.as<unsigned long long>() + V, V, dplan + 4);
     hipLaunchKernelGGL(bp_qscale_kernel<0>, dim3((unsigned)ceil_div(B, 4)), dim3(256), 0, s, qptr, qvals, B, idx->bp_vmax.as<uint32_t>(),
                        idx->store_dtype == VS_NONE ? 1 : 0, (idx->bp_quant || idx->bp_n_head > 0) ? 1 : 0, qscale, qslack, qwsum, (const int32_t*)qcols,
-                       idx->bp_n_head > 0 ? (const uint16_t*)idx->bp_hmap.as<uint16_t>() : (const uint16_t*)nullptr, bp_head_slack(idx));
+                       idx->bp_n_head > 0 ? (const uint16_t*)idx->bp_hmap.as<uint16_t>() : (const uint16_t*)nullptr, bp_head_slack(idx),
+                       bq_pk ? idx->bp_bq_maxrow : 0, bq_pk ? flag16 : (uint32_t*)nullptr);
+    if (bq_pk) hipLaunchKernelGGL(bq_split_kernel<0>, dim3(1), dim3(kScanThreads), 0, s, (const int2*)tiles, reinterpret_cast<const int32_t*>(dplan), (const uint32_t*)flag16,
+                                  tiles16, tiles2, n_split);
     VS_HIP(hipGetLastError());
     VS_STAGE("sparsify", s);
     // 2. the walk.  Work items = (tile, chunk); the tile count lives on the device, the chunks follow its lower bound ceil(B / qt)
@@ -598,6 +621,7 @@ int bp_filter_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64
     }
     idx->last_path = 3;
     idx->last_plan_dev = dplan;
+    idx->last_split_dev = bq_pk ? n_split : nullptr;
     idx->last_plan_rs = idx->bp_quad ? kQuadChunkBytes : idx->bp_bq ? kBqChunkBytes : bp_rec_bytes(bp_record_vm(idx));
     idx->last_plan_blocks = n_blocks;
     // lock-step window of the walk's work items (all walks; kernels ignore it when not every item is resident)
@@ -660,6 +684,21 @@ int bp_filter_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64
             VS_HIP(hipGetLastError());
         }
         ProfScope prof("csr_scan_topk", s);
+        if (bq_pk) {
+            // the packed walk on the tiles that qualify, the int32 walk on the rest (cut to two slots); either returns at once without tiles
+            BpArgs a16 = a, a2 = a;
+            a16.tiles = tiles16; a16.n_tiles_dev = n_split;
+            a2.tiles = tiles2; a2.n_tiles_dev = n_split + 1;
+            void (*k16)(BpArgs) = a.timing ? bp_bq_topk<4, 1, 1> : bp_bq_topk<4, 0, 1>;
+            void (*k2)(BpArgs) = a.timing ? bp_bq_topk<2, 1> : bp_bq_topk<2, 0>;
+            const size_t lds = bq_lds_bytes(2);
+            if (vals_cap > kBqEntCap) return fail(VS_EUNSUPPORTED, "bag-of-token chunks: tile entries beyond the table");
+            VS_HIP(hipFuncSetAttribute((const void*)k16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            VS_HIP(hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(k16, dim3(grid), dim3(kScanThreads), lds, s, a16);
+            hipLaunchKernelGGL(k2, dim3(grid), dim3(kScanThreads), lds, s, a2);
+            VS_HIP(hipGetLastError());
+        } else
         VS_TRY((launch_bp_walk<kQT, AM_FIX>(idx, a, grid, vals_cap, s)));
     }
     if (debug_on) {

@@ -230,6 +230,7 @@ struct vs_index {
     int64_t last_walk_postings = 0;      // postings (multiply-adds) the most recent search's walk visited
     const uint32_t* last_flags = nullptr; // device [last_flags_n]: queries of the most recent filter search that took the exact walk
     int last_flags_n = 0;
+    const int32_t* last_split_dev = nullptr;   // device [2]: tiles of the most recent filter search on the packed / the int32 bag-of-token walk (bp_bq.h)
     const int64_t* last_plan_dev = nullptr;   // device plan of the most recent filter search ([2] entries, [4] records, [5] postings walked)
     int last_plan_rs = 0;
     int64_t last_plan_blocks = 0;
@@ -243,6 +244,8 @@ struct vs_index {
     int bp_chunks = 0;   // option "postings_chunks": 0 = auto, else block runs per tile on the postings path
     int bp_walk_pref = -1;   // option "postings_walk": -1 auto (= 4 where it applies, else 0), 4 = quad chunks (bp_quad.h), 0 = one list per lane group (bp_walk.h), 1 = flat worklists (bp_flat.h), 2 = list walk on two accumulator sets (bp_duo.h), 3 = streamed flat walk (bp_stream.h)
     bool bp_quad = false;       // bp_rec holds quad chunks (bp_quad.h): 64-cell chunks of one-dword postings; dir / base count chunks
+    int bp_bq_maxrow = 0;       // bag-of-token chunks: non-zeros of the longest row (an upper bound: packets x 8) -- what a document can match of a query at most
+    int bp_packed_pref = -1;    // option "postings_packed": -1 / 1 = four query slots a tile on packed 16-bit sums where the batch allows it (bp_bq.h), 0 = two int32 slots
     bool bp_bq = false;         // bp_rec holds bag-of-token chunks (bp_bq.h): chunks of uint16 postings of a binary index; base counts chunks
     bool bp_no_quad = false;    // bp_build restarting itself without quad chunks (head columns found): consumed by the next bp_build
     int bp_arrange_pref = -1;   // option "postings_arrange": 1 = bank-aware order inside the lists (bp_arrange_kernel), -1 / 0 = as filled

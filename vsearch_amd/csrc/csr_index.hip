@@ -530,7 +530,7 @@ extern "C" int vs_index_info(const vs_index* idx, vs_index_info_t* o) {
     o->head_columns = idx->bp_ready ? idx->bp_n_head : 0;
     o->postings_state = idx->bp_ready ? 1 : idx->bp_state;
     o->postings_walk = !idx->bp_ready ? -1 : idx->bp_quad ? 4 : idx->bp_bq ? 6 : (idx->store_dtype == VS_NONE && idx->bp_walk_pref != 0) ? 5 : 0;
-    o->reserved0 = 0;
+    o->last_packed_tiles = 0;
     if (idx->last_path == 3 && idx->last_plan_dev) {               // the filter search keeps its plan on the device: read it now
         int64_t hp[6] = {0, 0, 0, 0, 0, 0};
         VS_HIP(hipSetDevice(idx->device));
@@ -540,6 +540,13 @@ extern "C" int vs_index_info(const vs_index* idx, vs_index_info_t* o) {
         // overflow chunks -- quad_count_kernel counts them all), no directory
         o->last_scan_bytes = (idx->bp_quad || idx->bp_bq) ? hp[4] * idx->last_plan_rs : hp[4] * idx->last_plan_rs + hp[2] * idx->last_plan_blocks * 4;
         o->last_walk_postings = hp[5];
+    }
+    if (idx->last_path == 3 && idx->last_split_dev) {
+        int32_t hs[2] = {0, 0};
+        VS_HIP(hipSetDevice(idx->device));
+        VS_HIP(hipDeviceSynchronize());
+        VS_HIP(hipMemcpy(hs, idx->last_split_dev, sizeof(hs), hipMemcpyDeviceToHost));
+        o->last_packed_tiles = hs[0];
     }
     if (idx->last_path == 3 && idx->last_flags && idx->last_flags_n > 0) {
         std::vector<uint32_t> h((size_t)idx->last_flags_n);
