@@ -711,6 +711,44 @@ print("OK")
     assert r.returncode == 0 and "OK" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
 
 
+def test_a_late_wave_does_not_split_the_cut_decision():
+    """Round 6 (docs/EXPERIMENTS.md, profiles/r06_prune_decision_race.txt): whether a candidate buffer is cut after an epilogue round is ONE
+    decision of the workgroup -- taken by the wave that arrives last at the round's end.  Until round 6 every thread read the counters behind
+    the barrier; a wave that read them late saw the next round's pushes and went into the cut's barriers alone (whole blocks of candidates
+    lost once other processes' waves on the CU stretched the window: round 5's "value in a VGPR came back wrong").  VS_BP_KNOB = 128 + 256 n
+    makes one wave of every workgroup sleep n x 512 cycles between the barrier and its read (n = 1, 2, 4, 16: inside and beyond the other
+    waves' next round), on the quad walk and on the list walk (exact records, and head columns behind the pre-pass): results must equal
+    the CSR scan's -- the round-5 code loses documents at every n, in a single process (profiles/r06_prune_decision_race.txt).  Small shards: every work item's first block, where all documents
+    are candidates and a counter stands exactly at the limit after round one.  A subprocess: the library reads the knob once."""
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = """
+import numpy as np, torch, sys
+sys.path.insert(0, %r)
+import oracle
+from vsearch_amd import _native as nat, synth
+from vsearch_amd.device_index import DeviceIndex
+for kind, walk, quant in ((0, -1, -1), (0, 0, 0), (2, -1, -1)):
+    idx = DeviceIndex.synthetic(7, 0, 20_000 if kind == 0 else 40_000, 29523, 768, kind, 0, nat.VS_F32)
+    for rep in range(3):
+        q = torch.from_numpy(oracle.synth_queries(11 + rep, 32, 29523, 776, 0, 0, kind)).cuda()
+        idx.set_option("blocked_postings", 0)
+        ids0, sc0 = idx.search(q, 100)
+        idx.set_option("blocked_postings", 1)
+        idx.set_option("postings_walk", walk)
+        idx.set_option("postings_quant", quant)
+        ids1, sc1 = idx.search(q, 100)
+        assert idx.info().last_path == 3, (kind, walk)
+        assert (ids0.cpu() == ids1.cpu()).all() and (sc0.cpu() == sc1.cpu()).all(), (kind, walk, rep)
+print("OK")
+""" % repo
+    for n in (1, 2, 4, 16):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, VS_BP_KNOB=str(128 + 256 * n)))
+        assert r.returncode == 0 and "OK" in r.stdout, (n, r.stdout[-500:], r.stderr[-1500:])
+
+
 def test_bot_index_row_sharded_two_shards_on_one_device_with_lock_step():
     """Two bag-of-token shards on ONE device, B >= 16, lock-step window on.  Shards on one device share one stream (api.hip
     `owns_stream`), so their walks run one after the other here; the bounded wait itself is exercised by

@@ -261,6 +261,7 @@ __global__ __launch_bounds__(kScanThreads) void bp_quad_topk(BpArgs a) {
     unsigned long long* upper_sh = tau + QT;                                                // [QT]
     int* scratch = reinterpret_cast<int*>(upper_sh + QT);                                   // [48]
     unsigned int* ccnt = reinterpret_cast<unsigned int*>(scratch + 48);                     // [QT]
+    unsigned int* chi = ccnt + QT;                                                          // [QT] the counters' high halves at the end of the previous block (epilogue)
     uint2* desc = reinterpret_cast<uint2*>(scratch + 64);                                   // [n_static + 64 * kQuadOverRead]
     const uint32_t desc_lds = (uint32_t)quad_fixed_lds();                                   // its LDS byte address
 
@@ -320,7 +321,7 @@ __global__ __launch_bounds__(kScanThreads) void bp_quad_topk(BpArgs a) {
             __syncthreads();
         }
         for (int i = tid; i < (int)(kQuadAccBytes / 4); i += kScanThreads) acc[i] = 0;
-        if (tid < QT) { tau[tid] = 0ull; ccnt[tid] = 0u; }
+        if (tid < QT) { tau[tid] = 0ull; ccnt[tid] = 0u; chi[tid] = 0u; }
         if (tid < QT) upper_sh[tid] = (a.upper && tid < nq) ? a.upper[q0 + tid] : ~0ull;
         __syncthreads();
         const uint32_t trips = (uint32_t)(n_static / 64);
@@ -381,6 +382,8 @@ __global__ __launch_bounds__(kScanThreads) void bp_quad_topk(BpArgs a) {
             // epilogue: 1024 documents at a time, one per thread: its QT sums -> order keys -> candidates; prune when a buffer could overflow
             for (int d0 = 0; d0 < rows_b || d0 == 0; d0 += kScanThreads) {
                 const int d = d0 + tid;
+                const bool more = d0 + kScanThreads < rows_b;             // another round of this block follows
+                const uint32_t inc = more ? 1u : 0x10000u;
                 // (LDS instructions are what the epilogue costs -- 16 waves x 2 rounds a block: the 8 threshold halves in four 16-byte reads,
                 //  a document's 8 sums read AND zeroed by four ds_wrxchg2_rtn_b32, the 8 counters below in two 16-byte reads: 10 instead of 32)
                 uint32_t thi[QT];
@@ -424,19 +427,44 @@ __global__ __launch_bounds__(kScanThreads) void bp_quad_topk(BpArgs a) {
                         if (q < nq && hi >= thi[q]) {
                             const uint64_t key = ((uint64_t)hi << 32) | (uint32_t)(~(uint32_t)row);
                             if (key > tau[q] && key < upper_sh[q]) {
-                                const uint32_t pos = atomicAdd(&ccnt[q], 1u);
-                                my_gcand[(size_t)q * kBpCap + pos] = key;
+                                const uint32_t old = atomicAdd(&ccnt[q], inc);                 // (low half: first rounds, high half: last rounds -- below)
+                                my_gcand[(size_t)q * kBpCap + (old & 0xFFFFu) + (old >> 16)] = key;
                             }
                         }
                     }
                 }
+                // Whether a buffer has to be cut is ONE decision of the workgroup (barriers sit behind it), read by every thread from the
+                // counters behind the round's barrier -- so what a thread reads there must not depend on WHEN it reads.  A block's first
+                // round counts its candidates in the LOW half of a slot's counter, its last round in the HIGH half (a candidate's place is
+                // low + high of the value the atomic returns).  Behind the first round's barrier the waves that are already in the second
+                // round change the high halves only: the count is low half + the high half as it stood at the end of the previous block
+                // (chi[], written there by one thread, two barriers ago).  Behind a block's last round nobody pushes before the next
+                // walk's barrier, which no wave passes before every wave has read: low + high as they are.
+                // (Until round 6 a counter was one number: a wave already in the second round pushed between two waves' reads, and with a
+                //  counter exactly at the limit -- 1024 after the first round of a work item's first block, where every document is a
+                //  candidate -- the late reader went into the cut's barriers alone: whole blocks of candidates lost once other
+                //  processes' waves on the CU stretched the window.  docs/EXPERIMENTS.md round 6, profiles/r06_prune_decision_race.txt.)
                 lds_barrier();                                          // (the counters and sums are LDS; candidates other threads stored are read only when a prune follows)
-                const bool last = b + 1 >= b1 && d0 + kScanThreads >= rows_b;
+                // (VS_BP_KNOB = 128 + 256 n, tests: one wave reads the counters n x 512 cycles late -- the others are pushing the next round's
+                //  candidates by then.  A SCALAR branch: s_sleep does not care about exec -- behind a vector condition every wave slept)
+                if ((a.knob & 128) && __builtin_amdgcn_readfirstlane(wv) == 5)
+                    for (int i = 0; i < (a.knob >> 8); ++i) __builtin_amdgcn_s_sleep(8);
+                const bool last = b + 1 >= b1 && !more;
                 uint32_t cnts[QT];
                 {
                     const uint4* c4 = reinterpret_cast<const uint4*>(ccnt);
                     const uint4 c0 = c4[0], c1 = c4[1];
-                    cnts[0] = c0.x; cnts[1] = c0.y; cnts[2] = c0.z; cnts[3] = c0.w; cnts[4] = c1.x; cnts[5] = c1.y; cnts[6] = c1.z; cnts[7] = c1.w;
+                    const uint32_t w[QT] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+                    if (more) {
+                        const uint4 h0 = c4[2], h1 = c4[3];              // chi[]
+                        const uint32_t h[QT] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+                        for (int q = 0; q < QT; ++q) cnts[q] = (w[q] & 0xFFFFu) + h[q];
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < QT; ++q) cnts[q] = (w[q] & 0xFFFFu) + (w[q] >> 16);
+                        if (tid < QT) chi[tid] = ccnt[tid] >> 16;         // (the next block's first round reads it two barriers from here)
+                    }
                 }
                 bool any = last;
 #pragma unroll
@@ -444,7 +472,7 @@ __global__ __launch_bounds__(kScanThreads) void bp_quad_topk(BpArgs a) {
                 if (any) __syncthreads();                               // the candidates stored above become visible to the workgroup
                 if (any)
                 for (int qs = 0; qs < nq; ++qs) {
-                    const uint32_t cnt = ccnt[qs];
+                    const uint32_t cw = ccnt[qs], cnt = (cw & 0xFFFFu) + (cw >> 16);       // (inside the cut nobody pushes: the word is what it is)
                     if (last || cnt > (uint32_t)(kBpCap - kScanThreads)) {
                         for (int i = tid; i < kBpCap; i += kScanThreads) sortbuf[i] = (uint32_t)i < cnt ? my_gcand[(size_t)qs * kBpCap + i] : 0ull;
                         wg_sort_desc<kScanThreads>(sortbuf, kBpCap, tid);
@@ -457,7 +485,8 @@ __global__ __launch_bounds__(kScanThreads) void bp_quad_topk(BpArgs a) {
                                 const unsigned long long kth = sortbuf[K - 1];
                                 if (kth > tau[qs]) tau[qs] = kth;
                                 if (a.gtau && kth != 0ull) atomicMax(a.gtau + q0 + qs, kth);
-                                ccnt[qs] = (uint32_t)K;
+                                ccnt[qs] = (uint32_t)K;                     // (low half K, high half 0)
+                                chi[qs] = 0u;
                             }
                         }
                         __syncthreads();

@@ -38,7 +38,6 @@ void bp_release(vs_index* idx) {
     idx->bp_hmap.release(); idx->bp_strip.release();
     idx->bp_n_head = 0;
     idx->bp_head_gemm = false;
-    idx->ws_head_w.release(); idx->ws_head_out.release();
     idx->bp_quad = false;
     idx->bp_bq = false;
     idx->bp_ready = false;
@@ -178,6 +177,9 @@ int bp_build(vs_index* idx, hipStream_t s) {
     const int RS0 = bp_rec_bytes(idx->store_dtype == VS_F32 ? VM_F16 : idx->store_dtype == VS_F16 ? VM_F16 : VM_BIN);   // smallest record this index can get
     const size_t b_dir = (size_t)n_blocks * ((size_t)V + 1) * 4;
     size_t free_b = 0, total_b = 0;
+    // (the head pre-pass's scratch of this device -- tens of GB, kept between searches -- is given back before a copy is sized: the next
+    //  search on a head-column index takes it again, within what is then free)
+    if (device_scratch(idx->device, kScratchHeadOut).bytes) { device_scratch(idx->device, kScratchHeadOut).release(); device_scratch(idx->device, kScratchHeadW).release(); }
     VS_HIP(hipMemGetInfo(&free_b, &total_b));
     const size_t margin = idx->bp_pref == 1 ? ((size_t)256 << 20) : ((size_t)4 << 30);  // leave room for scratch / other tensors
     auto no_room = [&](size_t need) {
@@ -567,8 +569,13 @@ int bp_filter_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64
         const size_t per_tile = (size_t)n_blocks * (size_t)idx->bp_rows * 8 * 4;
         size_t free_b = 0, total_b = 0;
         VS_HIP(hipMemGetInfo(&free_b, &total_b));
-        const size_t have = idx->ws_head_out.bytes, margin = (size_t)6 << 30;
-        const size_t room = free_b + have > margin ? free_b + have - margin : 0;
+        // ONE scratch per device, shared by every index on it (per index and sized from "what is free" the first search on a
+        // head-column index took most of the free HBM for good): at most a quarter of the device's memory, 48 GB, and what is free minus a
+        // margin; bp_build gives it back when a postings copy needs the room (head_scratch_release)
+        DevBuf& head_out = device_scratch(idx->device, kScratchHeadOut);
+        DevBuf& head_w = device_scratch(idx->device, kScratchHeadW);
+        const size_t have = head_out.bytes, margin = (size_t)6 << 30;
+        const size_t room = std::min<size_t>(free_b + have > margin ? free_b + have - margin : 0, total_b / 4);
         static const int tpp_env = getenv("VS_HEAD_TILES") ? atoi(getenv("VS_HEAD_TILES")) : 0;      // (developer: tiles per pass)
         int tpp = (int)std::min<size_t>(std::max<size_t>(have, std::min<size_t>(room, (size_t)48 << 30)) / std::max<size_t>(per_tile, 1), (size_t)ceil_div(B, qt));
         if (tpp_env > 0) tpp = std::min(tpp, tpp_env);
@@ -577,8 +584,8 @@ int bp_filter_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64
         else if (tpp >= 2) tpp &= ~1;                                          // (a weight operand holds two tiles: passes start on even tiles)
         if (tpp < 1) return fail(VS_ENOMEM, "head pre-pass: no HBM for the dense sums of one tile (%.2f GB)", (double)per_tile / 1e9);
         tiles_per_pass = tpp;
-        VS_TRY(idx->ws_head_out.reserve((size_t)tpp * per_tile));
-        VS_TRY(idx->ws_head_w.reserve((size_t)((tpp + 1) / 2) * head_ks * 1024));
+        VS_TRY(head_out.reserve((size_t)tpp * per_tile));
+        VS_TRY(head_w.reserve((size_t)((tpp + 1) / 2) * head_ks * 1024));
         n_pass = ceil_div(B, tpp);                                           // (a tile holds >= 1 query: passes beyond the batch's tiles return at once)
     }
     const int n_tiles_est = head_gemm ? std::min(tiles_per_pass, ceil_div(B, qt)) : ceil_div(B, qt);
@@ -657,8 +664,8 @@ int bp_filter_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64
         if (head_gemm) {
             HeadArgs h{};
             h.strip = a.strip;
-            h.wt = idx->ws_head_w.as<uint4>();
-            h.out = idx->ws_head_out.as<int32_t>();
+            h.wt = device_scratch(idx->device, kScratchHeadW).as<uint4>();
+            h.out = device_scratch(idx->device, kScratchHeadOut).as<int32_t>();
             h.tiles = tiles;
             h.n_tiles_dev = a.n_tiles_dev;
             h.tile0 = pass * tiles_per_pass;

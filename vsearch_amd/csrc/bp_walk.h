@@ -565,6 +565,7 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
     unsigned long long* upper_sh = tau + QT;                                                // [QT] exclusive upper bounds ("search after")
     int* scratch = reinterpret_cast<int*>(upper_sh + QT);                                   // [48]
     unsigned int* ccnt = reinterpret_cast<unsigned int*>(scratch + 48);                     // [QT]
+    unsigned int* chi = ccnt + 8;                                                           // [QT <= 8] the counters' high halves at the end of the previous block (epilogue)
     uint2* ent = reinterpret_cast<uint2*>(scratch + 64);                                    // [ent_cap]: x = column | slot byte offset << 16, y = weight bits
     _Float16* hw = reinterpret_cast<_Float16*>(ent + a.ent_cap);                            // [16][ldb] the tile's weights on the head columns (bp_head_lds)
 
@@ -663,7 +664,7 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
             __syncthreads();
         }
         for (int i = tid; i < RMAX * PITCH; i += kScanThreads) acc[i] = (acc_t)0;
-        if (tid < QT) { tau[tid] = 0ull; ccnt[tid] = 0u; }
+        if (tid < QT) { tau[tid] = 0ull; ccnt[tid] = 0u; chi[tid] = 0u; }
         if (tid < QT) upper_sh[tid] = (a.upper && tid < nq) ? a.upper[q0 + tid] : ~0ull;
         if (tid < 2) scratch[40 + tid] = 0;                   // chunk counters of even / odd blocks (below)
         __syncthreads();
@@ -954,6 +955,8 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
             // epilogue: 1024 documents at a time, one per thread: its QT sums -> order keys -> candidates; prune when a buffer could overflow
             for (int d0 = 0; d0 < rows_b || d0 == 0; d0 += kScanThreads) {
                 const int d = d0 + tid;
+                const bool more = d0 + kScanThreads < rows_b;         // another round of this block follows
+                const uint32_t inc = more ? 1u : 0x10000u;
                 // the score halves of the thresholds, once per round: nearly every (document, slot) ends at ONE 32-bit compare
                 uint32_t thi[QT];
 #pragma unroll
@@ -988,24 +991,39 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
                         if (q < nq && hi >= thi[q]) {
                             const uint64_t key = ((uint64_t)hi << 32) | (uint32_t)(~(uint32_t)row);
                             if (key > tau[q] && key < upper_sh[q]) {
-                                const uint32_t pos = atomicAdd(&ccnt[q], 1u);
-                                my_gcand[(size_t)q * kBpCap + pos] = key;
+                                const uint32_t old = atomicAdd(&ccnt[q], inc);                 // (low half: first rounds, high half: last rounds -- below)
+                                my_gcand[(size_t)q * kBpCap + (old & 0xFFFFu) + (old >> 16)] = key;
                             }
                         }
                     }
                 }
+                // Whether a buffer has to be cut is ONE decision of the workgroup (barriers sit behind it), read by every thread from the
+                // counters behind the round's barrier: a block's first round counts in the LOW half of a slot's counter, its last round in
+                // the HIGH half; behind the first round the waves already in the second change the high halves only, and the count is low
+                // half + the high half as it stood at the end of the previous block (chi[]) -- bp_quad.h, docs/EXPERIMENTS.md round 6
                 __syncthreads();
-                const bool last = b + 1 >= b1 && d0 + kScanThreads >= rows_b;
+                // (VS_BP_KNOB = 128 + 256 n, tests: one wave reads the counters n x 512 cycles late; a scalar branch -- s_sleep ignores exec)
+                if ((a.knob & 128) && __builtin_amdgcn_readfirstlane((tid >> 6)) == 5)
+                    for (int i = 0; i < (a.knob >> 8); ++i) __builtin_amdgcn_s_sleep(8);
+                const bool last = b + 1 >= b1 && !more;
                 // (the QT counters in one round of reads, then register compares: 8 dependent read-and-branch steps cost 1.7 k cycles here)
                 uint32_t cnts[QT];
 #pragma unroll
                 for (int q = 0; q < QT; ++q) cnts[q] = ccnt[q];
+                if (more) {
+#pragma unroll
+                    for (int q = 0; q < QT; ++q) cnts[q] = (cnts[q] & 0xFFFFu) + chi[q];
+                } else {
+#pragma unroll
+                    for (int q = 0; q < QT; ++q) cnts[q] = (cnts[q] & 0xFFFFu) + (cnts[q] >> 16);
+                    if (tid < QT) chi[tid] = ccnt[tid] >> 16;             // (the next block's first round reads it two barriers from here)
+                }
                 bool any = last;
 #pragma unroll
                 for (int q = 0; q < QT; ++q) any = any || cnts[q] > (uint32_t)(kBpCap - kScanThreads);
                 if (any)
                 for (int qs = 0; qs < nq; ++qs) {
-                    const uint32_t cnt = ccnt[qs];
+                    const uint32_t cw = ccnt[qs], cnt = (cw & 0xFFFFu) + (cw >> 16);       // (inside the cut nobody pushes: the word is what it is)
                     if (last || cnt > (uint32_t)(kBpCap - kScanThreads)) {
                         for (int i = tid; i < kBpCap; i += kScanThreads) sortbuf[i] = (uint32_t)i < cnt ? my_gcand[(size_t)qs * kBpCap + i] : 0ull;
                         wg_sort_desc<kScanThreads>(sortbuf, kBpCap, tid);
@@ -1018,7 +1036,8 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
                                 const unsigned long long kth = sortbuf[K - 1];
                                 if (kth > tau[qs]) tau[qs] = kth;
                                 if (a.gtau && kth != 0ull) atomicMax(a.gtau + q0 + qs, kth);
-                                ccnt[qs] = (uint32_t)K;
+                                ccnt[qs] = (uint32_t)K;                     // (low half K, high half 0)
+                                chi[qs] = 0u;
                             }
                         }
                         __syncthreads();

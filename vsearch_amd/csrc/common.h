@@ -97,7 +97,17 @@ struct DevBuf {
 
 // Small per-device scratch buffers that outlive a call (never freed: hipFree synchronises the device, and a
 // malloc/free pair per call costs more than the sparsify kernels themselves).  The library is driven by one host
-// thread; a slot is owned by one entry point.
+// thread; a slot is owned by ONE entry point:
+enum : int {
+    kScratchFlags = 0,      // sparsify.hip: per-row flags of the mask stage
+    kScratchCounts = 1,     // sparsify.hip: per-row non-zero counts
+    kScratchRowPtr = 2,     // sparsify.hip: vs_dense_to_csr row pointers
+    kScratchMergeKeys = 3,  // csr_index.hip: vs_merge_topk keys (kept between the calls of a sharded search)
+    kScratchHeadKeys = 4,   // dense.hip: keys of the fused encoder head
+    kScratchCsrSlots = 5,   // sparsify.hip: vs_embed_mask_to_csr slot runs
+    kScratchHeadOut = 6,    // bp_search.hip: the head pre-pass's dense sums -- ONE per device, shared by every index on it (it can be tens of GB)
+    kScratchHeadW = 7,      // bp_search.hip: the head pre-pass's weight operands
+};
 inline DevBuf& device_scratch(int device, int slot) {
     static DevBuf* pool = new DevBuf[16 * 8];
     return pool[(device & 15) * 8 + (slot & 7)];
@@ -256,7 +266,6 @@ struct vs_index {
     vs::DevBuf mat;      // [n_rows, n_cols] store_dtype
     // scratch owned by the handle (grow-only)
     vs::DevBuf ws_q, ws_cand, ws_out_ids, ws_out_scores, ws_misc, ws_mq_meta, ws_mq_q, ws_mq_cand, ws_fb, ws_pace;
-    vs::DevBuf ws_head_w, ws_head_out;   // head pre-pass (bp_head.h): the pass's weight operands, the dense part of the sums
     bool logical_dense = false;   // dense Index stored as CSR packets (sparsity-aware dense index)
     int qt_pref = 0;     // 0 = auto (multi-query pass when the batch qualifies), 1 = force the dense-image pass
     int last_qt = 0;     // queries per pass of the most recent search

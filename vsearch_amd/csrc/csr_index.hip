@@ -900,7 +900,7 @@ extern "C" int vs_merge_topk(const int64_t* cand_ids, const float* cand_scores, 
     hipStream_t s = (hipStream_t)stream;
     const size_t n = (size_t)B * n_cand;
     DevBuf st_ids, st_sc, o_ids, o_sc;
-    DevBuf& keys = device_scratch(device, 3);                 // kept between calls: the sharded search merges once per batch
+    DevBuf& keys = device_scratch(device, kScratchMergeKeys);                 // kept between calls: the sharded search merges once per batch
     const void *d_ids = nullptr, *d_sc = nullptr;
     VS_TRY(to_device(cand_ids, n * 8, st_ids, s, &d_ids));
     VS_TRY(to_device(cand_scores, n * 4, st_sc, s, &d_sc));

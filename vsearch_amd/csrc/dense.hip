@@ -566,7 +566,7 @@ extern "C" int vs_head_project_pool(const float* hidden, const float* W, int32_t
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { (void)hipGetLastError(); return fail(VS_ENODEVICE, "no HIP device visible"); }
     VS_HIP(hipSetDevice(device));
     hipStream_t s = (hipStream_t)stream;
-    DevBuf& keys = device_scratch(device, 4);                            // kept between calls: one per encoder batch
+    DevBuf& keys = device_scratch(device, kScratchHeadKeys);                            // kept between calls: one per encoder batch
     VS_TRY(keys.reserve((size_t)B * V * 4));
     VS_HIP(hipMemsetAsync(keys.p, 0, (size_t)B * V * 4, s));            // key 0 < key of any real number
     {

@@ -228,7 +228,7 @@ int run_mask(MaskArgs a, const float* x_in, float* emb_io, const int64_t* ids, u
     const size_t lds = mask_lds_bytes(a.V);
     if (lds > 160 * 1024) return fail(VS_EUNSUPPORTED, "V = %d needs %zu B of LDS (> 160 KiB)", a.V, lds);
     DevBuf st_x, st_ids, st_mask;
-    DevBuf& flags = device_scratch(device, 0);
+    DevBuf& flags = device_scratch(device, kScratchFlags);
     VS_TRY(flags.reserve(128));
     if (ids) VS_HIP(hipMemsetAsync(flags.p, 0, 4, s));
 #ifdef MR_TIMING
@@ -509,9 +509,9 @@ extern "C" int vs_embed_mask_to_csr(const float* x, int64_t ld, const int64_t* i
     VS_TRY(check_device(device));
     hipStream_t s = (hipStream_t)stream;
     const int32_t slot_cap = (int32_t)std::min<int64_t>(V, (int64_t)topk + (activate_lexical ? L : 0));
-    DevBuf& flags = device_scratch(device, 0);
-    DevBuf& counts = device_scratch(device, 1);
-    DevBuf& slots = device_scratch(device, 3);
+    DevBuf& flags = device_scratch(device, kScratchFlags);
+    DevBuf& counts = device_scratch(device, kScratchCounts);
+    DevBuf& slots = device_scratch(device, kScratchCsrSlots);
     VS_TRY(flags.reserve(128));
     VS_TRY(counts.reserve((size_t)B * 8));
     VS_TRY(slots.reserve((size_t)B * slot_cap * 8));
@@ -554,8 +554,8 @@ extern "C" int vs_dense_to_csr(const float* x, int32_t B, int32_t V, int64_t ld,
     DevBuf st_x, st_c, st_v;
     const void* dx = nullptr;
     VS_TRY(to_device(x, ((size_t)(B - 1) * ld + V) * 4, st_x, s, &dx));
-    DevBuf& counts = device_scratch(device, 1);
-    DevBuf& d_rp = device_scratch(device, 2);
+    DevBuf& counts = device_scratch(device, kScratchCounts);
+    DevBuf& d_rp = device_scratch(device, kScratchRowPtr);
     VS_TRY(counts.reserve((size_t)B * 8));
     VS_TRY(d_rp.reserve((size_t)(B + 1) * 8));
     const bool rp_dev = is_device_ptr(rowptr);

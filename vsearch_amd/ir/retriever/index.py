@@ -255,6 +255,16 @@ class Index:
         return "".join(f"{name:<18}: {value}\n" for name, value in rows)
 
 
+def _vsx_rows(path: str) -> int:
+    """rows of a native .vsx shard, from its header (csr_index.hip VsxHeader: magic[8], int32 store_dtype, n_cols, int64 n_rows, ...)"""
+    import struct
+    with open(path, "rb") as fh:
+        hdr = fh.read(24)
+    if len(hdr) < 24 or hdr[:7] != b"VSXCSR1":
+        raise ValueError(f"{path} is not a vsearch native shard file")
+    return int(struct.unpack_from("<q", hdr, 16)[0])
+
+
 class SparseIndex(Index):
     index_type = IndexType.SPARSE
 
@@ -432,22 +442,31 @@ class SparseIndex(Index):
                     self.shard_rows(gpus)
                 else:
                     # every file's rows, sliced at the GPUs' range boundaries; a GPU whose range spans two files holds two shards
-                    # (a shard group takes any number of shards per device, in row order)
+                    # (a shard group takes any number of shards per device, in row order).  ONE file at a time (all files at
+                    # once on the first GPU needed room for the whole index there): the row counts come from the files' headers, a file
+                    # is loaded on the GPU that gets most of its rows, cut into the ranges it overlaps (peer copies) and closed
                     from vsearch_amd.distributed import shard_rows as _range
-                    loaded = [DeviceIndex.load_native(f, device=gpus[0]) for f in files]
-                    rows = [int(d.info().n_rows) for d in loaded]
+                    rows = [_vsx_rows(f) for f in files]
                     total, built, start = sum(rows), [], 0
                     bounds = [_range(total, len(gpus), r) for r in range(len(gpus))]
                     try:
-                        for dev, n in zip(loaded, rows):
-                            for gpu, (b0, bn) in zip(gpus, bounds):
-                                lo, hi = max(start, b0), min(start + n, b0 + bn)
-                                if hi > lo:
+                        for f, n in zip(files, rows):
+                            cuts = [(gpu, max(start, b0), min(start + n, b0 + bn)) for gpu, (b0, bn) in zip(gpus, bounds)]
+                            cuts = [(gpu, lo, hi) for gpu, lo, hi in cuts if hi > lo]
+                            home = max(cuts, key=lambda c: c[2] - c[1])[0] if cuts else gpus[0]
+                            dev = DeviceIndex.load_native(f, device=home)
+                            try:
+                                if int(dev.info().n_rows) != n:
+                                    raise ValueError(f"{f}: header says {n} rows, the file holds {int(dev.info().n_rows)}")
+                                for gpu, lo, hi in cuts:
                                     built.append(dev.slice_rows(lo - start, hi - lo, gpu))
+                            finally:
+                                dev.close()
                             start += n
-                    finally:
-                        for dev in loaded:
-                            dev.close()
+                    except Exception:
+                        for d in built:
+                            d.close()
+                        raise
                     info = built[0].info()
                     self._dtype = torch.float32 if info.store_dtype == nat.VS_F32 else torch.float16
                     self._shape = (total, int(info.n_cols))
@@ -525,13 +544,20 @@ class SparseIndex(Index):
         gpus = self._devices or [_gpu_ordinal(self.device)]
         split_rows = bool(self._devices) and len(files) < len(gpus)      # fewer files than GPUs (one .npz: what `save` writes): row ranges
         all_gpus = gpus
-        if split_rows:
+        if split_rows and len(files) == 1:
             gpus = gpus[:1]
-        groups, start = [[] for _ in gpus], 0
+        groups, start, g_row0 = [[] for _ in gpus], 0, [None] * len(gpus)
         for f in files:
-            groups[min(len(gpus) - 1, start * len(gpus) // max(rows_total, 1))].append(f)
+            # (row ranges: a file goes to the GPU whose range holds its middle row -- converted there, then cut into the ranges it overlaps;
+            #  whole files: to the GPUs in row order, as evenly in rows as the files' boundaries allow)
+            at = (start + f_rows[f] // 2) if split_rows else start
+            g = min(len(gpus) - 1, at * len(gpus) // max(rows_total, 1))
+            if g_row0[g] is None:
+                g_row0[g] = start
+            groups[g].append(f)
             start += f_rows[f]
         plan = [(g, fs) for g, fs in zip(gpus, groups) if fs]
+        plan_row0 = [r0 for r0, fs in zip(g_row0, groups) if fs]
 
         def convert(store):
             built = []
@@ -572,6 +598,29 @@ class SparseIndex(Index):
         if len(built) == 1 and split_rows:
             self._dev = built[0]
             self.shard_rows(all_gpus)                                # joined on the first GPU, dealt out in row ranges (device to device)
+        elif split_rows:
+            # several files, fewer than GPUs: every converted group is cut into the GPUs' row ranges (peer copies) and closed; when a GPU has
+            # no room for a range beside the group it holds, the groups stay as they are -- whole files as shards (the dealing before round 5)
+            from vsearch_amd.distributed import shard_rows as _range
+            bounds = [_range(rows_total, len(all_gpus), r) for r in range(len(all_gpus))]
+            cut, ok = [], True
+            try:
+                for dev, r0 in zip(built, plan_row0):
+                    n = int(dev.info().n_rows)
+                    for gpu, (b0, bn) in zip(all_gpus, bounds):
+                        lo, hi = max(r0, b0), min(r0 + n, b0 + bn)
+                        if hi > lo:
+                            cut.append(dev.slice_rows(lo - r0, hi - lo, gpu))
+            except nat.VsearchNativeError as e:
+                logger.warning("row ranges over %d GPUs did not fit (%s): keeping %d whole-file shards", len(all_gpus), e, len(built))
+                ok = False
+                for d in cut:
+                    d.close()
+            if ok:
+                for dev in built:
+                    dev.close()
+                built = cut
+            self._adopt_shards(built)
         elif len(built) == 1:
             self._dev = built[0]
             self._prepare()
