@@ -229,7 +229,7 @@ def summarise(line):
     r3 = lambda x: None if x is None else float(f"{x:.4g}")
     out = {"_": "leg: [ms, q/s, roofline.frac, parity ok]", "headline": [r3(line["ms_per_step"]), r3(line["value"]), r3(line["roofline"]["frac"]), ok(line.get("parity"))]}
     short = {"C2_dense_100k": "C2", "C3_1m_sparse": "C3", "C5_bot_21m": "C5", "zipf_21m": "zipf", "fp16_21m": "fp16", "facade": "facade", "shard_group_8_on_one_gpu": "shards8",
-             "embed_mask_B1024": "mask", "dense_to_csr_B1024": "to_csr", "embed_to_csr_B1024": "mask_csr", "head_project_pool_64x256": "head", "rerank_1024x100": "rerank"}
+             "deep_k_21m": "deepk", "embed_mask_B1024": "mask", "dense_to_csr_B1024": "to_csr", "embed_to_csr_B1024": "mask_csr", "head_project_pool_64x256": "head", "rerank_1024x100": "rerank"}
     for key, rec in (line.get("secondary") or {}).items():
         if key not in short or not isinstance(rec, dict) or "error" in rec:
             continue
@@ -363,6 +363,31 @@ def secondary(index, batches, args, local_rank, device, headline_s):
         for b in (1, 32):
             lat[f"B={b}_ms"] = _timed(lambda: index.search(batches[0][:b], args.k), 20, 3) * 1e3
         out["latency_21m"] = lat
+    # deep k (reference: index.py:92 takes any k <= N): beyond the filter's candidate buffers (k + margin > 1024 ranks) a search on the quad
+    # copy leaves it for "search after" passes of the CSR scan; exact records (postings_walk = 0) serve 1024 ranks a pass on the fp64 walk
+    # (DESIGN 2).  64 queries, k = 2000, the same 21 M-doc index -- the documented cliff, with a number (ADVICE r4 / VERDICT r5 item 7)
+    if want("deepk"):
+        try:
+            kd, bd = 2000, 64
+            qd = batches[0][:bd]
+            ids_a, sc_a = index.search(qd, kd)
+            t_quad = _timed(lambda: index.search(qd, kd), 2)
+            path_a = index.info().last_path
+            index.set_option("postings_walk", 0)                      # records instead of quad chunks (rebuilt at the next search)
+            ids_b, sc_b = index.search(qd, kd)
+            t_rec = _timed(lambda: index.search(qd, kd), 2)
+            path_b = index.info().last_path
+            same = bool((ids_a == ids_b).all().item() and (sc_a == sc_b).all().item())
+            out["deep_k_21m"] = {"k": kd, "batch": bd, "docs": N_DOCS, "ms_per_step": t_quad * 1e3, "queries_per_sec": bd / t_quad,
+                                 "quad_copy": {"ms_per_step": t_quad * 1e3, "queries_per_sec": bd / t_quad, "last_path": int(path_a),
+                                               "note": "k + margin beyond the filter's 1024-rank buffers: CSR scan, 'search after' passes"},
+                                 "record_copy": {"ms_per_step": t_rec * 1e3, "queries_per_sec": bd / t_rec, "last_path": int(path_b),
+                                                 "note": "postings_walk = 0: exact records, fp64 walk, 1024 ranks a pass"},
+                                 "k100_same_batch_ms": _timed(lambda: index.search(qd, args.k), 2) * 1e3,
+                                 "parity": {"vs": "the two paths against each other (ids and scores bit for bit)", "ok": same}}
+            index.set_option("postings_walk", -1)
+        except Exception as e:
+            out["deep_k_21m"] = {"error": str(e)[:200]}
     index.close()
 
     # one process, 8 row shards of the same index on this one device (vs_shard_group_*: per-shard searches on their own streams, the

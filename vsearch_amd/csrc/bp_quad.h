@@ -251,6 +251,8 @@ __global__ __launch_bounds__(256) void quad_arrange_kernel(uint32_t* rec, unsign
 // waves walk the table (quad_walk_asm: wave w takes steps w, w + 16, ...); chunks that link to an overflow chunk leave a descriptor in
 // the wave's own list, which the wave walks right after (quad_list_asm), and so on down the chain; one LDS barrier; the epilogue turns
 // the block's sums into candidates.  The only global loads of a block are its chunks (and one scalar load of the next block's base).
+typedef unsigned short quad_us2 __attribute__((ext_vector_type(2)));
+
 template <int TM>          // TM = 1: phase clocks (VS_BP_TIMING)
 __global__ __launch_bounds__(kScanThreads) void bp_quad_topk(BpArgs a) {
     constexpr int QT = kQuadQT;
@@ -450,25 +452,27 @@ __global__ __launch_bounds__(kScanThreads) void bp_quad_topk(BpArgs a) {
                 if ((a.knob & 128) && __builtin_amdgcn_readfirstlane(wv) == 5)
                     for (int i = 0; i < (a.knob >> 8); ++i) __builtin_amdgcn_s_sleep(8);
                 const bool last = b + 1 >= b1 && !more;
-                uint32_t cnts[QT];
+                // (every vector instruction of a thread costs the epilogue ~ 16 cycles a round -- 4 waves a SIMD, 4 cycles each: low + high
+                //  of a counter is ONE v_dot2_u32_u16, the eight limits one compare of their maximum)
+                uint32_t cmax;
                 {
                     const uint4* c4 = reinterpret_cast<const uint4*>(ccnt);
                     const uint4 c0 = c4[0], c1 = c4[1];
                     const uint32_t w[QT] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+                    uint32_t t[QT];
                     if (more) {
                         const uint4 h0 = c4[2], h1 = c4[3];              // chi[]
                         const uint32_t h[QT] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
 #pragma unroll
-                        for (int q = 0; q < QT; ++q) cnts[q] = (w[q] & 0xFFFFu) + h[q];
+                        for (int q = 0; q < QT; ++q) t[q] = __builtin_amdgcn_udot2(__builtin_bit_cast(quad_us2, w[q]), quad_us2{1, 0}, h[q], false);
                     } else {
 #pragma unroll
-                        for (int q = 0; q < QT; ++q) cnts[q] = (w[q] & 0xFFFFu) + (w[q] >> 16);
-                        if (tid < QT) chi[tid] = ccnt[tid] >> 16;         // (the next block's first round reads it two barriers from here)
+                        for (int q = 0; q < QT; ++q) t[q] = __builtin_amdgcn_udot2(__builtin_bit_cast(quad_us2, w[q]), quad_us2{1, 1}, 0u, false);
+                        if (tid < QT) chi[tid] = ccnt[tid] >> 16;                    // (the next block's first round reads it two barriers from here)
                     }
+                    cmax = max(max(max(t[0], t[1]), max(t[2], t[3])), max(max(t[4], t[5]), max(t[6], t[7])));
                 }
-                bool any = last;
-#pragma unroll
-                for (int q = 0; q < QT; ++q) any = any || cnts[q] > (uint32_t)(kBpCap - kScanThreads);
+                const bool any = last || cmax > (uint32_t)(kBpCap - kScanThreads);
                 if (any) __syncthreads();                               // the candidates stored above become visible to the workgroup
                 if (any)
                 for (int qs = 0; qs < nq; ++qs) {
