@@ -263,6 +263,19 @@ def pmc_leg(name, batch):
     return None
 
 
+def pmc_utilisation(kernel):
+    """What the walk waits for, from the committed counter passes (tools/pmc_walk.sh -> tools/pmc_walk_summary.py -> profiles/pmc_summary.json
+    "utilisation"), only when taken on this kernel build: L1 -> L2 read requests per clock and CU, the L2 hit rate, and the request rate as a
+    fraction of the ceiling tools/microbench/l2_requests.hip measured for that hit rate (0.40 requests a clock and CU from L2, 0.095 beyond)."""
+    try:
+        rec = json.load(open(os.path.join(REPO, "profiles", "pmc_summary.json"))).get("utilisation", {}).get(kernel)
+        if rec and rec.get("source_hash") == kernel_source_hash():
+            return {k: rec[k] for k in ("l2_requests_per_clk_cu", "l2_hit_rate", "request_ceiling_frac", "tcp_tcc_read_latency_cycles", "shape", "tag") if k in rec}
+    except Exception:
+        pass
+    return None
+
+
 def run_leg(name, docs, nnz, kind, store, val_law, steps, B, k, local_rank, device, exact=False, columns="uniform", parity=True):
     """One secondary configuration: builds the synthetic index, times `steps` searches of 1024-query batches, returns the record
     (ms, q/s, scan kernel time, `roofline`, oracle parity of a prefix).  The `roofline` is traffic-based when profiles/pmc_summary.json
@@ -321,6 +334,11 @@ def run_leg(name, docs, nnz, kind, store, val_law, steps, B, k, local_rank, devi
         rl = roof("hbm", algo, L2_PEAK_GBS, "GB/s", traffic=None, bound_note="L2: the walk's bytes are L2 / Infinity-Cache served; no PMC pass of this leg on this kernel "
                   "build, so the algorithmic bytes are priced against the L2 -> L1 aggregate, not the HBM peak",
                   achieved_is="algorithmic bytes of the scan kernel / its time", **extra)
+    ut = pmc_utilisation("bp_bq_topk" if info.postings_walk == 6 else "bp_quad_topk" if info.postings_walk == 4 else "bp_walk_topk") if info.last_path == 3 else None
+    if ut:
+        for key in ("l2_requests_per_clk_cu", "l2_hit_rate", "request_ceiling_frac"):
+            rl[key] = ut.get(key)
+        rl["utilisation_source"] = f"profiles/pmc_summary.json utilisation ({ut.get('tag')}, {ut.get('shape')})"
     rec = {"docs": docs, "nnz_per_doc": nnz, "columns": columns, "store": {0: "fp32", 1: "fp16", -1: "binary"}.get(store, str(store)), "batch": B, "k": k, "steps": steps,
            "ms_per_step": dt * 1e3, "queries_per_sec": B / dt,
            "scan_path": info.last_path, "kernel": kernel, "scan_kernel_ms": per_search_s * 1e3, "scan_launches_per_search": launches / max(1, steps + 1),
@@ -373,7 +391,8 @@ def secondary(index, batches, args, local_rank, device, headline_s):
             ids_a, sc_a = index.search(qd, kd)
             t_quad = _timed(lambda: index.search(qd, kd), 2)
             path_a = index.info().last_path
-            index.set_option("postings_walk", 0)                      # records instead of quad chunks (rebuilt at the next search)
+            index.set_option("postings_walk", 0)                      # records instead of quad chunks (rebuilt at the next search) ...
+            index.set_option("postings_quant", 0)                     # ... with exact fp32 values: what the fp64 walk needs
             ids_b, sc_b = index.search(qd, kd)
             t_rec = _timed(lambda: index.search(qd, kd), 2)
             path_b = index.info().last_path
@@ -382,10 +401,11 @@ def secondary(index, batches, args, local_rank, device, headline_s):
                                  "quad_copy": {"ms_per_step": t_quad * 1e3, "queries_per_sec": bd / t_quad, "last_path": int(path_a),
                                                "note": "k + margin beyond the filter's 1024-rank buffers: CSR scan, 'search after' passes"},
                                  "record_copy": {"ms_per_step": t_rec * 1e3, "queries_per_sec": bd / t_rec, "last_path": int(path_b),
-                                                 "note": "postings_walk = 0: exact records, fp64 walk, 1024 ranks a pass"},
+                                                 "note": "postings_walk = 0, postings_quant = 0: exact fp32 records, fp64 walk, 1024 ranks a pass"},
                                  "k100_same_batch_ms": _timed(lambda: index.search(qd, args.k), 2) * 1e3,
                                  "parity": {"vs": "the two paths against each other (ids and scores bit for bit)", "ok": same}}
             index.set_option("postings_walk", -1)
+            index.set_option("postings_quant", -1)
         except Exception as e:
             out["deep_k_21m"] = {"error": str(e)[:200]}
     index.close()
@@ -738,6 +758,13 @@ def main():
             "roofline": roofline,
         }
         line["roofline"]["kernel_source_hash"] = kernel_source_hash()
+        # what the walk waits for: the L1 -> L2 request rate, the L2 hit rate, and the rate as a fraction of the request
+        # ceiling at that hit rate -- from the committed utilisation passes of THIS kernel build (null otherwise), like the traffic
+        ut = pmc_utilisation("bp_quad_topk" if info.postings_walk == 4 else "bp_bq_topk" if info.postings_walk == 6 else "bp_walk_topk") if info.last_path == 3 else None
+        for key in ("l2_requests_per_clk_cu", "l2_hit_rate", "request_ceiling_frac"):
+            line["roofline"][key] = (ut or {}).get(key)
+        line["roofline"]["utilisation_source"] = (f"profiles/pmc_summary.json utilisation ({ut.get('tag')}: rocprofv3 --pmc passes, {ut.get('shape')}); ceiling: "
+                                                  "tools/microbench/l2_requests.hip (0.40 requests a clock and CU from L2, 0.095 beyond)") if ut else None
         if world > 1:
             line["parity"] = sharded_parity
         if world == 1:

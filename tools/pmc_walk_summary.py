@@ -48,6 +48,34 @@ if g("TCP_TCC_READ_REQ_LATENCY_sum") and g("TCP_TCC_READ_REQ_sum"):
     lines.append(f"avg TCP->TCC read latency = {g('TCP_TCC_READ_REQ_LATENCY_sum')/g('TCP_TCC_READ_REQ_sum'):.0f} cycles")
 if g("SQ_INST_LEVEL_VMEM") and g("SQ_INSTS_VMEM"):
     lines.append(f"avg VMEM instruction latency = {g('SQ_INST_LEVEL_VMEM')/g('SQ_INSTS_VMEM'):.0f} cycles")
+# the figures bench.py quotes in its roofline objects: keyed on a hash of the kernel sources, like the traffic passes
+import json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+rec = {"tag": tag, "shape": shape, "kernel": kern}
+if g("TCP_TCC_READ_REQ_sum") and g("SQ_BUSY_CYCLES"):
+    rec["l2_requests_per_clk_cu"] = g("TCP_TCC_READ_REQ_sum") / (g("SQ_BUSY_CYCLES") / 32 * 256)
+if g("TCC_HIT_sum") is not None and g("TCC_MISS_sum") is not None and g("TCC_HIT_sum") + g("TCC_MISS_sum") > 0:
+    rec["l2_hit_rate"] = g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum"))
+if g("TCP_TCC_READ_REQ_LATENCY_sum") and g("TCP_TCC_READ_REQ_sum"):
+    rec["tcp_tcc_read_latency_cycles"] = g("TCP_TCC_READ_REQ_LATENCY_sum") / g("TCP_TCC_READ_REQ_sum")
+if g("SQ_WAVE_CYCLES"):
+    rec["waves_waiting_frac"] = g("SQ_WAIT_ANY", 0) / g("SQ_WAVE_CYCLES")
+if g("SQ_LDS_IDX_ACTIVE") and g("SQ_BUSY_CYCLES"):
+    rec["lds_busy_frac"] = g("SQ_LDS_IDX_ACTIVE") / (g("SQ_BUSY_CYCLES") / 32 * 256)
+if "l2_requests_per_clk_cu" in rec and "l2_hit_rate" in rec:
+    # the request ceiling of tools/microbench/l2_requests.hip (profiles/r05_l2_request_rate.txt): 0.40 requests a clock and CU from L2, 0.095 beyond it
+    h = rec["l2_hit_rate"]
+    rec["request_ceiling_per_clk_cu"] = 1.0 / (h / 0.40 + (1.0 - h) / 0.095)
+    rec["request_ceiling_frac"] = rec["l2_requests_per_clk_cu"] / rec["request_ceiling_per_clk_cu"]
+try:
+    import bench
+    rec["source_hash"] = bench.kernel_source_hash()
+    js = os.path.join("profiles", "pmc_summary.json")
+    allrec = json.load(open(js)) if os.path.exists(js) else {}
+    allrec.setdefault("utilisation", {})[kern] = rec
+    json.dump(allrec, open(js, "w"), indent=1)
+except Exception as e:
+    print("(pmc_summary.json not updated:", e, ")")
 txt = "\n".join(lines) + "\n"
 print(txt)
 os.makedirs("profiles", exist_ok=True)
