@@ -40,8 +40,10 @@ static_assert(kQuadAccBytes >= kBpSortBytes, "the accumulator area holds the 819
 // LDS: accumulators | candidate sort buffer (during a walk: the waves' link lists) | thresholds, bounds, scratch, counters | descriptors
 // (+ the null steps the loop over-reads)
 __host__ __device__ constexpr size_t quad_fixed_lds() { return kQuadAccBytes + (size_t)kBpCap * 8 + (size_t)kQuadQT * 16 + 64 * 4; }
-__host__ __device__ constexpr size_t quad_lds_bytes() { return quad_fixed_lds() + (size_t)(kBpEntCap + 64 + 64 * kQuadOverRead) * 8; }
+__host__ __device__ constexpr size_t quad_cut_lds() { return quad_fixed_lds() + (size_t)(kBpEntCap + 64 + 64 * kQuadOverRead) * 8; }        // the cut's histograms (wg_cut_topk), behind the table
+__host__ __device__ constexpr size_t quad_lds_bytes() { return quad_cut_lds() + (size_t)kCutHistWords * 4; }
 static_assert(quad_lds_bytes() <= (size_t)160 * 1024, "the quad walk's LDS");
+static_assert(kBpCap == 2 * kScanThreads, "wg_cut_topk: two keys of the candidate buffer a thread");
 static_assert(kQuadQT == 8 && (kQuadAccBytes + (size_t)kBpCap * 8) % 16 == 0, "the epilogue reads thresholds and counters 16 bytes at a time");
 // a wave's two link lists live in its 1 KB of the sort buffer: 64 descriptors each, of which 4 * kQuadOverRead are the null ones a walk over-reads
 constexpr int kQuadListCap = 64 - 4 * kQuadOverRead, kQuadListBytes = (kQuadListCap + 4 * kQuadOverRead) * 8;
@@ -266,6 +268,7 @@ __global__ __launch_bounds__(kScanThreads) void bp_quad_topk(BpArgs a) {
     unsigned int* chi = ccnt + QT;                                                          // [QT] the counters' high halves at the end of the previous block (epilogue)
     uint2* desc = reinterpret_cast<uint2*>(scratch + 64);                                   // [n_static + 64 * kQuadOverRead]
     const uint32_t desc_lds = (uint32_t)quad_fixed_lds();                                   // its LDS byte address
+    uint32_t* cut_hist = reinterpret_cast<uint32_t*>(smem + quad_cut_lds());                // [kCutHistWords]
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int K = a.k;
@@ -473,20 +476,40 @@ __global__ __launch_bounds__(kScanThreads) void bp_quad_topk(BpArgs a) {
                     cmax = max(max(max(t[0], t[1]), max(t[2], t[3])), max(max(t[4], t[5]), max(t[6], t[7])));
                 }
                 const bool any = last || cmax > (uint32_t)(kBpCap - kScanThreads);
+                [[maybe_unused]] long long t_cut = 0;
+                if constexpr (TM != 0) t_cut = (long long)__builtin_readcyclecounter();
                 if (any) __syncthreads();                               // the candidates stored above become visible to the workgroup
                 if (any)
                 for (int qs = 0; qs < nq; ++qs) {
                     const uint32_t cw = ccnt[qs], cnt = (cw & 0xFFFFu) + (cw >> 16);       // (inside the cut nobody pushes: the word is what it is)
                     if (last || cnt > (uint32_t)(kBpCap - kScanThreads)) {
                         for (int i = tid; i < kBpCap; i += kScanThreads) sortbuf[i] = (uint32_t)i < cnt ? my_gcand[(size_t)qs * kBpCap + i] : 0ull;
-                        wg_sort_desc<kScanThreads>(sortbuf, kBpCap, tid);
                         if (last) {
+                            // the item's result: its K best, sorted.  K <= 256 (k = 100: 128): cut to K by radix select, then ONE wave sorts
+                            // them in registers (no barrier stages); else the workgroup's bitonic sort of the whole buffer
                             uint64_t* out = a.cand + ((size_t)(q0 + qs) * a.nchunk + c) * (size_t)K;
-                            for (int i = tid; i < K; i += kScanThreads) out[i] = sortbuf[i];
+                            if (K <= 256) {
+                                uint64_t* mine = my_gcand + (size_t)qs * kBpCap;
+                                if (cnt > (uint32_t)K) (void)wg_cut_topk<kScanThreads>(sortbuf, K, mine, cut_hist, tid);
+                                else __syncthreads();
+                                const uint32_t n = min(cnt, (uint32_t)K);
+                                if (tid < 64) {
+                                    uint64_t kk[4];
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) { const uint32_t e = (uint32_t)(r * 64 + tid); kk[r] = e < n ? (cnt > (uint32_t)K ? mine[e] : sortbuf[e]) : 0ull; }
+                                    wave_sort256_desc(kk, tid);
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) { const int e = r * 64 + tid; if (e < K) out[e] = kk[r]; }
+                                }
+                            } else {
+                                wg_sort_desc<kScanThreads>(sortbuf, kBpCap, tid);
+                                for (int i = tid; i < K; i += kScanThreads) out[i] = sortbuf[i];
+                            }
                         } else if (cnt > (uint32_t)K) {
-                            for (int i = tid; i < K; i += kScanThreads) my_gcand[(size_t)qs * kBpCap + i] = sortbuf[i];
+                            // (a cut needs the K best as a SET and the K-th key, not an order: radix select instead of the 66-stage sort)
+                            const unsigned long long kth_sel = wg_cut_topk<kScanThreads>(sortbuf, K, my_gcand + (size_t)qs * kBpCap, cut_hist, tid);
                             if (tid == 0) {
-                                const unsigned long long kth = sortbuf[K - 1];
+                                const unsigned long long kth = kth_sel;
                                 if (kth > tau[qs]) tau[qs] = kth;
                                 if (a.gtau && kth != 0ull) atomicMax(a.gtau + q0 + qs, kth);
                                 ccnt[qs] = (uint32_t)K;                     // (low half K, high half 0)
@@ -496,6 +519,7 @@ __global__ __launch_bounds__(kScanThreads) void bp_quad_topk(BpArgs a) {
                         __syncthreads();
                     }
                 }
+                if constexpr (TM != 0) { if (any) tacc[3] += (uint32_t)((long long)__builtin_readcyclecounter() - t_cut); }      // (phase clocks: "dense" = inside the cuts)
             }
             lap(4);
             if constexpr (TM != 0) tacc[5] += 1u;

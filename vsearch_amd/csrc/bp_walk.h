@@ -456,7 +456,7 @@ __host__ __device__ constexpr size_t bp_acc_bytes() { return (((size_t)(RMAX + 1
 __host__ __device__ inline size_t bp_head_lds(int n_head) { return n_head > 0 ? (size_t)16 * (bp_head_pad(n_head) + 8) * 2 : 0; }
 template <int QT, int AM, int RMAX>
 __host__ __device__ inline size_t bp_lds_bytes(int ent_cap, int n_head = 0) {
-    return bp_acc_bytes<QT, AM, RMAX>() + (size_t)kBpCap * 8 + (size_t)QT * 16 + 64 * 4 + (size_t)ent_cap * 8 + bp_head_lds(n_head);
+    return bp_acc_bytes<QT, AM, RMAX>() + (size_t)kBpCap * 8 + (size_t)QT * 16 + 64 * 4 + (size_t)kCutHistWords * 4 + (size_t)ent_cap * 8 + bp_head_lds(n_head);
 }
 
 __device__ __forceinline__ uint64_t make_key_fix(int32_t a, uint32_t row) {
@@ -566,7 +566,8 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
     int* scratch = reinterpret_cast<int*>(upper_sh + QT);                                   // [48]
     unsigned int* ccnt = reinterpret_cast<unsigned int*>(scratch + 48);                     // [QT]
     unsigned int* chi = ccnt + 8;                                                           // [QT <= 8] the counters' high halves at the end of the previous block (epilogue)
-    uint2* ent = reinterpret_cast<uint2*>(scratch + 64);                                    // [ent_cap]: x = column | slot byte offset << 16, y = weight bits
+    uint32_t* cut_hist = reinterpret_cast<uint32_t*>(scratch + 64);                         // [kCutHistWords] the cut's histograms (wg_cut_topk)
+    uint2* ent = reinterpret_cast<uint2*>(scratch + 64 + kCutHistWords);                    // [ent_cap]: x = column | slot byte offset << 16, y = weight bits
     _Float16* hw = reinterpret_cast<_Float16*>(ent + a.ent_cap);                            // [16][ldb] the tile's weights on the head columns (bp_head_lds)
 
     const int tid = threadIdx.x;
@@ -1026,14 +1027,32 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
                     const uint32_t cw = ccnt[qs], cnt = (cw & 0xFFFFu) + (cw >> 16);       // (inside the cut nobody pushes: the word is what it is)
                     if (last || cnt > (uint32_t)(kBpCap - kScanThreads)) {
                         for (int i = tid; i < kBpCap; i += kScanThreads) sortbuf[i] = (uint32_t)i < cnt ? my_gcand[(size_t)qs * kBpCap + i] : 0ull;
-                        wg_sort_desc<kScanThreads>(sortbuf, kBpCap, tid);
                         if (last) {
+                            // the item's result: its K best, sorted.  K <= 256 (k = 100: 128): cut to K by radix select, then ONE wave sorts
+                            // them in registers (no barrier stages); else the workgroup's bitonic sort of the whole buffer
                             uint64_t* out = a.cand + ((size_t)(q0 + qs) * a.nchunk + c) * (size_t)K;
-                            for (int i = tid; i < K; i += kScanThreads) out[i] = sortbuf[i];
+                            if (K <= 256) {
+                                uint64_t* mine = my_gcand + (size_t)qs * kBpCap;
+                                if (cnt > (uint32_t)K) (void)wg_cut_topk<kScanThreads>(sortbuf, K, mine, cut_hist, tid);
+                                else __syncthreads();
+                                const uint32_t n = min(cnt, (uint32_t)K);
+                                if (tid < 64) {
+                                    uint64_t kk[4];
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) { const uint32_t e = (uint32_t)(r * 64 + tid); kk[r] = e < n ? (cnt > (uint32_t)K ? mine[e] : sortbuf[e]) : 0ull; }
+                                    wave_sort256_desc(kk, tid);
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) { const int e = r * 64 + tid; if (e < K) out[e] = kk[r]; }
+                                }
+                            } else {
+                                wg_sort_desc<kScanThreads>(sortbuf, kBpCap, tid);
+                                for (int i = tid; i < K; i += kScanThreads) out[i] = sortbuf[i];
+                            }
                         } else if (cnt > (uint32_t)K) {
-                            for (int i = tid; i < K; i += kScanThreads) my_gcand[(size_t)qs * kBpCap + i] = sortbuf[i];
+                            // (a cut needs the K best as a set and the K-th key: radix select, topk_keys.h, instead of the 66-stage sort)
+                            const unsigned long long kth_sel = wg_cut_topk<kScanThreads>(sortbuf, K, my_gcand + (size_t)qs * kBpCap, cut_hist, tid);
                             if (tid == 0) {
-                                const unsigned long long kth = sortbuf[K - 1];
+                                const unsigned long long kth = kth_sel;
                                 if (kth > tau[qs]) tau[qs] = kth;
                                 if (a.gtau && kth != 0ull) atomicMax(a.gtau + q0 + qs, kth);
                                 ccnt[qs] = (uint32_t)K;                     // (low half K, high half 0)
