@@ -28,6 +28,9 @@
 #include "bp_quad.h"
 #include "bp_bq_asm.h"
 
+#ifndef VS_BQ_DYN
+#define VS_BQ_DYN 1             // the table's steps dealt to the waves: 1 = in batches from a counter in LDS (bq_dyn_asm), 0 = statically (wave w: steps w, w + 16, ...)
+#endif
 #ifndef VS_BQ_ZERO
 #define VS_BQ_ZERO 1            // packed walk's epilogue: 1 = read AND zero a thread's 16 dwords of sums, 0 = never zero them, keep the last block's in registers (16 VGPRs live across the walk)
 #endif
@@ -199,6 +202,7 @@ __global__ __launch_bounds__(kScanThreads) void bp_bq_topk(BpArgs a) {
     unsigned long long* bases = reinterpret_cast<unsigned long long*>(smem + bq_base_lds(NP));      // [kBqBaseWin] first chunks of the item's next blocks
     const uint32_t desc_lds = (uint32_t)bq_fixed_lds(NP);
     const uint32_t sort_lds = (uint32_t)NP * PLANE;
+    const uint32_t deal_lds = sort_lds + (uint32_t)kFlCap * 8u + 128u;                     // scratch[0]: the block's batch counter (bq_dyn_asm)
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int K = a.k;
@@ -209,7 +213,7 @@ __global__ __launch_bounds__(kScanThreads) void bp_bq_topk(BpArgs a) {
     auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
     const uint32_t list_a = sort_lds + (uint32_t)wv * 2u * kBqListBytes, list_b = list_a + kBqListBytes;
     const uint32_t g8 = (uint32_t)(lane / kBqGroupLanes) * 8u, l4 = (uint32_t)(lane % kBqGroupLanes) * (uint32_t)(kBqLaneDwords * 4);
-    constexpr uint32_t kWaveStep = kBqStepDesc * 8u;                    // bytes of a wave's descriptors of one step
+    [[maybe_unused]] constexpr uint32_t kWaveStep = kBqStepDesc * 8u;                    // bytes of a wave's descriptors of one step
 
     for (int64_t item = blockIdx.x; item < items; item += gridDim.x) {
         const int tile = (int)(item / a.nchunk), c = (int)(item % a.nchunk);
@@ -267,6 +271,7 @@ __global__ __launch_bounds__(kScanThreads) void bp_bq_topk(BpArgs a) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) prev[q][h][j] = 0u;
         if (tid < 8) { tau[tid] = 0ull; ccnt[tid] = 0u; upper_sh[tid] = (a.upper && tid < nq) ? a.upper[q0 + tid] : ~0ull; }
+        if (tid == 0) scratch[0] = 2 * kScanWaves;                       // the batch counter: batches w and w + 16 are the waves' to start with
         __syncthreads();
         const uint32_t trips = (uint32_t)(n_static / kBqTableStep);
         bool pace_off = false;
@@ -295,6 +300,18 @@ __global__ __launch_bounds__(kScanThreads) void bp_bq_topk(BpArgs a) {
                         const uint32_t t = cur; cur = nxt; nxt = t;
                     }
                 };
+#if VS_BQ_DYN
+                // batches of kBqSets steps from a counter in LDS: the waves finish the block's table together whatever their memory luck
+                // (the statement comes back early when the wave's link list wants walking: tools/gen_bq_asm.py build_dyn)
+                {
+                    const uint32_t nb = (uint32_t)n_static / (uint32_t)(kBqSets * kBqStepDesc);
+                    uint32_t cur = (uint32_t)wv, nxt = (uint32_t)wv + (uint32_t)kScanWaves, pend = ~0u;
+                    while (cur < nb) {
+                        const uint32_t n_link = bq_dyn_asm(desc_lds + g8, nb, cur, nxt, pend, deal_lds, brec, l4, (uint32_t)a.n_cols, list_a, (uint32_t)kBqListCap);
+                        chain(n_link, list_a, list_b);
+                    }
+                }
+#else
                 const uint32_t n_link = bq_walk_asm(desc_lds + (uint32_t)wv * kWaveStep + g8, trips, brec, l4, (uint32_t)a.n_cols, list_a, (uint32_t)kBqListCap);
                 if (n_link <= (uint32_t)kBqListCap) {
                     chain(n_link, list_a, list_b);
@@ -308,6 +325,7 @@ __global__ __launch_bounds__(kScanThreads) void bp_bq_topk(BpArgs a) {
                         chain(n, list_a, list_b);
                     }
                 }
+#endif
             }
             lap(1);
             if (a.pace && items <= (int64_t)gridDim.x && tid == 0 && have && !pace_off) {       // lock step (bp_walk.h)
@@ -325,6 +343,7 @@ __global__ __launch_bounds__(kScanThreads) void bp_bq_topk(BpArgs a) {
             if (a.gtau && tid < nq) { const unsigned long long g = a.gtau[q0 + tid]; if (g > tau[tid]) tau[tid] = g; }
             lds_barrier();                                               // the block's sums are complete
             lap(2);
+            if (tid == 0) scratch[0] = 2 * kScanWaves;                   // (the next block's batch counter: every wave has left the walk, the next one starts behind a barrier)
             {
                 uint32_t thi[QT];
                 {
