@@ -489,18 +489,7 @@ __global__ __launch_bounds__(kScanThreads) void bp_quad_topk(BpArgs a) {
                             // them in registers (no barrier stages); else the workgroup's bitonic sort of the whole buffer
                             uint64_t* out = a.cand + ((size_t)(q0 + qs) * a.nchunk + c) * (size_t)K;
                             if (K <= 256) {
-                                uint64_t* mine = my_gcand + (size_t)qs * kBpCap;
-                                if (cnt > (uint32_t)K) (void)wg_cut_topk<kScanThreads>(sortbuf, K, mine, cut_hist, tid);
-                                else __syncthreads();
-                                const uint32_t n = min(cnt, (uint32_t)K);
-                                if (tid < 64) {
-                                    uint64_t kk[4];
-#pragma unroll
-                                    for (int r = 0; r < 4; ++r) { const uint32_t e = (uint32_t)(r * 64 + tid); kk[r] = e < n ? (cnt > (uint32_t)K ? mine[e] : sortbuf[e]) : 0ull; }
-                                    wave_sort256_desc(kk, tid);
-#pragma unroll
-                                    for (int r = 0; r < 4; ++r) { const int e = r * 64 + tid; if (e < K) out[e] = kk[r]; }
-                                }
+                                wg_final_topk256<kScanThreads>(sortbuf, cnt, K, my_gcand + (size_t)qs * kBpCap, out, cut_hist, tid);
                             } else {
                                 wg_sort_desc<kScanThreads>(sortbuf, kBpCap, tid);
                                 for (int i = tid; i < K; i += kScanThreads) out[i] = sortbuf[i];

@@ -410,6 +410,8 @@ __device__ __forceinline__ bool pace_wait(const uint32_t* p, uint32_t need) {
     return false;
 }
 
+typedef unsigned short walk_us2 __attribute__((ext_vector_type(2)));
+
 struct BpArgs {
     int32_t rows;             // documents per block (<= the kernel's RMAX)
     const uint32_t* dir;      // [n_blocks, n_cols + 1] one word per list (bp_dir_pack)
@@ -1007,21 +1009,26 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
                 if ((a.knob & 128) && __builtin_amdgcn_readfirstlane((tid >> 6)) == 5)
                     for (int i = 0; i < (a.knob >> 8); ++i) __builtin_amdgcn_s_sleep(8);
                 const bool last = b + 1 >= b1 && !more;
-                // (the QT counters in one round of reads, then register compares: 8 dependent read-and-branch steps cost 1.7 k cycles here)
-                uint32_t cnts[QT];
+                // (the counters in one round of reads; every vector instruction of a thread costs a round ~ 16 cycles -- 4 waves a SIMD: low + high
+                //  of a counter is one v_dot2_u32_u16, the limits one compare of the maximum)
+                uint32_t cmax = 0u;
+                {
+                    uint32_t w[QT];
 #pragma unroll
-                for (int q = 0; q < QT; ++q) cnts[q] = ccnt[q];
-                if (more) {
+                    for (int q = 0; q < QT; ++q) w[q] = ccnt[q];
+                    if (more) {
+                        uint32_t h[QT];
 #pragma unroll
-                    for (int q = 0; q < QT; ++q) cnts[q] = (cnts[q] & 0xFFFFu) + chi[q];
-                } else {
+                        for (int q = 0; q < QT; ++q) h[q] = chi[q];
 #pragma unroll
-                    for (int q = 0; q < QT; ++q) cnts[q] = (cnts[q] & 0xFFFFu) + (cnts[q] >> 16);
-                    if (tid < QT) chi[tid] = ccnt[tid] >> 16;             // (the next block's first round reads it two barriers from here)
+                        for (int q = 0; q < QT; ++q) cmax = max(cmax, __builtin_amdgcn_udot2(__builtin_bit_cast(walk_us2, w[q]), walk_us2{1, 0}, h[q], false));
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < QT; ++q) cmax = max(cmax, __builtin_amdgcn_udot2(__builtin_bit_cast(walk_us2, w[q]), walk_us2{1, 1}, 0u, false));
+                        if (tid < QT) chi[tid] = ccnt[tid] >> 16;             // (the next block's first round reads it two barriers from here)
+                    }
                 }
-                bool any = last;
-#pragma unroll
-                for (int q = 0; q < QT; ++q) any = any || cnts[q] > (uint32_t)(kBpCap - kScanThreads);
+                const bool any = last || cmax > (uint32_t)(kBpCap - kScanThreads);
                 if (any)
                 for (int qs = 0; qs < nq; ++qs) {
                     const uint32_t cw = ccnt[qs], cnt = (cw & 0xFFFFu) + (cw >> 16);       // (inside the cut nobody pushes: the word is what it is)
@@ -1032,18 +1039,7 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
                             // them in registers (no barrier stages); else the workgroup's bitonic sort of the whole buffer
                             uint64_t* out = a.cand + ((size_t)(q0 + qs) * a.nchunk + c) * (size_t)K;
                             if (K <= 256) {
-                                uint64_t* mine = my_gcand + (size_t)qs * kBpCap;
-                                if (cnt > (uint32_t)K) (void)wg_cut_topk<kScanThreads>(sortbuf, K, mine, cut_hist, tid);
-                                else __syncthreads();
-                                const uint32_t n = min(cnt, (uint32_t)K);
-                                if (tid < 64) {
-                                    uint64_t kk[4];
-#pragma unroll
-                                    for (int r = 0; r < 4; ++r) { const uint32_t e = (uint32_t)(r * 64 + tid); kk[r] = e < n ? (cnt > (uint32_t)K ? mine[e] : sortbuf[e]) : 0ull; }
-                                    wave_sort256_desc(kk, tid);
-#pragma unroll
-                                    for (int r = 0; r < 4; ++r) { const int e = r * 64 + tid; if (e < K) out[e] = kk[r]; }
-                                }
+                                wg_final_topk256<kScanThreads>(sortbuf, cnt, K, my_gcand + (size_t)qs * kBpCap, out, cut_hist, tid);
                             } else {
                                 wg_sort_desc<kScanThreads>(sortbuf, kBpCap, tid);
                                 for (int i = tid; i < K; i += kScanThreads) out[i] = sortbuf[i];

@@ -51,8 +51,9 @@ __device__ __forceinline__ void wg_sort_desc(uint64_t* buf, int n, int tid) {
 //   buf: 2 * NT keys in LDS (0 = empty slot), at least K + 1 of them non-zero; hist: (2 * 256 + 8) uint32 of LDS scratch; every thread
 //   of the workgroup calls it; the caller's barrier separates the fill of buf from the call.  Returns the K-th largest key.
 constexpr int kCutHistWords = 2 * 256 + 8;
+// (NOT inlined: the walks call it on their rare path -- inlined, its registers and the compiler's spills around it land in the walks' hot loops)
 template <int NT>
-__device__ __forceinline__ uint64_t wg_cut_topk(const uint64_t* buf, int K, uint64_t* gdst, uint32_t* hist, int tid) {
+__device__ __attribute__((noinline)) uint64_t wg_cut_topk(const uint64_t* buf, int K, uint64_t* gdst, uint32_t* hist, int tid) {
     const int lane = tid & 63;
     const uint64_t k0 = buf[tid], k1 = buf[tid + NT];
     uint32_t* ctl = hist + 512;                   // [0] bin, [1] rank left inside it, [2] keys in it, [3] output counter, [4..5] the K-th key
@@ -150,6 +151,25 @@ __device__ __forceinline__ void wave_sort256_desc(uint64_t (&k)[4], int lane) {
                 }
             }
         }
+    }
+}
+
+// A work item's final result for K <= 256: the K best of the candidate buffer, sorted descending, to out[0, K) (zeros behind the last).
+// buf: the 2 * NT keys in LDS (0 = empty), cnt of them live; scratch_g: K keys of global scratch (the buffer's own backing store);
+// cut to K by radix select when there are more, then ONE wave sorts them in registers.  Not inlined (rare path, see wg_cut_topk).
+template <int NT>
+__device__ __attribute__((noinline)) void wg_final_topk256(const uint64_t* buf, uint32_t cnt, int K, uint64_t* scratch_g, uint64_t* out, uint32_t* hist, int tid) {
+    const bool cut = cnt > (uint32_t)K;
+    if (cut) (void)wg_cut_topk<NT>(buf, K, scratch_g, hist, tid);
+    else __syncthreads();
+    const uint32_t n = min(cnt, (uint32_t)K);
+    if (tid < 64) {
+        uint64_t kk[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const uint32_t e = (uint32_t)(r * 64 + tid); kk[r] = e < n ? (cut ? scratch_g[e] : buf[e]) : 0ull; }
+        wave_sort256_desc(kk, tid);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int e = r * 64 + tid; if (e < K) out[e] = kk[r]; }
     }
 }
 
