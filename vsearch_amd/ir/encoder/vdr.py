@@ -149,7 +149,10 @@ class VDREncoder(PreTrainedModel):
         """Generator over the batches of `embed(texts, ...)`, each as CSR: (rowptr int64 [b+1], cols int32, vals fp32, V) CUDA tensors --
         what `embed(batch).to_sparse_csr()` holds (vdr.py:97-179 + retriever.py:304), with the mask stage and the CSR conversion fused
         in one kernel (`vs_embed_mask_to_csr`): the masked dense batch is never written.  Falls back to embed + dense_to_csr outside
-        the fused kernel's range (topk <= 0, norm, V > 32 Ki)."""
+        the fused kernel's range (topk <= 0, V > 32 Ki, a non-fp32 head; `norm` needs no fallback: forward() has normalised already).
+        One divergence from the reference, for NON-FINITE activations only: `batch_emb *= mask` (vdr.py:169) turns an unselected NaN / inf
+        into NaN, which to_sparse_csr() keeps as a stored element; the fused kernel emits the SELECTED non-zero cells only, so such a cell
+        is dropped here (the unfused path, x * 0, keeps it).  Finite activations: identical (tests/test_gpu_facade.py)."""
         max_len = max_len or self.config.max_len
         topk = topk if topk is not None else self.config.topk
         texts = [texts] if isinstance(texts, str) else texts

@@ -167,7 +167,13 @@ class Retriever(BiEncoder):
         batches = self.encode_corpus_csr(texts, batch_size=batch_size, max_len=max_len) if fused else None
         for s in range(0, n, batch_size):
             if fused:
-                rp, ci, va, n_cols = next(batches)
+                try:
+                    rp, ci, va, n_cols = next(batches)
+                except (nat.VsearchNativeError, ValueError):
+                    # (a native error of the fused kernel -- raised here, outside the append below: the same host fallback serves it)
+                    if dev_index is not None:
+                        dev_index.close()
+                    return None
             else:
                 emb = self.encode_corpus(texts[s:s + batch_size], batch_size=batch_size, max_len=max_len, convert_to_tensor=True)
                 rp, ci, va = sp.dense_to_csr(emb.float().contiguous())        # device tensors
