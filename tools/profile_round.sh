@@ -1,7 +1,7 @@
 #!/bin/bash
 # One call on the GPU box: the round's evidence set at HEAD -> gpurun_out/<tag>_* (summaries are then copied to profiles/ by
 # tools/rocprof_summary.py / pmc_walk_summary.py on the build box).  Usage: bash tools/profile_round.sh r03
-TAG=${1:-r05}
+TAG=${1:-r06}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT

@@ -976,7 +976,7 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
                         //  from 6 k to 22 - 26 k cycles a block: docs/EXPERIMENTS.md)
                         const int32_t* hp = a.head_out + head_out_offset((int64_t)tile_rel, n_blocks, b, a.rows, d);
 #pragma unroll
-                        for (int q = 0; q < QT; ++q) pre[q] = q < nq ? hp[q * 16] : 0;
+                        for (int q = 0; q < QT; ++q) pre[q] = (q < nq && !(a.knob & 256)) ? hp[q * 16] : 0;          // (VS_BP_KNOB=256: ablation, WRONG results -- what the scratch reads cost)
                     }
 #pragma unroll
                     for (int q = 0; q < QT; ++q) sums[q] = pa[q];         // independent reads, in flight together
