@@ -715,7 +715,7 @@ def test_a_late_wave_does_not_split_the_cut_decision():
     """Round 6 (docs/EXPERIMENTS.md, profiles/r06_prune_decision_race.txt): whether a candidate buffer is cut after an epilogue round is ONE
     decision of the workgroup -- taken by the wave that arrives last at the round's end.  Until round 6 every thread read the counters behind
     the barrier; a wave that read them late saw the next round's pushes and went into the cut's barriers alone (whole blocks of candidates
-    lost once other processes' waves on the CU stretched the window: round 5's "value in a VGPR came back wrong").  VS_BP_KNOB = 128 + 256 n
+    lost once other processes' waves on the CU stretched the window: round 5's "value in a VGPR came back wrong").  VS_BP_KNOB = 128 + 4096 n
     makes one wave of every workgroup sleep n x 512 cycles between the barrier and its read (n = 1, 2, 4, 16: inside and beyond the other
     waves' next round), on the quad walk and on the list walk (exact records, and head columns behind the pre-pass): results must equal
     the CSR scan's -- the round-5 code loses documents at every n, in a single process (profiles/r06_prune_decision_race.txt).  Small shards: every work item's first block, where all documents
@@ -745,7 +745,7 @@ for kind, walk, quant in ((0, -1, -1), (0, 0, 0), (2, -1, -1)):
 print("OK")
 """ % repo
     for n in (1, 2, 4, 16):
-        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, VS_BP_KNOB=str(128 + 256 * n)))
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, VS_BP_KNOB=str(128 + 4096 * n)))
         assert r.returncode == 0 and "OK" in r.stdout, (n, r.stdout[-500:], r.stderr[-1500:])
 
 

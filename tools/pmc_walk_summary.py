@@ -70,7 +70,7 @@ if "l2_requests_per_clk_cu" in rec and "l2_hit_rate" in rec:
 try:
     import bench
     rec["source_hash"] = bench.kernel_source_hash()
-    js = os.path.join("profiles", "pmc_summary.json")
+    js = os.environ.get("VS_PMC_SUMMARY_JSON", os.path.join("profiles", "pmc_summary.json"))
     allrec = json.load(open(js)) if os.path.exists(js) else {}
     allrec.setdefault("utilisation", {})[kern] = rec
     json.dump(allrec, open(js, "w"), indent=1)

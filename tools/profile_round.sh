@@ -41,6 +41,7 @@ for LEG in C3:C3_1m_sparse C5:C5_bot_21m zipf:zipf_21m fp16:fp16_21m; do
   python3 tools/rocprof_summary.py --fetch "$(db ${TAG}_fetch_${LEG%%:*})" --write "$(db ${TAG}_write_${LEG%%:*})" --tag ${TAG}_${LEG%%:*} --leg ${LEG##*:} --queries 1024 --searches 2 --out $S \
       --note "tools/leg_pmc.py ${LEG%%:*} under rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes)" > /dev/null
 done
+export VS_PMC_SUMMARY_JSON=$S/pmc_summary.json
 python3 tools/pmc_walk_summary.py $OUT/${TAG}_pmc ${TAG} bp_quad_topk > /dev/null; python3 tools/pmc_walk_summary.py $OUT/${TAG}_pmc_zipf ${TAG}_head_gemm head_gemm "4 M docs zipf, 1024 queries" > /dev/null
 python3 tools/pmc_walk_summary.py $OUT/${TAG}_pmc_zipf ${TAG}_zipf_walk bp_walk_topk "4 M docs zipf, 1024 queries" > /dev/null; python3 tools/pmc_walk_summary.py $OUT/${TAG}_pmc_bot ${TAG}_bq bp_bq_topk "21 M docs bag-of-token, 1024 queries" > /dev/null
 cp $ROOT/profiles/${TAG}_*utilisation.txt $S/ 2>/dev/null

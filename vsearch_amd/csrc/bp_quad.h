@@ -450,10 +450,10 @@ __global__ __launch_bounds__(kScanThreads) void bp_quad_topk(BpArgs a) {
                 //  candidate -- the late reader went into the cut's barriers alone: whole blocks of candidates lost once other
                 //  processes' waves on the CU stretched the window.  docs/EXPERIMENTS.md round 6, profiles/r06_prune_decision_race.txt.)
                 lds_barrier();                                          // (the counters and sums are LDS; candidates other threads stored are read only when a prune follows)
-                // (VS_BP_KNOB = 128 + 256 n, tests: one wave reads the counters n x 512 cycles late -- the others are pushing the next round's
+                // (VS_BP_KNOB = 128 + 4096 n, tests: one wave reads the counters n x 512 cycles late -- the others are pushing the next round's
                 //  candidates by then.  A SCALAR branch: s_sleep does not care about exec -- behind a vector condition every wave slept)
                 if ((a.knob & 128) && __builtin_amdgcn_readfirstlane(wv) == 5)
-                    for (int i = 0; i < (a.knob >> 8); ++i) __builtin_amdgcn_s_sleep(8);
+                    for (int i = 0; i < (a.knob >> 12); ++i) __builtin_amdgcn_s_sleep(8);
                 const bool last = b + 1 >= b1 && !more;
                 // (every vector instruction of a thread costs the epilogue ~ 16 cycles a round -- 4 waves a SIMD, 4 cycles each: low + high
                 //  of a counter is ONE v_dot2_u32_u16, the eight limits one compare of their maximum)
@@ -481,7 +481,9 @@ __global__ __launch_bounds__(kScanThreads) void bp_quad_topk(BpArgs a) {
                 if (any) __syncthreads();                               // the candidates stored above become visible to the workgroup
                 if (any)
                 for (int qs = 0; qs < nq; ++qs) {
-                    const uint32_t cw = ccnt[qs], cnt = (cw & 0xFFFFu) + (cw >> 16);       // (inside the cut nobody pushes: the word is what it is)
+                    // (a slot's count as the decision above took it: a wave that has left this loop is already pushing the next round's
+                    //  candidates -- into the high halves)
+                    const uint32_t cw = ccnt[qs], cnt = (cw & 0xFFFFu) + (more ? chi[qs] : (cw >> 16));
                     if (last || cnt > (uint32_t)(kBpCap - kScanThreads)) {
                         for (int i = tid; i < kBpCap; i += kScanThreads) sortbuf[i] = (uint32_t)i < cnt ? my_gcand[(size_t)qs * kBpCap + i] : 0ull;
                         if (last) {

@@ -1005,9 +1005,9 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
                 // the HIGH half; behind the first round the waves already in the second change the high halves only, and the count is low
                 // half + the high half as it stood at the end of the previous block (chi[]) -- bp_quad.h, docs/EXPERIMENTS.md round 6
                 __syncthreads();
-                // (VS_BP_KNOB = 128 + 256 n, tests: one wave reads the counters n x 512 cycles late; a scalar branch -- s_sleep ignores exec)
+                // (VS_BP_KNOB = 128 + 4096 n, tests: one wave reads the counters n x 512 cycles late; a scalar branch -- s_sleep ignores exec)
                 if ((a.knob & 128) && __builtin_amdgcn_readfirstlane((tid >> 6)) == 5)
-                    for (int i = 0; i < (a.knob >> 8); ++i) __builtin_amdgcn_s_sleep(8);
+                    for (int i = 0; i < (a.knob >> 12); ++i) __builtin_amdgcn_s_sleep(8);
                 const bool last = b + 1 >= b1 && !more;
                 // (the counters in one round of reads; every vector instruction of a thread costs a round ~ 16 cycles -- 4 waves a SIMD: low + high
                 //  of a counter is one v_dot2_u32_u16, the limits one compare of the maximum)
@@ -1031,7 +1031,9 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
                 const bool any = last || cmax > (uint32_t)(kBpCap - kScanThreads);
                 if (any)
                 for (int qs = 0; qs < nq; ++qs) {
-                    const uint32_t cw = ccnt[qs], cnt = (cw & 0xFFFFu) + (cw >> 16);       // (inside the cut nobody pushes: the word is what it is)
+                    // (a slot's count as the decision above took it: a wave that has left this loop is already pushing the next round's
+                    //  candidates -- into the high halves)
+                    const uint32_t cw = ccnt[qs], cnt = (cw & 0xFFFFu) + (more ? chi[qs] : (cw >> 16));
                     if (last || cnt > (uint32_t)(kBpCap - kScanThreads)) {
                         for (int i = tid; i < kBpCap; i += kScanThreads) sortbuf[i] = (uint32_t)i < cnt ? my_gcand[(size_t)qs * kBpCap + i] : 0ull;
                         if (last) {
