@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Generates vsearch_amd/csrc/bp_head_asm.h: one work item of a wave of the head pre-pass (bp_head.h) as ONE inline-asm statement --
 MA strip operands (16 documents each) x 8 weight operands (two query tiles each) per k-step, all k-steps, and the conversion + store
-of the sums.  Two shapes:
+of the sums (16-bit: units of 2^14 of the walk's fixed point).  Two shapes:
 
     head_item_asm       MA = 4:  64 documents x 16 tiles, 128 accumulators in VGPRs, two waves per SIMD (512-thread workgroups)
     head_item_asm_wide  MA = 8: 128 documents x 16 tiles, 256 accumulators in AGPRs, one wave per SIMD (256-thread workgroups):
@@ -130,6 +130,10 @@ def gen(MA):
         for v in regs:
             emit(f"v_mul_f32 v{v}, %[mul], v{v}")
             emit(f"v_cvt_i32_f32 v{v}, v{v}")
+        # 16-bit sums (round 6): `mul` carries the 2^-14 (a sum < 2^30 leaves below 2^16), a lane's 4 documents pack into 2 dwords
+        for m in range(MA):
+            emit(f"v_cvt_pk_u16_u32 v{regs[4 * m]}, v{regs[4 * m]}, v{regs[4 * m + 1]}")
+            emit(f"v_cvt_pk_u16_u32 v{regs[4 * m + 1]}, v{regs[4 * m + 2]}, v{regs[4 * m + 3]}")
         emit("s_mov_b64 %[sv], exec")
         for half in (0, 1):
             if half:
@@ -140,7 +144,7 @@ def gen(MA):
             emit(f"s_mov_b32 exec_hi, {mask}")
             for m in range(MA):
                 if "nostore" not in VARIANT:
-                    emit(f"global_store_dwordx4 %[so], {r4(regs[4 * m])}, %[osg]" + (f" offset:{512 * m}" if m else ""))
+                    emit(f"global_store_dwordx2 %[so], v[{regs[4 * m]}:{regs[4 * m] + 1}], %[osg]" + (f" offset:{256 * m}" if m else ""))
             emit("s_mov_b64 exec, %[sv]")                 # (restored before every branch out of the epilogue)
             emit("s_add_u32 %[osg0], %[osg0], %[os0]")
             emit("s_addc_u32 %[osg1], %[osg1], %[os1]")
@@ -163,7 +167,7 @@ def func(name, MA, what):
     return f'''// {what}
 // strip operands from `abase` (+ lane * 16; k-steps `astep` bytes apart), weight operands from `bbase` + boff[t] (k-steps 1 KB apart;
 // operand t = tiles 2 t, 2 t + 1), `ks` k-steps; the sums of the first `n_store` tiles go to `obase` + `so` (per lane), tiles
-// `ostride` bytes apart, the document groups 512 bytes apart.  All addresses wave-uniform except boff / l16 / so.
+// `ostride` bytes apart, the document groups 256 bytes apart (uint16 sums: head_mul carries the 2^-14).  All addresses wave-uniform except boff / l16 / so.
 __device__ __forceinline__ void {name}(unsigned long long abase, unsigned long long bbase, uint32_t astep, const uint32_t (&boff)[8], uint32_t l16, uint32_t ks,
                                               unsigned long long obase, unsigned long long ostride, uint32_t so, uint32_t n_store, float head_mul) {{
     // (the 64-bit bases are copied into named SGPR pairs inside the statement: s[92:93], s[94:95], s[96:97])

@@ -9,7 +9,8 @@
 //
 // So the dense part moves out: head_gemm_kernel reads every strip operand ONCE per pass for TW x 8 tiles (64 tiles = 512 queries at
 // TW = 8) and writes the sums -- int32 fixed-point units, exactly what the walk's accumulators hold -- to a scratch array in HBM
-// (64 KB per (tile, block)); the walk's epilogue adds them to its list sums (bp_walk_topk<.., HD = 2>).  The strip is no longer
+// (32 KB per (tile, block): 16-bit, in units of 2^14 -- a sum below 2^30 fits, and the truncation is one more term of the proof's slack:
+// round 6 halved the scratch's HBM round trip this way); the walk's epilogue adds them to its list sums (bp_walk_topk<.., HD = 2>).  The strip is no longer
 // bound by a CU's L1, so the head can be wider: columns present in >= 1/8 of the documents, up to 1024 of them (a list of density p
 // costs ~ 4 800 p^2 clocks per block and tile against ~ 30 per head column here), which halves what is left for the lists.
 //
@@ -28,7 +29,7 @@ namespace vs {
 struct HeadArgs {
     const __half* strip;          // [block][k-step][document / 16][64 lanes] x 8 halves (bp_strip_index)
     uint4* wt;                    // [tile - tile0][k-step][64 lanes] x 8 halves: the tiles' weights as MFMA B operands
-    int32_t* out;                 // [tile - tile0][block][document / 16][slot 8][16 documents] int32
+    uint16_t* out;                // [tile - tile0][block][document / 16][slot 8][16 documents] uint16: the dense sums in units of 2^14 (kHeadOutShift) of the walk's fixed point
     const int2* tiles;            // (first query, queries) of every tile
     const int32_t* n_tiles_dev;   // tile count of the batch (device)
     int32_t tile0, tile_cnt;      // this pass: tiles [tile0, tile0 + tile_cnt)
@@ -113,8 +114,8 @@ __global__ __launch_bounds__(WD * WT * 64) void head_gemm_kernel(HeadArgs a) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) boff[t] = (uint32_t)min(t, (nt - 1 - t0) >> 1) * (uint32_t)ks * 1024u + l16;
         const unsigned long long obase = (unsigned long long)(a.out + head_out_index(t0, a.n_blocks, b, a.rows, d0, 0));
-        const unsigned long long ostride = (unsigned long long)a.n_blocks * (unsigned long long)mbk * 512ull;      // bytes between the tiles of a (block, document group)
-        const uint32_t so = (uint32_t)(lane & 7) * 64u + (uint32_t)(lane >> 4) * 16u;                             // slot row + the lane's 4 documents
+        const unsigned long long ostride = (unsigned long long)a.n_blocks * (unsigned long long)mbk * 256ull;      // bytes between the tiles of a (block, document group)
+        const uint32_t so = (uint32_t)(lane & 7) * 32u + (uint32_t)(lane >> 4) * 8u;                              // slot row + the lane's 4 documents (2 bytes each)
         if constexpr (WIDE != 0) head_item_asm_wide(abase, bbase, (uint32_t)mbk * 1024u, boff, l16, (uint32_t)ks, obase, ostride, so, (uint32_t)min(TW, nt - t0), a.head_mul);
         else head_item_asm(abase, bbase, (uint32_t)mbk * 1024u, boff, l16, (uint32_t)ks, obase, ostride, so, (uint32_t)min(TW, nt - t0), a.head_mul);
     }

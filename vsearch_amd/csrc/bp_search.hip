@@ -442,10 +442,12 @@ int csr_prepare_impl(vs_index* idx, hipStream_t s) {
 //   strip values below the fp16 normal range (taken as flushed): value < 2^-14, weights sum < 2^30 / max -> 2^16 / max value
 //   fp32 accumulation: 33 additions per k-step of 32 columns, each off by <= one ulp of a sum < 2^30     -> 33 * 128 per k-step
 //   the lo column's own sums are 2^-11 of that; two truncations                                          -> 64 + 2
+//   head pre-pass: the sums handed to the walk as uint16 in units of 2^14 (truncated)                    -> 2^14
 int32_t bp_head_slack(const vs_index* idx) {
     if (idx->bp_n_head <= 0) return 0;
     const int hp = bp_head_pad(idx->bp_n_head);
-    return 256 + 4 * hp + (int32_t)ceilf(65536.f / idx->bp_vmax_f) + 33 * 128 * (hp / 32) + 66;
+    // (head pre-pass: its sums reach the walk truncated to units of 2^kHeadOutShift)
+    return 256 + 4 * hp + (int32_t)ceilf(65536.f / idx->bp_vmax_f) + 33 * 128 * (hp / 32) + 66 + (idx->bp_head_gemm ? (1 << kHeadOutShift) : 0);
 }
 
 // chunks of the postings walk for `n_tiles` query tiles (see bp_filter_search)
@@ -566,7 +568,7 @@ int bp_filter_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64
     int tiles_per_pass = 0, n_pass = 1;
     const int head_ks = bp_head_pad(idx->bp_n_head) / 32;
     if (head_gemm) {
-        const size_t per_tile = (size_t)n_blocks * (size_t)idx->bp_rows * 8 * 4;
+        const size_t per_tile = (size_t)n_blocks * (size_t)idx->bp_rows * 8 * 2;             // uint16 sums (bp_head.h)
         size_t free_b = 0, total_b = 0;
         VS_HIP(hipMemGetInfo(&free_b, &total_b));
         // ONE scratch per device, shared by every index on it (per index and sized from "what is free" the first search on a
@@ -665,7 +667,7 @@ int bp_filter_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64
             HeadArgs h{};
             h.strip = a.strip;
             h.wt = device_scratch(idx->device, kScratchHeadW).as<uint4>();
-            h.out = device_scratch(idx->device, kScratchHeadOut).as<int32_t>();
+            h.out = device_scratch(idx->device, kScratchHeadOut).as<uint16_t>();
             h.tiles = tiles;
             h.n_tiles_dev = a.n_tiles_dev;
             h.tile0 = pass * tiles_per_pass;
@@ -676,7 +678,7 @@ int bp_filter_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64
             h.rows = idx->bp_rows;
             h.n_rows = idx->n_rows;
             h.n_blocks = n_blocks;
-            h.head_pre = a.head_pre; h.head_mul = a.head_mul;
+            h.head_pre = a.head_pre; h.head_mul = ldexpf(a.head_mul, -kHeadOutShift);      // (the product leaves its sums in units of 2^14)
             a.head_out = h.out;
             a.tile0 = h.tile0;
             a.tile_cnt = tiles_per_pass;

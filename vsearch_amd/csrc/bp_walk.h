@@ -129,6 +129,7 @@ __global__ __launch_bounds__(kScanThreads) void bp_count_kernel(const uint32_t* 
 // ~95 clocks per head column (the strip streams from L2 at ~26 TB/s chip-wide) against 4 800 p^2 for a list of density p, so
 // the lists win below p ~ 1/7; the default threshold is 1/4.  hmap[c] = strip index of column c, 0xFFFF = ordinary column.
 constexpr int kBpHeadCap = 512;          // multiplied inside the walk (their weights live in its LDS)
+constexpr int kHeadOutShift = 14;        // the head pre-pass hands its sums over as uint16 in units of 2^14 (a sum < 2^30 fits; < 2^14 units lost: bp_head_slack)
 constexpr int kBpHeadCapGemm = 1024;     // served by the head pre-pass (bp_head.h)
 // One workgroup.  Deterministic: when more than `cap` columns reach `thresh`, the threshold rises to the smallest document
 // count that leaves at most `cap` of them; strip indexes follow column order.
@@ -441,7 +442,7 @@ struct BpArgs {
     const __half* strip;      // fp16 values of the head columns, MFMA operand order (bp_strip_index)
     int32_t n_head;
     float head_pre, head_mul; // powers of two: weights enter the fp16 operand as w * scale * head_pre (< 2^15), the sums leave as C * head_mul
-    const int32_t* head_out;  // HD = 2 (head pre-pass, bp_head.h): the dense part of the sums, [tile - tile0][block][document / 16][slot][16] int32
+    const uint16_t* head_out; // HD = 2 (head pre-pass, bp_head.h): the dense part of the sums, [tile - tile0][block][document / 16][slot][16] uint16 in units of 2^kHeadOutShift
     int32_t tile0, tile_cnt;  // tile_cnt > 0: this launch walks tiles [tile0, tile0 + tile_cnt) only (the passes of the head pre-pass)
     uint32_t* pace;           // optional [nchunk][blocks_per_chunk], zeroed per search: work items that have finished a block (flat walk: lock-step window)
     int32_t pace_window;      // blocks an item may run ahead of the slowest item of its chunk
@@ -956,6 +957,7 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
             lap(2);
             lap(3);
             // epilogue: 1024 documents at a time, one per thread: its QT sums -> order keys -> candidates; prune when a buffer could overflow
+            [[maybe_unused]] uint32_t nx0 = 0u, nx4 = 0u;                 // (HD = 2: the head sums' lines of the second round, asked for in the first)
             for (int d0 = 0; d0 < rows_b || d0 == 0; d0 += kScanThreads) {
                 const int d = d0 + tid;
                 const bool more = d0 + kScanThreads < rows_b;         // another round of this block follows
@@ -974,9 +976,37 @@ __global__ __launch_bounds__(kScanThreads) void bp_walk_topk(BpArgs a) {
                         // (tried and dropped, 21 M docs: the same loads issued BEFORE the block's barrier, or for both of the thread's
                         //  documents at once right behind it -- the walk went from 126 ms to 161 - 186, the waves' wait at the barrier
                         //  from 6 k to 22 - 26 k cycles a block: docs/EXPERIMENTS.md)
-                        const int32_t* hp = a.head_out + head_out_offset((int64_t)tile_rel, n_blocks, b, a.rows, d);
+                        // (uint16 sums read as the DWORD that holds the document and its neighbour: 2-byte loads took the epilogue from 8.5 k to
+                        //  13.9 k cycles a block)
+                        const uint32_t* hp = reinterpret_cast<const uint32_t*>(a.head_out + head_out_offset((int64_t)tile_rel, n_blocks, b, a.rows, d & ~1));
+                        const uint32_t sh = (uint32_t)(d & 1) * 16u;
+                        // (a 16-document group's sums are two cache lines, slots 0 - 3 and 4 - 7: four loads in flight to ONE missing line wait for
+                        //  each other in the L1 -- the lines are asked for once each, the other six loads hit behind them)
+                        uint32_t hw[QT];
 #pragma unroll
-                        for (int q = 0; q < QT; ++q) pre[q] = (q < nq && !(a.knob & 256)) ? hp[q * 16] : 0;          // (VS_BP_KNOB=256: ablation, WRONG results -- what the scratch reads cost)
+                        for (int q = 0; q < QT; ++q) hw[q] = 0u;
+                        if (!(a.knob & 256)) {                                  // (VS_BP_KNOB=256: ablation, WRONG results -- what the scratch reads cost)
+                            if (d0 == 0) {
+                                hw[0] = hp[0];
+                                if constexpr (QT > 4) hw[4] = hp[32];
+                                // ... and the two lines of the thread's SECOND document (the block's next round), asked for with them: four
+                                // different lines, in flight together (one wait); the next round finds them in its registers
+                                if (more && d + kScanThreads < rows_b) {
+                                    const uint32_t* hn = reinterpret_cast<const uint32_t*>(a.head_out + head_out_offset((int64_t)tile_rel, n_blocks, b, a.rows, (d + kScanThreads) & ~1));
+                                    nx0 = hn[0];
+                                    if constexpr (QT > 4) nx4 = hn[32];
+                                }
+                                asm volatile("s_waitcnt vmcnt(0)" : "+v"(hw[0]), "+v"(hw[QT > 4 ? 4 : 0]), "+v"(nx0), "+v"(nx4) :: "memory");
+                            } else {
+                                hw[0] = nx0;
+                                if constexpr (QT > 4) hw[4] = nx4;
+                            }
+#pragma unroll
+                            for (int q = 1; q < QT; ++q)
+                                if (q != 4) hw[q] = hp[q * 8];
+                        }
+#pragma unroll
+                        for (int q = 0; q < QT; ++q) pre[q] = q < nq ? (int32_t)(((hw[q] >> sh) & 0xFFFFu) << kHeadOutShift) : 0;
                     }
 #pragma unroll
                     for (int q = 0; q < QT; ++q) sums[q] = pa[q];         // independent reads, in flight together
