@@ -365,10 +365,11 @@ def test_eight_rank_bench_launch_on_one_gpu_equals_the_unsharded_search(tmp_path
 
 @pytest.mark.parametrize("kind", ["plain", "bot", "zipf"])
 def test_four_processes_sharing_the_gpu_keep_their_results(kind):
-    """Four processes on the one GPU, 120 searches each, every result against the CSR scan (tools/contention_check.py): oversubscribed
-    queues start a kernel's workgroups far apart and context-switch its waves -- the run that exposed a quad walk which lost whole blocks
-    of candidates in 10 - 25 % of the searches while every single-process test passed (round 5).  The quad chunks, the bag-of-token
-    chunks and the head pre-pass + list walk."""
+    """Four processes on the one GPU, 120 searches each, every result against the CSR scan (tools/contention_check.py): other processes'
+    waves on a CU stretch the timing windows inside a workgroup -- the run that exposed a quad walk which lost whole blocks of candidates
+    in 10 - 25 % of the searches while every single-process test passed (round 5; root cause, round 6: the epilogue's cut decision read
+    per thread from counters the next round was already pushing to -- test_a_late_wave_does_not_split_the_cut_decision forces that window
+    in a single process).  The quad chunks, the bag-of-token chunks and the head pre-pass + list walk."""
     import os, subprocess, sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(repo, "tools", "contention_check.py"), "4", "120", kind], capture_output=True, text=True, timeout=900)

@@ -1,9 +1,10 @@
 """N processes sharing ONE GPU, each searching its own synthetic shard over and over: every filter + refine result against the CSR scan of
 the same index.  python tools/contention_check.py [processes] [searches] [plain|bot|zipf]
 
-Why: with four or more processes the GPU's queues are oversubscribed and a kernel's workgroups start far apart in time (and waves are
-context-switched); round 5 had a version of the quad walk that passed every single-process test and lost whole blocks of candidates in
-10 - 25 % of the searches here (docs/EXPERIMENTS.md, round 5, "a base held in a VGPR across the walk").  tests/test_gpu_search.py runs it."""
+Why: with four or more processes other kernels' waves share the CUs and stretch the timing windows inside a workgroup; round 5 had a
+version of the quad walk that passed every single-process test and lost whole blocks of candidates in 10 - 25 % of the searches here
+(root cause, round 6: a per-thread cut decision in the walks' epilogue -- docs/EXPERIMENTS.md, profiles/r06_prune_decision_race.txt).
+tests/test_gpu_search.py runs it."""
 import os, subprocess, sys
 import numpy as np
 repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -385,17 +385,25 @@ __global__ __launch_bounds__(kScanThreads) void bp_quad_topk(BpArgs a) {
             lds_barrier();                                               // the block's sums are complete
             lap(2);
             // epilogue: 1024 documents at a time, one per thread: its QT sums -> order keys -> candidates; prune when a buffer could overflow
+            int32_t thr[QT];
+            bool thr_stale = true;
             for (int d0 = 0; d0 < rows_b || d0 == 0; d0 += kScanThreads) {
                 const int d = d0 + tid;
                 const bool more = d0 + kScanThreads < rows_b;             // another round of this block follows
                 const uint32_t inc = more ? 1u : 0x10000u;
                 // (LDS instructions are what the epilogue costs -- 16 waves x 2 rounds a block: the 8 threshold halves in four 16-byte reads,
                 //  a document's 8 sums read AND zeroed by four ds_wrxchg2_rtn_b32, the 8 counters below in two 16-byte reads: 10 instead of 32)
-                uint32_t thi[QT];
-                {
+                // (the thresholds' score halves as SIGNED numbers a sum compares with directly, kept across the block's rounds: they change
+                //  only in a cut -- a vector instruction costs a round ~ 16 cycles, and this was 16 of them and four LDS reads a round)
+                if (d0 == 0 || thr_stale) {
                     const uint4* t4 = reinterpret_cast<const uint4*>(tau);
 #pragma unroll
-                    for (int i = 0; i < QT / 2; ++i) { const uint4 t = t4[i]; thi[2 * i] = t.y; thi[2 * i + 1] = t.w; }
+                    for (int i = 0; i < QT / 2; ++i) {
+                        const uint4 t = t4[i];
+                        thr[2 * i] = 2 * i < nq ? (int32_t)(t.y ^ 0x80000000u) : 0x7FFFFFFF;          // (a slot without a query: no sum reaches it)
+                        thr[2 * i + 1] = 2 * i + 1 < nq ? (int32_t)(t.w ^ 0x80000000u) : 0x7FFFFFFF;
+                    }
+                    thr_stale = false;
                 }
                 if (d < rows_b) {
                     const int64_t row = b * a.rows + d;
@@ -428,8 +436,8 @@ __global__ __launch_bounds__(kScanThreads) void bp_quad_topk(BpArgs a) {
 #endif
 #pragma unroll
                     for (int q = 0; q < QT; ++q) {
-                        const uint32_t hi = (uint32_t)sums[q] ^ 0x80000000u;
-                        if (q < nq && hi >= thi[q]) {
+                        if (sums[q] >= thr[q]) {
+                            const uint32_t hi = (uint32_t)sums[q] ^ 0x80000000u;
                             const uint64_t key = ((uint64_t)hi << 32) | (uint32_t)(~(uint32_t)row);
                             if (key > tau[q] && key < upper_sh[q]) {
                                 const uint32_t old = atomicAdd(&ccnt[q], inc);                 // (low half: first rounds, high half: last rounds -- below)
@@ -479,6 +487,7 @@ __global__ __launch_bounds__(kScanThreads) void bp_quad_topk(BpArgs a) {
                 [[maybe_unused]] long long t_cut = 0;
                 if constexpr (TM != 0) t_cut = (long long)__builtin_readcyclecounter();
                 if (any) __syncthreads();                               // the candidates stored above become visible to the workgroup
+                thr_stale = any;                                        // (a cut raises thresholds)
                 if (any)
                 for (int qs = 0; qs < nq; ++qs) {
                     // (a slot's count as the decision above took it: a wave that has left this loop is already pushing the next round's
