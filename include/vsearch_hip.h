@@ -287,7 +287,8 @@ VS_API int vs_embed_mask(float* emb, int64_t ld, const int64_t* ids, int32_t B, 
 /* The mask stage of VDREncoder.embed FUSED with Tensor.to_sparse_csr() (vdr.py:152-169 + retriever.py:304; SURVEY.md 8(f1) "write CSR
  * rows directly"): x [B, V] fp32 (device; NOT modified) -> the CSR of x * (topk_mask | lexical_mask): int64 rowptr [B + 1], int32 cols /
  * fp32 vals [cap] (device; cap >= B * (topk + L) always suffices; nnz = rowptr[B]).  One read of [B, V] instead of the five passes of
- * vs_embed_mask + vs_dense_to_csr.  VS_EUNSUPPORTED outside the fast mask kernel's range (topk <= 0, V > 32 Ki): use those two.     */
+ * vs_embed_mask + vs_dense_to_csr.  VS_EUNSUPPORTED outside the fused kernel's range (topk <= 0, V > 32 Ki, topk + L > 8192): use
+ * those two.                                                                                      */
 VS_API int vs_embed_mask_to_csr(const float* x, int64_t ld, const int64_t* ids, int32_t B, int32_t L, int32_t vocab, int32_t shift,
                                 int32_t topk, int activate_lexical, int64_t* rowptr, int32_t* cols, float* vals, int64_t cap,
                                 int device, void* stream);

@@ -531,6 +531,30 @@ def test_embed_mask_to_csr_equals_mask_then_to_sparse_csr(topk, lexical):
     assert (rp == r_rp).all() and (ci == r_ci).all() and (va.view(torch.int32) == r_va.view(torch.int32)).all()
     with pytest.raises(NotImplementedError):
         sp.embed_mask_to_csr(emb, ids, VOCAB, SHIFT, 0, True)
+    with pytest.raises(NotImplementedError):                          # more kept elements a row than the fused kernel stages: the two-call path serves those
+        sp.embed_mask_to_csr(emb, ids, VOCAB, SHIFT, 8192, True)
+
+
+@pytest.mark.parametrize("B,topk,lexical", [(600, 768, True), (257, 64, False), (1500, 8000, True)])
+def test_embed_mask_to_csr_many_rows_per_workgroup(B, topk, lexical):
+    """The fused kernel gives every workgroup a run of consecutive rows (uneven when B is not a multiple of the CU count), ranks a row's
+    kept elements with wave scans and moves the workgroup's run to its place once the workgroups before it have published their totals:
+    row pointers, columns and value bits equal mask-then-to_sparse_csr on batches of 1 .. 6 rows a workgroup, with zero rows, ties and
+    lexical columns whose value is zero in the middle of a run."""
+    g = torch.Generator().manual_seed(B)
+    L = 40
+    emb = torch.rand((B, V), generator=g) * 3
+    emb[B // 2] = 0.0
+    emb[B // 3, ::5] = 2.0
+    emb[B - 1, 1000:] = 0.0
+    emb[7, ::2] = 0.0
+    emb = emb.cuda()
+    ids = torch.randint(SHIFT, VOCAB, (B, L), generator=g).cuda()
+    rp, ci, va = sp.embed_mask_to_csr(emb, ids, VOCAB, SHIFT, topk, lexical)
+    ref = emb.clone()
+    sp.apply_embed_mask_(ref, ids if lexical else None, VOCAB, SHIFT, topk, lexical)
+    r_rp, r_ci, r_va = sp.dense_to_csr(ref)
+    assert (rp == r_rp).all() and (ci == r_ci).all() and (va.view(torch.int32) == r_va.view(torch.int32)).all()
 
 
 def test_encoder_embed_csr_equals_embed_then_to_sparse_csr(tiny_retriever):

@@ -78,6 +78,12 @@ struct MaskArgs {
     int32_t* slot_cols;
     float* slot_vals;
     int32_t slot_cap;
+    // ... and the CSR arrays the workgroups' runs end up in (the kernel's last step): rowptr [B + 1], cols / vals [csr_cap]; behind
+    // `flags`: flags[1] = the workgroup ticket, 8-byte words 32 ..: the workgroups' totals -- zeroed by the host before the launch
+    int64_t* csr_rowptr;
+    int32_t* csr_cols;
+    float* csr_vals;
+    int64_t csr_cap;
 };
 
 // block-wide sum of one 64-bit value per thread (kSpThreads threads); red: kSpThreads / 64 slots in LDS
@@ -229,10 +235,10 @@ int run_mask(MaskArgs a, const float* x_in, float* emb_io, const int64_t* ids, u
     if (lds > 160 * 1024) return fail(VS_EUNSUPPORTED, "V = %d needs %zu B of LDS (> 160 KiB)", a.V, lds);
     DevBuf st_x, st_ids, st_mask;
     DevBuf& flags = device_scratch(device, kScratchFlags);
-    VS_TRY(flags.reserve(128));
+    VS_TRY(flags.reserve(256));
     if (ids) VS_HIP(hipMemsetAsync(flags.p, 0, 4, s));
 #ifdef MR_TIMING
-    VS_HIP(hipMemsetAsync(flags.p, 0, 128, s));
+    VS_HIP(hipMemsetAsync(flags.p, 0, 256, s));
 #endif
     a.flags = flags.as<int>();
     const size_t row_span = a.B > 0 ? ((size_t)(a.B - 1) * a.ld + a.V) * 4 : 0;
@@ -257,7 +263,7 @@ int run_mask(MaskArgs a, const float* x_in, float* emb_io, const int64_t* ids, u
     ProfScope prof("mask_rows", s);
     if (!a.bow && a.topk > 0 && a.x && a.V <= kMrCols) {
         // the encoder's case (mask_rows_fast.h): persistent workgroups, the next row's loads in flight through a row's select
-        void (*kern)(MaskArgs) = a.V <= 4 * kMrStep ? mask_rows_fast_kernel<4> : a.V <= 8 * kMrStep ? mask_rows_fast_kernel<8> : mask_rows_fast_kernel<16>;
+        void (*kern)(MaskArgs) = a.V <= 4 * kMrStep ? mask_rows_fast_kernel<4> : a.V <= 8 * kMrStep ? mask_rows_fast_kernel<8> : a.V <= 15 * kMrStep ? mask_rows_fast_kernel<15> : mask_rows_fast_kernel<16>;
         int cus = 0;
         VS_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
         VS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mask_fast_lds_bytes()));
@@ -269,14 +275,14 @@ int run_mask(MaskArgs a, const float* x_in, float* emb_io, const int64_t* ids, u
     VS_HIP(hipGetLastError());
 #ifdef MR_TIMING
     {
-        unsigned long long h[16];
-        VS_HIP(hipMemcpyAsync(h, flags.p, 128, hipMemcpyDeviceToHost, s));
+        unsigned long long h[32];
+        VS_HIP(hipMemcpyAsync(h, flags.p, 256, hipMemcpyDeviceToHost, s));
         VS_HIP(hipStreamSynchronize(s));
         static int calls = 0;
         if (++calls == 5) {
             const double rows = (double)a.B;
-            fprintf(stderr, "[vsearch_hip] mask stage, cycles per row (wave 0): barrier+wait %.0f, pack %.0f, issue+clear+lex %.0f, pass A %.0f, pick A %.0f, pass B + pick B %.0f, candidates %.0f, write %.0f\n",
-                    h[1] / rows, h[2] / rows, h[3] / rows, h[4] / rows, h[5] / rows, h[6] / rows, h[7] / rows, h[8] / rows);
+            fprintf(stderr, "[vsearch_hip] mask stage, cycles per row (wave 0): barrier+wait %.0f, pack %.0f, issue+clear+lex %.0f, pass A %.0f, pick A %.0f, pass B + pick B %.0f, masks %.0f, candidates %.0f (list %.0f, barrier %.0f, ranking %.0f, barrier %.0f), write %.0f\n",
+                    h[1] / rows, h[2] / rows, h[3] / rows, h[4] / rows, h[5] / rows, h[6] / rows, h[7] / rows, h[8] / rows, h[12] / rows, h[13] / rows, h[14] / rows, h[15] / rows, h[9] / rows);
         }
     }
 #endif
@@ -474,29 +480,12 @@ extern "C" int vs_embed_mask(float* emb, int64_t ld, const int64_t* ids, int32_t
     return run_mask(a, nullptr, emb, ids, nullptr, device, (hipStream_t)stream);
 }
 
-namespace {
-// the slot runs of vs_embed_mask_to_csr -> the CSR arrays: one workgroup per row, coalesced copies
-template <int UNUSED>
-__global__ __launch_bounds__(256) void slots_compact_kernel(const int64_t* rowptr, const int32_t* slot_cols, const float* slot_vals, int32_t slot_cap, int32_t B,
-                                                            int32_t* cols, float* vals, int64_t cap, int* flags) {
-    for (int b = blockIdx.x; b < B; b += gridDim.x) {
-        const int64_t p0 = rowptr[b];
-        const int n = (int)min((int64_t)slot_cap, rowptr[b + 1] - p0);
-        if (p0 + n > cap) { if (threadIdx.x == 0) atomicOr(flags, 4); continue; }
-        for (int i = threadIdx.x; i < n; i += 256) {
-            cols[p0 + i] = slot_cols[(size_t)b * slot_cap + i];
-            vals[p0 + i] = slot_vals[(size_t)b * slot_cap + i];
-        }
-    }
-}
-}  // namespace
-
 // VDREncoder.embed's mask stage FUSED with Tensor.to_sparse_csr() (vdr.py:152-169 + retriever.py:304; SURVEY 8(f1) "write CSR rows
 // directly"): x [B, V] (the pooled activations, NOT modified) -> the CSR of  x * (topk_mask | lexical_mask).  The mask kernel ranks the
 // kept elements while it still holds the row in registers and writes (column, value) pairs; the dense masked row is never written nor
 // read back: one read of [B, V] instead of the five passes of vs_embed_mask + vs_dense_to_csr.
 //   rowptr int64 [B + 1] (device), cols int32 / vals fp32 [cap] (device), cap >= B * (topk + L) suffices; nnz = rowptr[B].
-//   VS_EUNSUPPORTED: outside the fast mask kernel's range (bow, topk <= 0, V > 32 Ki) -- use vs_embed_mask + vs_dense_to_csr.
+//   VS_EUNSUPPORTED: outside the fast mask kernel's range (bow, topk <= 0, V > 32 Ki, topk + L > 8192) -- use vs_embed_mask + vs_dense_to_csr.
 extern "C" int vs_embed_mask_to_csr(const float* x, int64_t ld, const int64_t* ids, int32_t B, int32_t L, int32_t vocab, int32_t shift, int32_t topk,
                                     int activate_lexical, int64_t* rowptr, int32_t* cols, float* vals, int64_t cap, int device, void* stream) {
     if (!x || !rowptr || !cols || !vals || B <= 0 || vocab <= 0 || shift < 0 || shift >= vocab || ld < vocab - shift || cap < 0) return fail(VS_EINVAL, "bad argument");
@@ -509,13 +498,18 @@ extern "C" int vs_embed_mask_to_csr(const float* x, int64_t ld, const int64_t* i
     VS_TRY(check_device(device));
     hipStream_t s = (hipStream_t)stream;
     const int32_t slot_cap = (int32_t)std::min<int64_t>(V, (int64_t)topk + (activate_lexical ? L : 0));
+    if (slot_cap > kMrStage) return fail(VS_EUNSUPPORTED, "vs_embed_mask_to_csr serves rows of topk + L <= %d kept elements", kMrStage);
     DevBuf& flags = device_scratch(device, kScratchFlags);
     DevBuf& counts = device_scratch(device, kScratchCounts);
     DevBuf& slots = device_scratch(device, kScratchCsrSlots);
-    VS_TRY(flags.reserve(128));
+    int cus = 0;
+    VS_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+    const int grid = std::max(1, std::min(B, cus));
+    const size_t flag_bytes = 256 + (size_t)grid * 8 * 5;                    // (+ developer builds: four clock readings per workgroup)                        // error bits, ticket | (developer builds: phase clocks) | the workgroups' totals
+    VS_TRY(flags.reserve(flag_bytes));
     VS_TRY(counts.reserve((size_t)B * 8));
     VS_TRY(slots.reserve((size_t)B * slot_cap * 8));
-    VS_HIP(hipMemsetAsync(flags.p, 0, 4, s));
+    VS_HIP(hipMemsetAsync(flags.p, 0, flag_bytes, s));
     MaskArgs a{};
     a.x = x; a.emb = nullptr; a.ld = ld; a.ids = activate_lexical ? ids : nullptr;
     a.V = V; a.B = B; a.L = L; a.vocab = vocab; a.shift = shift; a.topk = topk; a.activate_lexical = activate_lexical; a.bow = 0;
@@ -524,18 +518,42 @@ extern "C" int vs_embed_mask_to_csr(const float* x, int64_t ld, const int64_t* i
     a.slot_cols = slots.as<int32_t>();
     a.slot_vals = reinterpret_cast<float*>(slots.as<int32_t>() + (size_t)B * slot_cap);
     a.slot_cap = slot_cap;
+    a.csr_rowptr = rowptr; a.csr_cols = cols; a.csr_vals = vals; a.csr_cap = cap;
     {
+        // ONE launch: select, rank, emit, and -- once the workgroups before it have published their totals -- every workgroup moves its run
+        // to its place in cols / vals and writes its rows' rowptr entries (mask_rows_fast.h step 5)
         ProfScope prof("mask_to_csr", s);
-        void (*kern)(MaskArgs) = V <= 4 * kMrStep ? mask_rows_fast_kernel<4, 1> : V <= 8 * kMrStep ? mask_rows_fast_kernel<8, 1> : mask_rows_fast_kernel<16, 1>;
-        int cus = 0;
-        VS_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+        void (*kern)(MaskArgs) = V <= 4 * kMrStep ? mask_rows_fast_kernel<4, 1> : V <= 8 * kMrStep ? mask_rows_fast_kernel<8, 1> : V <= 15 * kMrStep ? mask_rows_fast_kernel<15, 1> : mask_rows_fast_kernel<16, 1>;
         VS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mask_fast_lds_bytes()));
-        hipLaunchKernelGGL(kern, dim3(std::max(1, std::min(B, cus))), dim3(kMrThreads), mask_fast_lds_bytes(), s, a);
-        hipLaunchKernelGGL(scan_counts_kernel<0>, dim3(1), dim3(kSpThreads), 0, s, counts.as<int64_t>(), B, rowptr);
-        hipLaunchKernelGGL(slots_compact_kernel<0>, dim3(std::min(B, 4096)), dim3(256), 0, s, (const int64_t*)rowptr, (const int32_t*)a.slot_cols, (const float*)a.slot_vals, slot_cap, B,
-                           cols, vals, cap, flags.as<int>());
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kMrThreads), mask_fast_lds_bytes(), s, a);
         VS_HIP(hipGetLastError());
     }
+#ifdef MR_TIMING
+    {
+        unsigned long long h[32];
+        VS_HIP(hipMemcpyAsync(h, flags.p, 256, hipMemcpyDeviceToHost, s));
+        VS_HIP(hipStreamSynchronize(s));
+        static int calls = 0;
+        if (++calls == 5) {
+            const double rows = (double)B;
+            std::vector<unsigned long long> rt((size_t)grid * 4);
+            VS_HIP(hipMemcpy(rt.data(), (const char*)flags.p + 256 + (size_t)grid * 8, rt.size() * 8, hipMemcpyDeviceToHost));
+            unsigned long long t0 = ~0ull;
+            for (int i = 0; i < grid; ++i) t0 = std::min(t0, rt[4 * i]);
+            std::vector<double> st, rd, en, pf;
+            for (int i = 0; i < grid; ++i) { st.push_back((rt[4 * i] - t0) / 100.0); rd.push_back((rt[4 * i + 1] - t0) / 100.0); en.push_back((rt[4 * i + 2] - t0) / 100.0); pf.push_back((rt[4 * i + 3] - t0) / 100.0); }
+            auto pct = [](std::vector<double> v, double q) { std::sort(v.begin(), v.end()); return v[(size_t)(q * (v.size() - 1))]; };
+            fprintf(stderr, "[vsearch_hip] mask -> CSR workgroups (us after the first start): start median %.1f max %.1f; rows done min %.1f median %.1f max %.1f; prefix known min %.1f median %.1f max %.1f; end min %.1f median %.1f max %.1f\n",
+                    pct(st, 0.5), pct(st, 1.0), pct(rd, 0.0), pct(rd, 0.5), pct(rd, 1.0), pct(pf, 0.0), pct(pf, 0.5), pct(pf, 1.0), pct(en, 0.0), pct(en, 0.5), pct(en, 1.0));
+            fprintf(stderr, "[vsearch_hip] mask -> CSR workgroups by ticket (rows done / prefix known / end):");
+            for (int i = 0; i < grid; i += std::max(1, grid / 16)) fprintf(stderr, " %d: %.1f %.1f %.1f;", i, rd[i], pf[i], en[i]);
+            fprintf(stderr, " %d: %.1f %.1f %.1f\n", grid - 1, rd[grid - 1], pf[grid - 1], en[grid - 1]);
+            fprintf(stderr, "[vsearch_hip] mask -> CSR, cycles per row (wave 0): barrier+wait %.0f, pack %.0f, issue+clear+lex %.0f, pass A %.0f, pick A %.0f, pass B + pick B %.0f, masks %.0f, "
+                    "candidates %.0f (list %.0f, barrier %.0f, ranking %.0f, barrier %.0f), totals %.0f, rank + stage %.0f, copy out %.0f; per workgroup: its place in the CSR arrays %.0f, kernel %.0f cycles\n", h[1] / rows, h[2] / rows, h[3] / rows, h[4] / rows, h[5] / rows, h[6] / rows, h[7] / rows, h[8] / rows,
+                    h[12] / rows, h[13] / rows, h[14] / rows, h[15] / rows, h[9] / rows, h[10] / rows, h[11] / rows, h[16] / (double)grid, h[17] / (double)grid);
+        }
+    }
+#endif
     int hflags = 0;
     VS_HIP(hipMemcpyAsync(&hflags, flags.p, 4, hipMemcpyDeviceToHost, s));
     VS_HIP(hipStreamSynchronize(s));

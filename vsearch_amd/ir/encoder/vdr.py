@@ -149,7 +149,7 @@ class VDREncoder(PreTrainedModel):
         """Generator over the batches of `embed(texts, ...)`, each as CSR: (rowptr int64 [b+1], cols int32, vals fp32, V) CUDA tensors --
         what `embed(batch).to_sparse_csr()` holds (vdr.py:97-179 + retriever.py:304), with the mask stage and the CSR conversion fused
         in one kernel (`vs_embed_mask_to_csr`): the masked dense batch is never written.  Falls back to embed + dense_to_csr outside
-        the fused kernel's range (topk <= 0, V > 32 Ki, a non-fp32 head; `norm` needs no fallback: forward() has normalised already).
+        the fused kernel's range (topk <= 0, V > 32 Ki, topk + L > 8192, a non-fp32 head; `norm` needs no fallback: forward() has normalised already).
         One divergence from the reference, for NON-FINITE activations only: `batch_emb *= mask` (vdr.py:169) turns an unselected NaN / inf
         into NaN, which to_sparse_csr() keeps as a stored element; the fused kernel emits the SELECTED non-zero cells only, so such a cell
         is dropped here (the unfused path, x * 0, keeps it).  Finite activations: identical (tests/test_gpu_facade.py)."""
@@ -165,7 +165,8 @@ class VDREncoder(PreTrainedModel):
                 for s in range(0, len(texts), batch_size):
                     enc = self.encode(texts[s:s + batch_size], max_len=max_len)
                     emb = self(**enc).contiguous()
-                    fused = topk is not None and int(topk) > 0 and V <= 32768 and emb.dtype == torch.float32
+                    fused = (topk is not None and int(topk) > 0 and V <= 32768 and emb.dtype == torch.float32
+                             and min(V, int(topk) + (enc["input_ids"].shape[1] if activate_lexical else 0)) <= sp.FUSED_CSR_MAX_KEPT)
                     if fused:
                         rp, ci, va = sp.embed_mask_to_csr(emb, enc["input_ids"], self.config.vocab_size, self.config.shift_vocab_num, int(topk), activate_lexical)
                     else:

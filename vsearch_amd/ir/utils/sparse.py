@@ -91,11 +91,14 @@ def apply_embed_mask_(emb: torch.Tensor, input_ids, vocab_size: int, shift_num: 
     return emb
 
 
+FUSED_CSR_MAX_KEPT = 8192      # kMrStage (csrc/mask_rows_fast.h): kept elements of a row the fused kernel stages
+
+
 def embed_mask_to_csr(emb: torch.Tensor, input_ids, vocab_size: int, shift_num: int, topk: int, activate_lexical: bool):
     """The mask stage of VDREncoder.embed (vdr.py:152-169) fused with Tensor.to_sparse_csr() (retriever.py:304): pooled activations
     emb [B, V] (CUDA fp32, NOT modified) -> (rowptr int64 [B+1], cols int32 [nnz], vals fp32 [nnz]) of emb * (topk_mask | lexical_mask).
     One read of [B, V]; the masked dense batch is never written.  NotImplementedError outside the fused kernel's range (topk <= 0,
-    V > 32 Ki): callers then use apply_embed_mask_ + dense_to_csr."""
+    V > 32 Ki, topk + L > 8192): callers then use apply_embed_mask_ + dense_to_csr."""
     assert emb.is_cuda and emb.dtype == torch.float32 and emb.is_contiguous()
     dev = _dev_of(emb)
     B, V = emb.shape
@@ -104,8 +107,8 @@ def embed_mask_to_csr(emb: torch.Tensor, input_ids, vocab_size: int, shift_num: 
         ids = input_ids.detach().to(device=emb.device, dtype=torch.int64).contiguous()
         L = ids.shape[1]
     tk = -1 if topk is None else int(topk)
-    if tk <= 0 or V > 32768:
-        raise NotImplementedError("embed_mask_to_csr serves top-k masks of V <= 32 Ki columns")
+    if tk <= 0 or V > 32768 or min(V, tk + L) > FUSED_CSR_MAX_KEPT:
+        raise NotImplementedError("embed_mask_to_csr serves top-k masks of V <= 32 Ki columns and topk + L <= 8192 kept elements a row")
     cap = B * min(V, tk + L)
     rowptr = torch.empty(B + 1, dtype=torch.int64, device=emb.device)
     cols = torch.empty(max(cap, 1), dtype=torch.int32, device=emb.device)
