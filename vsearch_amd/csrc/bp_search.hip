@@ -475,15 +475,24 @@ int bp_choose_chunks(const vs_index* idx, int n_tiles, int64_t n_blocks, int pla
             if (eff >= 0.95) break;
         }
         nchunk = (int)std::min<int64_t>(best, n_blocks);
-        // Quad chunks (round 5): FOUR chunks whenever that fills the CUs, else the smallest power of two that does.  Work items go to the
-        // XCDs round robin (item % 8) and take chunk item % nchunk: with 4 chunks a block is swept by two XCDs' L2s instead of four (2
-        // chunks) -- 134.3 ms against 141.0 at 21 M docs x 1024 queries although the 512 items then run two to a CU without lock step;
-        // 8 chunks (one XCD each, four items to a CU): 144.6; a count that does not divide 8 scatters every chunk over all XCDs: 3
-        // chunks 225 ms, 5: 231, 6: 176.  B = 512: 70.5 ms (4) / 72.5 (8); B = 256: 37.9 (8) / 72.1 (4: half the CUs idle); B = 2048: 268 (4) / 292 (1).
+        // Quad chunks: a power of two (work items go to the XCDs round robin -- item % 8 -- and take chunk item % nchunk: a count that does
+        // not divide 8 scatters every chunk over all XCDs: 3 chunks 225 ms, 5: 231, 6: 176 at 21 M docs x 1024 queries), and the SMALLEST
+        // that fills the CUs: one item per CU.  Round 5 ran four chunks (two items per CU, a block swept by two XCDs' L2s instead of
+        // four: 134.3 ms against 141.0 with two) -- with round 6's epilogue (uniform cut decision, cuts by selection) the order is
+        // the other way round, in every fresh process: 21 M docs, B = 1024: 2 chunks 129.9 - 130.0 ms / 4: 134.5; B = 2048: 1 chunk
+        // 258.7 / 2: 260.0 / 4: 269.3; B = 512: 4 chunks 67.4 / 8: 73.5 (2: half the CUs idle); B = 256: 8 chunks 36.6 / 16: 43.1;
+        // 2.6 M docs (one rank's shard of an 8-GPU step), B = 1024: 2 chunks 16.73 ms / 4: 17.53 / 8: 19.45 -- every item pays its
+        // start-up (entry sort, the candidate flood until its thresholds rise, the final cuts) once (profiles/r06_chunks.txt).
         if (idx->bp_quad) {
-            int c = 4;
-            while ((int64_t)n_tiles * c < idx->cu_count && c < 64) c *= 2;
-            nchunk = (int)std::min<int64_t>(c, n_blocks);
+            int pick = 1;
+            double pick_eff = 0.0;
+            for (int c = 1; c <= 64; c *= 2) {
+                const int64_t it = (int64_t)n_tiles * c;
+                const double eff = (double)it / (double)(ceil_div64(it, idx->cu_count) * idx->cu_count);
+                if (eff > pick_eff + 1e-9) { pick_eff = eff; pick = c; }
+                if (eff >= 0.9) break;
+            }
+            nchunk = (int)std::min<int64_t>(pick, n_blocks);
         }
     }
     if (idx->bp_chunks > 0) nchunk = (int)std::min<int64_t>(idx->bp_chunks, n_blocks);
