@@ -452,6 +452,13 @@ def test_dense_head_strips_keep_the_results(store, gemm):
             ids, sc, info = _search(idx, q, 100, blocked_postings=1, postings_head=-1, postings_head_tiles=tiles)
             assert info.last_path == 3 and (ids == ref_ids).all() and (sc == ref_sc).all(), f"{tiles} tiles per pass"
         idx.set_option("postings_head_tiles", 0)
+        # both kernels of the pre-pass (the LDS ring is auto's from 32 tiles a pass on: here it is forced onto 3 tiles, 2 + 1 and single ones)
+        for product in (1, 0):
+            for tiles in (0, 2, 1):
+                ids, sc, info = _search(idx, q, 100, blocked_postings=1, postings_head=-1, postings_head_product=product, postings_head_tiles=tiles)
+                assert info.last_path == 3 and (ids == ref_ids).all() and (sc == ref_sc).all(), f"head product {product}, {tiles} tiles per pass"
+        idx.set_option("postings_head_tiles", 0)
+        idx.set_option("postings_head_product", -1)
     _, _, allsc = oracle.csr_search(ip, ix, d.astype(np.float32), V, q, 100, acc64=True, return_all=True)
     compare.check_topk_valid(allsc, ref_ids, ref_sc, rtol=RTOL)
     # forced exact pass and the fp64 walk on the same index (the latter rebuilds the copy without strips)

@@ -140,6 +140,11 @@ extern "C" int vs_index_set_option(vs_index* idx, const char* name, int value) {
         idx->bp_head_gemm_pref = value;
         return VS_OK;
     }
+    if (n == "postings_head_product") {
+        if (value < -1 || value > 1) return fail(VS_EINVAL, "postings_head_product: -1 = auto, 0 = operands straight from global memory, 1 = through the LDS ring");
+        idx->bp_head_product = value;
+        return VS_OK;
+    }
     if (n == "postings_head_tiles") {
         if (value < 0 || value > 4096) return fail(VS_EINVAL, "postings_head_tiles: 0 = auto, else tiles per pass of the head pre-pass");
         idx->bp_head_tiles = value;

@@ -121,4 +121,58 @@ __global__ __launch_bounds__(WD * WT * 64) void head_gemm_kernel(HeadArgs a) {
     }
 }
 
+// The product with BOTH operands through LDS (round 6; tools/gen_head_asm.py says how): a workgroup = 2 x 2 wide waves = 256 documents x
+// 32 tiles, its four waves load a stage's 64 KB together -- 32 KB per k-step and CU instead of the 64 KB of four independent wide
+// waves -- and keeps four k-steps of loads in flight (LDS-DMA into a ring of five k-step slots: all 160 KB of LDS, from address 0).
+template <int UNUSED>
+__global__ __launch_bounds__(256) void head_gemm_lds_kernel(HeadArgs a) {
+    const int n_tiles = a.n_tiles_dev[0];
+    const int nt = max(0, min(n_tiles - a.tile0, a.tile_cnt));
+    if (nt <= 0) return;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int wd = wv >> 1, wt_ = wv & 1;
+    const int ks = bp_head_pad(a.n_head) / 32, mbk = a.rows / 16;
+    const int tgroups = (nt + 31) / 32, npairs = (nt + 1) / 2;
+    const int druns = (a.rows + 255) / 256;
+    const int64_t items = a.n_blocks * druns * tgroups;
+    const uint4* strip4 = reinterpret_cast<const uint4*>(a.strip);
+    const uint32_t l16 = (uint32_t)lane * 16u;
+    // Work items = (run of 256 documents, tile group).  The tile groups of ONE run go to workgroups of the same XCD (blockIdx % 8) that
+    // run side by side: the run's strip operands miss that XCD's L2 once and hit it for the other groups -- the product is bound by the
+    // requests that leave the L2 (0.095 per clock and CU against 0.40 that hit; profiles/r06_head_lds.txt).
+    const int per_xcd = (int)gridDim.x >> 3, sets = per_xcd / tgroups;
+    const bool by_xcd = (gridDim.x & 7) == 0 && sets >= 1;
+    const int xcd = (int)blockIdx.x & 7, yy = (int)blockIdx.x >> 3;
+    if (by_xcd && yy >= sets * tgroups) return;
+    const int64_t n_runs = a.n_blocks * druns;
+    const int64_t first = by_xcd ? (int64_t)(xcd * sets + yy / tgroups) : (int64_t)blockIdx.x;
+    const int64_t stride = by_xcd ? (int64_t)(8 * sets) : (int64_t)gridDim.x;
+    const int64_t last = by_xcd ? n_runs : items;
+    for (int64_t item = first; item < last; item += stride) {
+        const int tg = by_xcd ? yy % tgroups : (int)(item % tgroups);
+        const int64_t r = by_xcd ? item : item / tgroups;
+        const int dr = (int)(r % druns);
+        const int64_t b = r / druns;
+        const int rows_b = (int)min((int64_t)a.rows, a.n_rows - b * a.rows);
+        // what this wave loads: strip groups 16 dr + 4 wv + i (clamped into the block), weight operands 16 tg + 4 wv + i (clamped into the pass)
+        uint32_t aoff[4], boff[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            aoff[i] = (uint32_t)min(dr * 16 + 4 * wv + i, mbk - 1) * 1024u + l16;
+            boff[i] = (uint32_t)min(tg * 16 + 4 * wv + i, npairs - 1) * (uint32_t)ks * 1024u + l16;
+        }
+        const unsigned long long abase = (unsigned long long)(strip4 + (size_t)b * ks * mbk * 64);
+        const unsigned long long bbase = (unsigned long long)a.wt;
+        // what it multiplies and stores: documents d0 .., tiles t0 .. (relative to tile0)
+        const int d0 = dr * 256 + wd * 128, t0 = tg * 32 + wt_ * 16;
+        const int n_docs16 = max(0, min(8, (rows_b - d0 + 15) / 16));
+        const int n_store = n_docs16 > 0 ? max(0, min(16, nt - t0)) : 0;
+        const unsigned long long obase = (unsigned long long)(a.out + head_out_index(min(t0, nt - 1), a.n_blocks, b, a.rows, min(d0, a.rows - 16), 0));
+        const unsigned long long ostride = (unsigned long long)a.n_blocks * (unsigned long long)mbk * 256ull;
+        const uint32_t so = (uint32_t)(lane & 7) * 32u + (uint32_t)(lane >> 4) * 8u;
+        head_item_asm_lds(abase, bbase, (uint32_t)mbk * 1024u, aoff, boff, (uint32_t)wv * 4096u, (uint32_t)wd * 8192u + l16, (uint32_t)wt_ * 8192u + l16, (uint32_t)ks,
+                          obase, ostride, so, (uint32_t)n_store, (uint32_t)n_docs16, a.head_mul);
+    }
+}
+
 }  // namespace vs

@@ -696,8 +696,15 @@ int bp_filter_search(vs_index* idx, const float* dq, int32_t B, int32_t k, int64
             hipLaunchKernelGGL(head_weights_kernel<0>, dim3(tiles_per_pass), dim3(256), 0, s, h);
             // (developer: waves of a workgroup, documents x tiles; 1xx = wide waves.  21 M docs x 1023 head columns x 1024 queries: 114: 56.4 ms,
             //  24: 76.5, 122: ~ 60 -- the product is bound by operand traffic, and a wide wave moves a third fewer bytes per MFMA)
-            static const int shape_env = getenv("VS_HEAD_SHAPE") ? atoi(getenv("VS_HEAD_SHAPE")) : 114;
-            if (shape_env == 24) hipLaunchKernelGGL((head_gemm_kernel<2, 4>), dim3(idx->cu_count), dim3(512), 0, s, h);
+            //  Round 6: 2 x 2 wide waves that share their operands through an LDS ring, four k-steps of LDS-DMA in flight, a document run's
+            //  tile groups side by side on one XCD (head_gemm_lds_kernel): 51.9 -> 37.1 ms.  A pass of fewer than 32 tiles leaves half of
+            //  such a workgroup idle: those go to the direct kernel.)
+            static const int shape_env = getenv("VS_HEAD_SHAPE") ? atoi(getenv("VS_HEAD_SHAPE")) : 0;
+            const bool ring = shape_env == 222 || (shape_env == 0 && (idx->bp_head_product == 1 || (idx->bp_head_product < 0 && tiles_per_pass >= 32 && idx->cu_count % 8 == 0)));
+            if (ring) {
+                VS_HIP(hipFuncSetAttribute((const void*)head_gemm_lds_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+                hipLaunchKernelGGL(head_gemm_lds_kernel<0>, dim3(idx->cu_count), dim3(256), 163840, s, h);
+            } else if (shape_env == 24) hipLaunchKernelGGL((head_gemm_kernel<2, 4>), dim3(idx->cu_count), dim3(512), 0, s, h);
             else hipLaunchKernelGGL((head_gemm_kernel<1, 4, 1>), dim3(idx->cu_count), dim3(256), 0, s, h);
             VS_HIP(hipGetLastError());
         }

@@ -228,6 +228,8 @@ struct vs_index {
     int bp_head_gemm_pref = -1;   // option "postings_head_gemm": -1 auto (= 1), 1 = the head columns' part of the sums by the head pre-pass (bp_head.h: up to 1024 columns
                                   // present in >= 1/8 of the documents), 0 = multiplied inside the walk, tile by tile (up to 512 columns in >= 1/4)
     int bp_head_tiles = 0;        // option "postings_head_tiles": tiles per pass of the head pre-pass (0 = as many as the scratch HBM holds)
+    int bp_head_product = -1;     // option "postings_head_product": the pre-pass's kernel: 0 = every wide wave loads its own operands, 1 = 2 x 2 waves share them
+                                  // through an LDS ring (bp_head.h: head_gemm_lds_kernel), -1 auto (the ring from 256 queries a pass on)
     bool bp_head_gemm = false;    // this copy's strips are served by the head pre-pass
     int bp_head_pref = -1;   // option "postings_head": -1 auto (columns present in >= 1/4 of the documents, at most 512), 0 = none, N = share 1/N
     vs::DevBuf bp_vmax;  // [2] uint32: float bits of max |value| (bounds the fixed-point walk's products), any-value-negative flag
