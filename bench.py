@@ -527,7 +527,7 @@ def secondary(index, batches, args, local_rank, device, headline_s):
         ms, kms = kernel_ms("mask_to_csr", lambda: sp.embed_mask_to_csr(emb, tok, VOC, SHIFT, NNZ_DOC, True), 50)
         byts = B * V * 4.0 + B * (NNZ_DOC + L) * 8.0 * 2
         out["embed_to_csr_B1024"] = {"what": "mask stage + to_sparse_csr() fused (vdr.py:152-169 + retriever.py:304): [1024, 29523] fp32 in, CSR out; replaces the two legs above in build_index",
-                                     "ms": ms, "kernel_ms": kms, "kernel": "mask_rows_fast_kernel (CSR emission) + scan_counts + slots_compact",
+                                     "ms": ms, "kernel_ms": kms, "kernel": "mask_rows_fast_kernel<G, 1> (one launch: select, rank, emit, place)",
                                      "roofline": roof("hbm", byts / (kms * 1e6), HBM_PEAK_GBS, "GB/s", achieved_is="one read of [B, V] fp32 + the slot runs written and compacted / kernel time")}
         Bh, Lh, H = 64, 256, 768
         hid = torch.randn((Bh, Lh, H), device=device, generator=g)
