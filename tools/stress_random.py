@@ -17,11 +17,12 @@ for it in range(iters):
     store = nat.VS_NONE if kind == 1 else int(rng.choice([nat.VS_F32, nat.VS_F16]))
     n = int(rng.choice([5000, 9000, 30000, 70000, 150000]))
     nnz = int(rng.choice([86, 86, 400])) if kind == 1 else int(rng.choice([300, 768]))
-    B = int(rng.choice([1, 3, 8, 9, 40, 129]))
+    B = int(rng.choice([1, 3, 8, 9, 40, 129, 300]))
     k = int(rng.choice([1, 10, 100, 300]))
     opts = dict(postings_align=int(rng.choice([0, 1])), postings_lanes=int(rng.choice([0, 4, 8])), postings_rows=int(rng.choice([0, 512, 1024, 1920])),
                 postings_chunks=int(rng.choice([0, 1, 3])), postings_head=int(rng.choice([-1, 0, 2, 16])), postings_quant=int(rng.choice([-1, 0])),
-                postings_walk=int(rng.choice([-1, 0, 4, 4, -1])), postings_pace=int(rng.choice([-1, 0, 4])), postings_arrange=int(rng.choice([0, 1])))
+                postings_walk=int(rng.choice([-1, 0, 4, 4, -1])), postings_pace=int(rng.choice([-1, 0, 4])), postings_arrange=int(rng.choice([0, 1])),
+                postings_head_product=int(rng.choice([-1, 0, 1])), postings_packed=int(rng.choice([-1, 0])))
     if n < 66000 and kind == 1:
         n = 70000                                                     # (the binary index takes the postings walk from 65 536 documents)
     idx = DeviceIndex.synthetic(it, 0, n, V, nnz, kind, 0, store)
