@@ -219,7 +219,7 @@ VS_API int  vs_index_prepare(vs_index* index, void* stream);
  *                       (flat worklists, two accumulator sets, streamed records: only in a `make EXPERIMENTAL=1` build).  A copy that does
  *                       not fit HBM falls back to the records, then to the CSR scan.  All return identical results; a change rebuilds the copy.
  *   "postings_head_gemm" -1 / 1 = the head columns' part of the filter sums comes from the head pre-pass (bp_head.h: one MFMA product per
- *                       pass of query tiles, columns in >= 1/8 of the documents, up to 1024), 0 = multiplied inside the walk (round 4)
+ *                       pass of query tiles, columns in >= 1/8 of the documents, up to 1024; from 1 M documents on, HBM permitting: >= 1/16, up to 1536), 0 = multiplied inside the walk (round 4)
  *   "postings_head_tiles" 0 = auto, else query tiles per pass of the head pre-pass (its scratch: 32 KB per tile and block)
  *   "postings_head_product" the pre-pass's kernel: 1 = workgroups of 2 x 2 waves share a k-step's operands through an LDS ring (LDS-DMA,
  *                       four k-steps in flight), 0 = every wave loads its own, -1 = auto (the ring from 32 tiles a pass on).  Identical results

@@ -418,7 +418,7 @@ def test_skewed_columns_device_generator_and_search():
 def test_dense_head_strips_keep_the_results(store, gemm):
     """Option postings_head: the columns present in >= 1/N of the documents move from posting lists to dense fp16 strips scored on
     the matrix cores -- inside the walk, tile by tile (postings_head_gemm = 0: auto N = 4, at most 512 columns), or by the head
-    pre-pass (bp_head.h, the default: auto N = 8, at most 1024).  Whatever N, the results are the CSR scan's, bit for bit; more
+    pre-pass (bp_head.h, the default: auto N = 8, at most 1024; an index of 1 M documents and more: 16 / 1536).  Whatever N, the results are the CSR scan's, bit for bit; more
     qualifying columns than the cap keep the most frequent."""
     n = 9000
     cap, auto_n = (1024, 8) if gemm else (512, 4)
@@ -445,7 +445,8 @@ def test_dense_head_strips_keep_the_results(store, gemm):
         seen[head] = info.head_columns
     assert seen[0] == 0
     assert seen[2] == int((df >= -(-n // 2)).sum()) and seen[-1] == min(cap, int((df >= -(-n // auto_n)).sum()))
-    assert seen[2] < seen[-1] <= seen[8] <= seen[64] <= cap and seen[64] > cap - 32       # (ties at the raised threshold can leave a few below the cap)
+    lo, mid = (seen[8], seen[-1]) if gemm else (seen[-1], seen[8])                      # (auto: 1/16 with the pre-pass, 1/4 inside the walk)
+    assert seen[2] < lo <= mid <= seen[64] <= cap and seen[64] > cap - 32                # (ties at the raised threshold can leave a few below the cap)
     if gemm:
         # the pre-pass in several passes over the batch's 3 tiles (2 + 1), and one tile at a time
         for tiles in (2, 1):
@@ -544,13 +545,13 @@ def test_baseline_sized_bag_of_token_index():
 
 
 def test_baseline_sized_skewed_index_with_head_strips():
-    """C3's secondary column law at C4's size: 21 015 324 docs x 768 nnz with Zipf column popularity; 1023 head columns become dense
+    """C3's secondary column law at C4's size: 21 015 324 docs x 768 nnz with Zipf column popularity; 1536 head columns become dense
     strips, their part of the sums comes from the head pre-pass (bp_head.h).  Bit-equal to the CSR scan on a batch slice, no query falls back."""
     n = 21_015_324
     idx = DeviceIndex.synthetic(0, 0, n, V, 768, synth.KIND_SKEW, 0, nat.VS_F32)
     q = oracle.synth_queries(1, 64, kind=synth.KIND_SKEW)
     ids, sc, info = _search(idx, q, 100, blocked_postings=-1)
-    assert info.last_path == 3 and info.last_fallbacks == 0 and info.head_columns >= 500
+    assert info.last_path == 3 and info.last_fallbacks == 0 and info.head_columns > 1024          # (the wide head of a large index)
     ref_ids, ref_sc, info = _search(idx, q[20:28], 100, blocked_postings=0)
     assert info.last_path == 1
     assert (ids[20:28] == ref_ids).all() and (sc[20:28] == ref_sc).all()

@@ -205,7 +205,8 @@ __device__ __forceinline__ void {name}(unsigned long long abase, unsigned long l
 # The loop is unrolled over 10 k-steps (2 operand sets x 5 slots); the k-step counter is tested after each.
 LSG = {"asg": 88, "bsg": 90, "osg": 92}
 LA, LB = [32, 96], [64, 128]      # operand sets: A v[32:63] / v[96:127], B v[64:95] / v[128:159]
-NSLOT = 5
+LEAD = 3 if "lead3" in VARIANT else 4      # k-steps of DMA in flight (experiment: lead3)
+NSLOT = LEAD + 1
 
 
 def gen_lds():
@@ -252,17 +253,17 @@ def gen_lds():
     for r in range(256):
         emit(f"v_accvgpr_write_b32 a{r}, 0")
     # prologue: k-steps 0 .. 3 on their way, operand set 0 <- slot 0
-    for c in range(4):
+    for c in range(LEAD):
         out.extend(dma(c))
-    emit("s_waitcnt vmcnt(24)")
+    emit(f"s_waitcnt vmcnt({8 * (LEAD - 1)})")
     emit("s_barrier")
     out.extend(lreads(0, 0))
     emit("1:")
-    for c in range(2 * NSLOT):
+    for c in range(2 * NSLOT if NSLOT % 2 else NSLOT):
         emit("s_waitcnt lgkmcnt(0)")
         mf = mfmas(c % 2)
-        others = ["s_waitcnt vmcnt(16)" + ("" if "nobar" in VARIANT else "\n\ts_barrier")] + lreads((c + 1) % NSLOT, (c + 1) % 2)
-        d = dma((c + 4) % NSLOT)
+        others = [f"s_waitcnt vmcnt({8 * (LEAD - 2)})" + ("" if "nobar" in VARIANT else "\n\ts_barrier")] + lreads((c + 1) % NSLOT, (c + 1) % 2)
+        d = dma((c + LEAD) % NSLOT)
         # 4 MFMAs, the wait + barrier, then a read every 2 MFMAs (16 reads), then the DMA pieces (3 instructions each) every 3 MFMAs
         seq = []
         mi = 0

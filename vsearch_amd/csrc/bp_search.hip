@@ -267,12 +267,22 @@ int bp_build(vs_index* idx, hipStream_t s) {
         DevBuf nh;
         VS_TRY(nh.alloc(4));
         VS_TRY(idx->bp_hmap.alloc((size_t)V * 2));
-        // head pre-pass (bp_head.h, default): columns in >= 1/8 of the documents, up to 1024; multiplied inside the walk: >= 1/4, up to 512
+        // head pre-pass (bp_head.h, default): columns in >= 1/8 of the documents, up to 1024 -- from 1 M documents on, where the HBM has
+        // room: >= 1/16, up to 1536 (the proof's slack grows with the columns: on a few thousand documents the wider head costs
+        // fallbacks, tests/test_gpu_filter.py::test_head_strips_across_value_ranges); multiplied inside the walk: >= 1/4, up to 512.  (Round 6: with the product through the LDS ring a head column costs ~ 22 us per 1024 queries at 21 M
+        // docs, and the densest lists of the tail more: Zipf 21 M docs, columns 1024 / 1280 / 1536 / 1792 / 2048: 157.7 / 154.2 / 152.7 /
+        // 151.3 / 150.9 ms per search, 9 GB of strips per 256 columns.)
         static const int gemm_env = getenv("VS_BP_HEAD_GEMM") ? atoi(getenv("VS_BP_HEAD_GEMM")) : -2;   // (developer override of "postings_head_gemm")
         if (gemm_env > -2) idx->bp_head_gemm_pref = gemm_env;
         const bool gemm = idx->bp_head_gemm_pref != 0 && kQT == 8;
+        static const int cap_env = getenv("VS_BP_HEAD_CAP") ? atoi(getenv("VS_BP_HEAD_CAP")) : 0;      // (developer: another cap of the pre-pass's columns, <= 2048)
+        // the larger cap where its strips, the tail's records (at most 4 bytes a posting) and a pass's scratch (48 GB at most) all fit
+        VS_HIP(hipMemGetInfo(&free_b, &total_b));
+        const size_t strips_hi = (size_t)n_blocks * kBpHeadCapGemm * idx->bp_rows * 2;
+        const bool wide = idx->n_rows >= (1 << 20) && free_b >= strips_hi + (size_t)idx->nnz * 4 + ((size_t)48 << 30) + margin;
+        const int cap_gemm = cap_env > 0 ? std::min(cap_env, 2048) : wide ? kBpHeadCapGemm : kBpHeadCapGemmLow;
         hipLaunchKernelGGL(bp_head_select_kernel<0>, dim3(1), dim3(kScanThreads), 0, s, df_nnz, V,
-                           (unsigned long long)ceil_div64(idx->n_rows, idx->bp_head_pref > 0 ? idx->bp_head_pref : (gemm ? 8 : 4)), gemm ? kBpHeadCapGemm : kBpHeadCap,
+                           (unsigned long long)ceil_div64(idx->n_rows, idx->bp_head_pref > 0 ? idx->bp_head_pref : (gemm ? (wide ? 16 : 8) : 4)), gemm ? cap_gemm : kBpHeadCap,
                            idx->bp_hmap.as<uint16_t>(), nh.as<int32_t>());
         VS_HIP(hipGetLastError());
         int32_t h_n = 0;

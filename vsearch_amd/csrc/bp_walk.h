@@ -130,7 +130,8 @@ __global__ __launch_bounds__(kScanThreads) void bp_count_kernel(const uint32_t* 
 // the lists win below p ~ 1/7; the default threshold is 1/4.  hmap[c] = strip index of column c, 0xFFFF = ordinary column.
 constexpr int kBpHeadCap = 512;          // multiplied inside the walk (their weights live in its LDS)
 constexpr int kHeadOutShift = 14;        // the head pre-pass hands its sums over as uint16 in units of 2^14 (a sum < 2^30 fits; < 2^14 units lost: bp_head_slack)
-constexpr int kBpHeadCapGemm = 1024;     // served by the head pre-pass (bp_head.h)
+constexpr int kBpHeadCapGemm = 1536;     // served by the head pre-pass (bp_head.h), where the HBM has room for their strips;
+constexpr int kBpHeadCapGemmLow = 1024;  // ... where it is tight
 // One workgroup.  Deterministic: when more than `cap` columns reach `thresh`, the threshold rises to the smallest document
 // count that leaves at most `cap` of them; strip indexes follow column order.
 template <int UNUSED>

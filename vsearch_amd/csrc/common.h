@@ -226,7 +226,7 @@ struct vs_index {
     int bp_n_head = 0;
     float bp_vmax_f = 1.f;   // max |value| of the index (bp_build)
     int bp_head_gemm_pref = -1;   // option "postings_head_gemm": -1 auto (= 1), 1 = the head columns' part of the sums by the head pre-pass (bp_head.h: up to 1024 columns
-                                  // present in >= 1/8 of the documents), 0 = multiplied inside the walk, tile by tile (up to 512 columns in >= 1/4)
+                                  // present in >= 1/8 of the documents; from 1 M documents on, HBM permitting, 1536 in >= 1/16), 0 = multiplied inside the walk, tile by tile (up to 512 columns in >= 1/4)
     int bp_head_tiles = 0;        // option "postings_head_tiles": tiles per pass of the head pre-pass (0 = as many as the scratch HBM holds)
     int bp_head_product = -1;     // option "postings_head_product": the pre-pass's kernel: 0 = every wide wave loads its own operands, 1 = 2 x 2 waves share them
                                   // through an LDS ring (bp_head.h: head_gemm_lds_kernel), -1 auto (the ring from 256 queries a pass on)
