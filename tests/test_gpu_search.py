@@ -377,6 +377,18 @@ def test_four_processes_sharing_the_gpu_keep_their_results(kind):
     assert r.returncode == 0 and len(lines) == 4 and all(": 0 bad searches" in l and "path 3" in l for l in lines), r.stdout[-2000:] + r.stderr[-1000:]
 
 
+@pytest.mark.parametrize("kind", ["dense", "mask"])
+def test_four_processes_sharing_the_gpu_dense_and_mask_kernels(kind):
+    """The same rig on the dense MFMA search and on the encoder's mask kernels: four processes, every result against
+    torch.  The fused mask -> CSR kernel is the one kernel here whose workgroups wait for each other (a workgroup places its rows once
+    the workgroups with lower tickets have published their totals): with four processes on the GPU they are not all resident at once."""
+    import os, subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(repo, "tools", "contention_check.py"), "4", "60", kind], capture_output=True, text=True, timeout=900)
+    lines = [l for l in r.stdout.splitlines() if "bad searches" in l]
+    assert r.returncode == 0 and len(lines) == 4 and all(": 0 bad searches" in l for l in lines), r.stdout[-2000:] + r.stderr[-1000:]
+
+
 def test_reserve_and_append_equals_single_shot():
     """Shard-by-shard construction (vs_index_create_reserved + vs_index_append_csr) == one-shot creation."""
     n = 1500

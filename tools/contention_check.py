@@ -1,5 +1,7 @@
 """N processes sharing ONE GPU, each searching its own synthetic shard over and over: every filter + refine result against the CSR scan of
-the same index.  python tools/contention_check.py [processes] [searches] [plain|bot|zipf]
+the same index.  python tools/contention_check.py [processes] [searches] [plain|bot|zipf|dense|mask]
+(dense: the MFMA search of a dense index against torch; mask: the encoder's mask stage and the fused mask -> CSR kernel -- whose workgroups
+wait for each other's totals in ticket order: under contention they are not all resident at once -- against torch.)
 
 Why: with four or more processes other kernels' waves share the CUs and stretch the timing windows inside a workgroup; round 5 had a
 version of the quad walk that passed every single-process test and lost whole blocks of candidates in 10 - 25 % of the searches here
@@ -13,7 +15,57 @@ sys.path.insert(0, repo)
 KINDS = {"plain": (20_000, 768, 0, "VS_F32"), "bot": (60_000, 86, 1, "VS_NONE"), "zipf": (40_000, 768, 2, "VS_F32")}
 
 
+def child_dense(rank, reps):
+    import torch
+    from vsearch_amd.device_index import DeviceIndex
+    g = torch.Generator(device="cuda").manual_seed(100 + rank)
+    V, n, b = 4096, 30_000, 64
+    mat = torch.zeros((n, V), device="cuda")
+    c = torch.rand((n, V), device="cuda", generator=g).topk(96, dim=1).indices
+    mat.scatter_(1, c, 0.01 + 3 * torch.rand(c.shape, device="cuda", generator=g))
+    q = torch.zeros((b, V), device="cuda")
+    qc = torch.rand((b, V), device="cuda", generator=g).topk(64, dim=1).indices
+    q.scatter_(1, qc, 0.01 + 3 * torch.rand(qc.shape, device="cuda", generator=g))
+    idx = DeviceIndex.from_dense(mat)
+    want = (q.double() @ mat.double().T).topk(100, dim=1)
+    nbad = 0
+    for i in range(reps):
+        ids, sc = idx.search(q, 100)
+        # (scores to 1e-4 against fp64; ids where the fp64 scores are not tied to that tolerance)
+        ok = torch.allclose(sc.double(), want.values, rtol=1e-4, atol=0) and bool(((ids == want.indices) | (torch.abs(sc.double() - want.values) <= 1e-4 * want.values)).all())
+        nbad += 0 if ok else 1
+    print(f"rank {rank} dense: {nbad} bad searches of {reps} (path dense, walk -)", flush=True)
+    return 1 if nbad else 0
+
+
+def child_mask(rank, reps):
+    import torch
+    from vsearch_amd.ir.utils import sparse as sp
+    g = torch.Generator(device="cuda").manual_seed(200 + rank)
+    B, V, K, L, VOC, SHIFT = 700, 29523, 768, 64, 30522, 999
+    emb = torch.rand((B, V), device="cuda", generator=g) * 3
+    emb[5] = 0.0
+    tok = torch.randint(SHIFT, VOC, (B, L), device="cuda", generator=g)
+    mask = torch.zeros_like(emb, dtype=torch.bool)
+    mask.scatter_(1, emb.topk(K, dim=1).indices, True)
+    mask.scatter_(1, tok - SHIFT, True)
+    dense = emb * mask
+    want = dense.to_sparse_csr()
+    nbad = 0
+    for i in range(reps):
+        rp, ci, va = sp.embed_mask_to_csr(emb, tok, VOC, SHIFT, K, True)
+        ok = bool((rp == want.crow_indices()).all()) and ci.numel() == want.col_indices().numel() and bool((ci == want.col_indices()).all()) and bool((va == want.values()).all())
+        e2 = emb.clone()
+        sp.apply_embed_mask_(e2, tok, VOC, SHIFT, K, True)
+        ok = ok and bool((e2 == dense).all())
+        nbad += 0 if ok else 1
+    print(f"rank {rank} mask: {nbad} bad searches of {reps} (path mask, walk -)", flush=True)
+    return 1 if nbad else 0
+
+
 def child(rank, reps, kind):
+    if kind == "dense": return child_dense(rank, reps)
+    if kind == "mask": return child_mask(rank, reps)
     import bench, torch
     from collections import Counter
     from vsearch_amd import _native as nat
