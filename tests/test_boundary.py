@@ -160,3 +160,13 @@ def test_src_ir_import_shim():
     from src.ir.utils.sparse import build_bow_mask       # noqa: F401
     import vsearch_amd.ir as ir
     assert Retriever is ir.Retriever
+
+
+@pytest.mark.parametrize("gen,args,header", [("gen_quad_asm.py", ["4"], "bp_quad_asm.h"), ("gen_bq_asm.py", ["8"], "bp_bq_asm.h"), ("gen_head_asm.py", [], "bp_head_asm.h")])
+def test_generated_asm_headers_match_their_generators(tmp_path, gen, args, header):
+    """The walks' inner loops and the head product are generated inline-asm statements (tools/gen_*_asm.py -> csrc/*_asm.h): the committed
+    header is what the committed generator writes (its first line names the output path)."""
+    out = tmp_path / header
+    subprocess.check_call([sys.executable, os.path.join(REPO, "tools", gen)] + args + [str(out)], cwd=REPO, stdout=subprocess.DEVNULL)
+    want = open(os.path.join(REPO, "vsearch_amd", "csrc", header)).read().split("\n", 1)[1]
+    assert out.read_text().split("\n", 1)[1] == want, f"{header} is not what tools/{gen} {' '.join(args)} generates"
