@@ -383,6 +383,18 @@ __global__ __launch_bounds__(kScanThreads) void bp_quad_topk(BpArgs a) {
             if (b + 1 < b1) base_cur = a.base[b + 1];
             if (a.gtau && tid < nq) { const unsigned long long g = a.gtau[q0 + tid]; if (g > tau[tid]) tau[tid] = g; }
             lds_barrier();                                               // the block's sums are complete
+            // The NEXT block's cold start: the epilogue below drains every load a wave had in flight, and the next walk's first steps would
+            // each wait for a line that leaves the L2.  One dword per lane from the 64 lines of this wave's first 8 steps (lane l: step
+            // l >> 3, lane group (l >> 1) & 3, half l & 1 of the 256-byte chunk) brings them into the XCD's L2 while the epilogue runs;
+            // the value is never used (the register is held until the loads are back: the compiler does not know it is a load's).
+            // (measured, 21 M docs: 8 steps 127.2 ms, 4 steps 129.1, 16 steps 131.3 -- 8 steps of 32 workgroups are the XCD's 4 MB --, none 130.2;
+            //  VS_BP_KNOB=512 turns it off)
+            uint32_t pf = 0;
+            if ((a.knob & 512) == 0 && b + 1 < b1 && (uint32_t)(lane >> 3) < trips) {
+                const uint32_t dx = *reinterpret_cast<const uint32_t*>(smem + desc_lds + (uint32_t)(lane >> 3) * 512u + (uint32_t)wv * 32u + (uint32_t)((lane >> 1) & 3) * 8u);
+                const char* pl = a.rec + (size_t)base_cur * kQuadChunkBytes + (dx & 0xFFFFFF00u) + (uint32_t)(lane & 1) * 128u;
+                asm volatile("global_load_dword %0, %1, off" : "=v"(pf) : "v"(pl) : "memory");
+            }
             lap(2);
             // epilogue: 1024 documents at a time, one per thread: its QT sums -> order keys -> candidates; prune when a buffer could overflow
             int32_t thr[QT];
@@ -521,6 +533,7 @@ __global__ __launch_bounds__(kScanThreads) void bp_quad_topk(BpArgs a) {
                 }
                 if constexpr (TM != 0) { if (any) tacc[3] += (uint32_t)((long long)__builtin_readcyclecounter() - t_cut); }      // (phase clocks: "dense" = inside the cuts)
             }
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf) : : "memory");   // (the prefetch above has landed -- long ago)
             lap(4);
             if constexpr (TM != 0) tacc[5] += 1u;
             if (b + 1 >= b1) break;
